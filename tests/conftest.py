@@ -1,0 +1,34 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def load_golden(name):
+    """Golden vectors captured from the reference's own leaf files by
+    oracle/make_golden.py (plain .npz, allow_pickle=False)."""
+    with np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False) as z:
+        return {k: torch.from_numpy(np.array(z[k])) for k in z.files}
+
+
+@pytest.fixture
+def golden():
+    return load_golden
+
+
+def rel_err(a, b):
+    """max |a-b| / max |b|  (norm-wise relative error, the 1e-4 fp32 bar of north_star)."""
+    a, b = a.double(), b.double()
+    den = b.abs().max().clamp_min(1e-30)
+    return float((a - b).abs().max() / den)
