@@ -1,0 +1,234 @@
+"""bench.py — render + Chamfer forward+backward images/s on MI355X (BASELINE.json metric).
+
+A step = one pass of the hot path over one batch of synthetic input already resident in HBM:
+  sampler fwd (Philox in-kernel) -> Chamfer(pred, gt) fwd -> raster fwd (silhouette+depth)
+  -> L1(sil) + L1(depth) -> backward of all of it to d/d(v,q,t) [-> RCCL all-reduce if N>1].
+Workload (config.workload): BASELINE configs[2] = C3: B=64 per GPU, K=32 sphere primitives,
+256x256, n=256 points per primitive (N=8192) vs M=2048 GT points.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK_TFLOPS = 157.3     # fp32 vector peak (packed FMA)
+
+
+def synth_inputs(B, K, M, seed, device):
+    """SURVEY.md 8d synthetic inputs (seed 1234 = reference config.py:20)."""
+    g = torch.Generator().manual_seed(seed)
+    v = (torch.rand(B, K, 3, generator=g) + 0.1) / torch.tensor([8.0, 10.0, 10.0])   # vpnet_one_resnet.py:71,84
+    q = torch.rand(B, K, 4, generator=g)                                               # sigmoid range (:72)
+    t = 0.35 * (torch.rand(B, K, 3, generator=g) * 2 - 1)                              # tanh range (:73), inside the frustum
+    gt_points = torch.rand(B, M, 3, generator=g) - 0.5                                 # dataset.py:165
+    return torch.cat([v, q, t], 2).to(device), gt_points.to(device)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--batch', type=int, default=64, help='samples per GPU')
+    ap.add_argument('--prims', type=int, default=32)
+    ap.add_argument('--points', type=int, default=256, help='sampled points per primitive')
+    ap.add_argument('--gt-points', type=int, default=2048)
+    ap.add_argument('--size', type=int, default=256)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample', type=int, default=2, help='images in the CPU baseline sample')
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d'
+                     % (args.gpus, args.gpus))
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    import vpn_amd
+    from vpn_amd import _lib
+    from vpn_amd.dist import GradAllReduce
+    _lib.lib()
+
+    B, K, n, M, H = args.batch, args.prims, args.points, args.gt_points, args.size
+    W = H
+    kinds = vpn_amd.kinds_tensor([vpn_amd.SPHERE] * K, dev)      # reference default: all spheres (config.py:33-34)
+    # each rank owns global samples [rank*B, (rank+1)*B): weak scaling, per-GPU work fixed
+    params_all, gt_all = synth_inputs(B * world, K, M, 1234, dev)
+    params = params_all[rank * B:(rank + 1) * B].clone().requires_grad_(True)
+    gt_points = gt_all[rank * B:(rank + 1) * B].contiguous()
+    cam = torch.tensor([[1.0, 0.0, 0.0]], device=dev).expand(B, 3).contiguous()    # train.py:172-174
+    # GT silhouette / depth: render of a second primitive set (seed 4321), silhouette thresholded at 0.5
+    p2, _ = synth_inputs(B * world, K, M, 4321, dev)
+    with torch.no_grad():
+        a2, d2 = vpn_amd.RasterFunction.apply(p2[rank * B:(rank + 1) * B].contiguous(), kinds, cam, H, W,
+                                              vpn_amd.config.RASTER_SIGMA, vpn_amd.config.RASTER_GAMMA,
+                                              vpn_amd.config.RASTER_Z_FAR)
+    gt_sil = (a2 > 0.5).float()
+    gt_depth = d2.clone()
+    reducer = GradAllReduce(B * world, K, dev, rank, world) if world > 1 else None
+    cd_fn = vpn_amd.ChamferDistanceLoss()
+    sigma, gamma, z_far = vpn_amd.config.RASTER_SIGMA, vpn_amd.config.RASTER_GAMMA, vpn_amd.config.RASTER_Z_FAR
+
+    def step(i):
+        params.grad = None
+        pts = vpn_amd.Sampling.sample_primitives(params, kinds, n, seed=1234 + i, sample_base=rank * B)
+        cd = cd_fn(pts, gt_points)
+        alpha, depth = vpn_amd.RasterFunction.apply(params, kinds, cam, H, W, sigma, gamma, z_far)
+        loss = cd + (alpha - gt_sil).abs().mean() + (depth - gt_depth).abs().mean()
+        loss.backward()
+        if reducer is not None:
+            return reducer.reduce(params.grad, loss)
+        return params.grad, loss
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+    ms_per_step = dt / args.steps * 1e3
+    value = B * world * args.steps / dt
+
+    # ---- per-entry-point device time (HIP events on the launch stream), same steps again
+    ksteps = max(5, min(args.steps, 20))
+    with _lib.KernelTimer() as kt:
+        for i in range(ksteps):
+            step(i)
+    ktimes = kt.summary()          # name -> (calls, mean ms); vpn_chamfer_nn mixes both directions
+    # split the two chamfer directions (first call of a step = p1->p2, second = p2->p1)
+    nn = [a.elapsed_time(b) for name, a, b in kt.records if name == 'vpn_chamfer_nn']
+    nn_fwd = sum(nn[0::2]) / max(1, len(nn[0::2]))
+    nn_rev = sum(nn[1::2]) / max(1, len(nn[1::2]))
+    phases = {k: round(v[1] * 1e3, 2) for k, v in ktimes.items()}      # microseconds
+    phases['vpn_chamfer_nn[p1->p2]'] = round(nn_fwd * 1e3, 2)
+    phases['vpn_chamfer_nn[p2->p1]'] = round(nn_rev * 1e3, 2)
+    phases.pop('vpn_chamfer_nn', None)
+
+    # algorithmic bytes per launch (SURVEY.md 8d per-image figures x B; stated in DESIGN.md)
+    N = K * n
+    alg = {
+        'vpn_chamfer_nn[p1->p2]': B * (12 * (N + M) + 8 * N),
+        'vpn_chamfer_nn[p2->p1]': B * (12 * (N + M) + 8 * M),
+        'vpn_raster_fwd': B * (40 * K + 8 * H * W),
+        'vpn_raster_bwd': B * (8 * H * W + 40 * K + 40 * K),
+        'vpn_sample_fwd': B * (40 * K + 12 * N),
+        'vpn_sample_bwd': B * (12 * N + 40 * K + 40 * K),
+        'vpn_chamfer_bwd': B * (12 * (N + M) + 8 * (N + M) + 12 * N),
+    }
+    flops = {   # fp32 vector ops actually issued per launch (for the VALU view)
+        'vpn_chamfer_nn[p1->p2]': 12.0 * B * N * M,
+        'vpn_chamfer_nn[p2->p1]': 12.0 * B * N * M,
+    }
+    dom = max((k for k in phases if k in alg), key=lambda k: phases[k])
+    dom_s = phases[dom] * 1e-6
+    achieved = alg[dom] / dom_s / 1e9
+    roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': None,
+                'algorithmic_bytes_per_launch': alg[dom], 'avg_launch_us': phases[dom]}
+    if dom in flops:
+        roofline['valu_tflops'] = round(flops[dom] / dom_s / 1e12, 2)
+        roofline['valu_frac_of_fp32_peak'] = round(flops[dom] / dom_s / 1e12 / VALU_PEAK_TFLOPS, 4)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(params_all[:args.cpu_sample].detach().cpu(), gt_all[:args.cpu_sample].cpu(),
+                           gt_sil[:args.cpu_sample].cpu(), gt_depth[:args.cpu_sample].cpu(), K, n, H, W,
+                           sigma, gamma, z_far, params, kinds, cam, gt_points, gt_sil, gt_depth, vpn_amd)
+
+    if rank == 0:
+        out = {
+            'metric': 'render+Chamfer fwd+bwd images/sec', 'value': round(value, 1), 'unit': 'images/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'C3: B=%d/GPU, K=%d sphere primitives, %dx%d silhouette+depth, n=%d pts/prim '
+                                   '(N=%d) vs M=%d GT points, Chamfer+L1 fwd+bwd' % (B, K, H, W, n, N, M),
+                       'global_batch': B * world, 'parallelism': 'dp%d' % world,
+                       'collective': 'rccl all-reduce %d B/step' % ((B * world * K * 10 + 1) * 4) if world > 1 else 'none'},
+            'roofline': roofline, 'kernel_us': phases,
+        }
+        if cpu is not None:
+            out['cpu_baseline'] = cpu
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(params, gt_points, gt_sil, gt_depth, K, n, H, W, sigma, gamma, z_far,
+                 gpu_params, kinds, cam, gpu_gt_points, gpu_gt_sil, gpu_gt_depth, vpn_amd):
+    """The oracle (CPU PyTorch restatement of the reference path, dense B*N*M Chamfer) timed on
+    the host cores on a bounded sample of the same workload, and compared with the HIP path on
+    exactly those samples."""
+    from oracle import vpn_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    S = params.shape[0]
+    u = O.philox_uniforms(1234, 0, S, K, n)
+    kl = [0] * K
+    camc = torch.tensor([[1.0, 0.0, 0.0]]).expand(S, 3).contiguous()
+
+    def run():
+        p = params.clone().requires_grad_(True)
+        total = 0.0
+        for b in range(S):                               # one image per chunk: dense tensors stay < 2 GB
+            pb = p[b:b + 1]
+            pts = O.sample_primitives(pb, kl, u[b:b + 1])
+            cd = O.chamfer_loss(pts, gt_points[b:b + 1], each_batch=True).sum() / S
+            a, d = O.raster(pb, kl, camc[b:b + 1], H, W, sigma, gamma, z_far)
+            loss = cd + (a - gt_sil[b:b + 1]).abs().sum() / (S * H * W) + (d - gt_depth[b:b + 1]).abs().sum() / (S * H * W)
+            loss.backward()
+            total += float(loss)
+        return total, p.grad
+
+    run()                                                # warm-up
+    t0 = time.perf_counter()
+    loss_c, grad_c = run()
+    dt = time.perf_counter() - t0
+    # same samples on the GPU (explicit uniforms = the Philox draws the kernel makes itself)
+    pg = gpu_params[:S].detach().clone().requires_grad_(True)
+    pts = vpn_amd.Sampling.sample_primitives(pg, kinds, n, seed=1234, sample_base=0)
+    cd = vpn_amd.ChamferDistanceLoss()(pts, gpu_gt_points[:S])
+    a, d = vpn_amd.RasterFunction.apply(pg, kinds, cam[:S].contiguous(), H, W, sigma, gamma, z_far)
+    loss_g = cd + (a - gpu_gt_sil[:S]).abs().mean() + (d - gpu_gt_depth[:S]).abs().mean()
+    loss_g.backward()
+    gerr = float((pg.grad.cpu() - grad_c).abs().max() / grad_c.abs().max())
+    lerr = abs(float(loss_g) - loss_c) / abs(loss_c)
+    return {'value': round(S / dt, 3), 'unit': 'images/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d images of the same workload (1 warm-up + 1 timed pass, %.1f s), torch CPU fp32, '
+                      'dense B*N*M Chamfer as chamfer_distance.py:14-23' % (S, dt),
+            'parity_vs_gpu': {'loss_rel': float('%.3g' % lerr), 'grad_rel': float('%.3g' % gerr)}}
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,133 @@
+/* vpn_hip.h — C ABI of libvpn_hip.so, the MI355X (gfx950) implementation of the
+ * volumetric-primitive hot path (surface sampler, Chamfer nearest-neighbour
+ * reduction, primitive soft raster), forward and analytic backward.
+ *
+ * Conventions:
+ *  - every pointer is DEVICE memory owned by the caller (outputs and workspaces
+ *    included); the library allocates nothing and keeps no global state
+ *    (contrast: the reference's module-global renderer, vertex_renderer.py:7,18);
+ *  - all tensors are contiguous fp32 unless stated, indices are int32;
+ *  - `stream` is a hipStream_t passed as void*; kernels are only enqueued, no
+ *    entry point synchronises with the host (the reference syncs through
+ *    .item() at vertex_renderer.py:30-35 and cuboid.py:96);
+ *  - return value: 0 on success, a positive hipError_t value if a launch failed,
+ *    or a negative VPN_E_* code for rejected arguments.  Unlike the reference's
+ *    emd extension (emd_cuda.cu:236-281, result ignored at emd_module.py:56) the
+ *    host binding must raise on non-zero.
+ *
+ * Each entry point cites the reference interface it replaces (file:line relative
+ * to the reference root).  The Python binding a maintainer adds is in
+ * INTEGRATION.md (ctypes).
+ */
+#ifndef VPN_HIP_H
+#define VPN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VPN_ABI_VERSION 1
+
+/* primitive kinds (reference: train.py:106-116 cuboids first, then spheres, cones are stubs) */
+#define VPN_SPHERE 0
+#define VPN_CUBOID 1
+
+/* negative return codes */
+#define VPN_E_BADARG  (-1)   /* null pointer / non-positive size              */
+#define VPN_E_TOOBIG  (-2)   /* size above a documented limit                 */
+#define VPN_E_KIND    (-3)   /* unknown primitive kind (e.g. cone: sampling.py:39-45 is `pass`) */
+
+/* packed primitive parameters: [B, K, 10] = (v0 v1 v2 | q0 q1 q2 q3 | t0 t1 t2)
+ * — the reference passes K separate (B,3),(B,4),(B,3) tensors (train.py:117).  */
+#define VPN_PARAM_STRIDE 10
+/* largest K the raster / sampler stage in LDS */
+#define VPN_MAX_PRIMS 1024
+
+int vpn_abi_version(void);
+/* static description of a code returned by any entry point below */
+const char* vpn_error_string(int code);
+
+/* ------------------------------------------------------------------ sampler
+ * Replaces Sampling.sphere_sampling / cuboid_sampling (modules/sampling/
+ * sampling.py:11-37, sphere.py:22-43, cuboid.py:8-101), transform_points
+ * (modules/transform/transform.py:6-9) and the per-primitive loop + torch.cat of
+ * sample_predict_points (train.py:105-120) in one launch.
+ *   params [B,K,10], kinds [K] int32 (device), points [B, K*n, 3] primitive-major.
+ *   u: explicit uniform draws [B,K,n,3] (sphere: u0 = elev draw, u1 = azim draw,
+ *      sphere.py:26-27; cuboid: the three draws of cuboid.py:66), or NULL to
+ *      generate them in-kernel with Philox4x32-10 keyed by (seed, sample_base+b,
+ *      k, point) so the result does not depend on how the batch is sharded.
+ */
+int vpn_sample_fwd(const float* params, const int32_t* kinds, const float* u,
+                   uint64_t seed, uint64_t sample_base, int B, int K, int n,
+                   float* points, void* stream);
+/* grad_params [B,K,10] is WRITTEN (not accumulated). */
+int vpn_sample_bwd(const float* params, const int32_t* kinds, const float* u,
+                   uint64_t seed, uint64_t sample_base, int B, int K, int n,
+                   const float* grad_points, float* grad_params, void* stream);
+
+/* ---------------------------------------------------------------- transform
+ * Replaces transform_points / rotate_points (modules/transform/transform.py:6-9,
+ * rotate.py:7-25, translate.py:4-8): out = R(q) p + t.  t may be NULL (pure
+ * rotation).  points/out [B,N,3], q [B,4], t [B,3].
+ */
+int vpn_transform_fwd(const float* points, const float* q, const float* t,
+                      int B, int N, float* out, void* stream);
+/* grad_points [B,N,3], grad_q [B,4], grad_t [B,3] are written; any may be NULL. */
+int vpn_transform_bwd(const float* points, const float* q, const float* grad_out,
+                      int B, int N, float* grad_points, float* grad_q, float* grad_t,
+                      void* stream);
+
+/* ------------------------------------------------------------------ Chamfer
+ * Replaces the dense B*N*M expression of ChamferDistanceLoss.forward
+ * (modules/loss/chamfer_distance.py:14-23).  p1 [B,N,3], p2 [B,M,3].
+ *   dist1[b,i] = min_j ||p1_i - p2_j|| (NON-squared), idx1 = argmin_j with the
+ *   reference's tie rule (lowest index among equal sqrt values), dist2/idx2 the
+ *   other direction.  Bit-exact with the fp32 reference expression.
+ */
+int vpn_chamfer_fwd(const float* p1, const float* p2, int B, int N, int M,
+                    float* dist1, int32_t* idx1, float* dist2, int32_t* idx2, void* stream);
+/* One direction only (one kernel launch): for every query point the nearest target point.
+ * queries [B,Nq,3], targets [B,Nt,3] -> dist [B,Nq], idx [B,Nq].  vpn_chamfer_fwd is two of these. */
+int vpn_chamfer_nn(const float* queries, const float* targets, int B, int Nq, int Nt,
+                   float* dist, int32_t* idx, void* stream);
+/* loss_b[b] = w1*mean_i dist1[b,i] + w2*mean_j dist2[b,j]   (chamfer_distance.py:25-28) */
+int vpn_chamfer_loss(const float* dist1, const float* dist2, int B, int N, int M,
+                     float w1, float w2, float* loss_b, void* stream);
+/* Backward of loss_b w.r.t. the points given grad_loss_b [B].  grad_p1 [B,N,3] /
+ * grad_p2 [B,M,3] are written; either may be NULL.  A coincident pair gives NaN
+ * like the reference's autograd (0/0). */
+int vpn_chamfer_bwd(const float* p1, const float* p2,
+                    const float* dist1, const int32_t* idx1,
+                    const float* dist2, const int32_t* idx2,
+                    const float* grad_loss_b, int B, int N, int M, float w1, float w2,
+                    float* grad_p1, float* grad_p2, void* stream);
+
+/* ------------------------------------------------------------------- raster
+ * Replaces VertexRenderer.render (modules/render/vertex_renderer.py:14-26) and the
+ * per-sample loop of SilhouetteLoss.forward (modules/loss/silhouette.py:16-20):
+ * one launch renders the whole batch straight from the primitive parameters (the
+ * reference meshes the primitives first, modules/meshing/sphere.py:8-27, and
+ * rasterises the mesh with kaolin's DIBRenderer, which is not in its tree).
+ *   cam [B,3] = (dist, elev_deg, azim_deg)   (vertex_renderer.py:18)
+ *   alpha, depth [B,H,W]; aux [B,3,H,W] = (prod(1-a), zbar, sum w) saved for bwd.
+ */
+int vpn_raster_fwd(const float* params, const int32_t* kinds, const float* cam,
+                   int B, int K, int H, int W, float sigma, float gamma, float z_far,
+                   float* alpha, float* depth, float* aux, void* stream);
+/* bytes of workspace vpn_raster_bwd needs */
+size_t vpn_raster_bwd_workspace(int B, int K, int H, int W);
+/* grad_alpha / grad_depth [B,H,W] (either may be NULL = zero); grad_params
+ * [B,K,10] is written. */
+int vpn_raster_bwd(const float* params, const int32_t* kinds, const float* cam,
+                   int B, int K, int H, int W, float sigma, float gamma, float z_far,
+                   const float* aux, const float* grad_alpha, const float* grad_depth,
+                   void* workspace, float* grad_params, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VPN_HIP_H */

@@ -1,0 +1,295 @@
+// sampler.hip — surface-point sampler of volumetric primitives, forward and analytic
+// backward, one launch for the whole [B,K] primitive tensor (gfx950).
+//
+// Replaces (reference file:line): Sampling.sphere_sampling / cuboid_sampling
+// (modules/sampling/sampling.py:11-37), reparameterization + spherical_to_cartesian
+// (sphere.py:22-43), cuboid quotas / reparameterization / face snapping
+// (cuboid.py:30-101), transform_points (modules/transform/transform.py:6-9) and the
+// per-primitive Python loop + torch.cat of sample_predict_points (train.py:105-120).
+//
+// Layout: one workgroup per (primitive k, sample b); the primitive's pose (R from q),
+// volume and face quotas are computed once by lane 0 and staged in LDS; lanes stride
+// over the n points.  Backward: dL/d(v,q,t) only needs G = sum_n g_n c_n^T (3x3) and
+// sum_n g_n, reduced wave-shuffle -> LDS -> one chain-rule pass by lane 0.
+#include "vpn_common.h"
+
+namespace vpn {
+
+constexpr int SAMP_BLOCK = 256;
+
+struct PrimLds {
+    Pose pose;
+    float v[3];
+    int cum[7];   // cuboid: prefix sums of the face quotas (cum[0] = 0, cum[6] = n)
+    int kind;
+};
+
+// face quotas of cuboid.py:30-53: round-half-even(n * area_f / total) for faces 0..4,
+// remainder to face 5.  Same fp32 operation order as the reference.
+__device__ inline void cuboid_quota(const float v[3], int n, int cum[7]) {
+    float w = v[0], h = v[1], d = v[2];
+    float hd = h * d, dw = d * w, wh = w * h;
+    float total = (hd + dw + wh) * 2.0f;
+    float area[6] = {hd, hd, dw, dw, wh, wh};
+    int acc = 0;
+    cum[0] = 0;
+#pragma unroll
+    for (int f = 0; f < 5; ++f) {
+        float weight = area[f] / total;
+        int c = (int)rintf((float)n * weight);
+        acc += c;
+        cum[f + 1] = acc;
+    }
+    cum[6] = n;
+}
+
+// canonical coefficient c with p_c = c * v  (unit sphere point, or unit box point snapped to a face)
+__device__ inline void canonical_coeff(const PrimLds& P, int p, const float u[3], float c[3]) {
+    if (P.kind == VPN_SPHERE) {
+        float elev = -acosf(1.0f - 2.0f * u[0]) + VPN_PI * 0.5f;   // sphere.py:26
+        float azim = u[1] * 2.0f * VPN_PI;                          // sphere.py:27
+        float ce = cosf(elev);
+        c[0] = ce * sinf(azim);                                     // sphere.py:38-40
+        c[1] = sinf(elev);
+        c[2] = ce * cosf(azim);
+    } else {
+        c[0] = -1.0f + 2.0f * u[0];                                 // cuboid.py:66
+        c[1] = -1.0f + 2.0f * u[1];
+        c[2] = -1.0f + 2.0f * u[2];
+        // cuboid.py:88-99: index range -> face; later faces overwrite earlier ones only if
+        // ranges overlap, which happens when a quota is negative; ranges here are disjoint.
+#pragma unroll
+        for (int f = 0; f < 6; ++f) {
+            if (p >= P.cum[f] && p < P.cum[f + 1]) c[f >> 1] = (f & 1) ? -1.0f : 1.0f;
+        }
+    }
+}
+
+__device__ inline void load_prim(PrimLds& P, const float* prm, int kind, int n) {
+    P.pose = make_pose(prm[3], prm[4], prm[5], prm[6]);
+    P.v[0] = prm[0]; P.v[1] = prm[1]; P.v[2] = prm[2];
+    P.kind = kind;
+    if (kind == VPN_CUBOID) cuboid_quota(P.v, n, P.cum);
+}
+
+__global__ __launch_bounds__(SAMP_BLOCK) void sample_fwd_kernel(
+    const float* __restrict__ params, const int32_t* __restrict__ kinds, const float* __restrict__ u,
+    uint64_t seed, uint64_t sample_base, int K, int n, float* __restrict__ points) {
+    __shared__ PrimLds P;
+    const int k = blockIdx.x, b = blockIdx.y;
+    const float* prm = params + ((size_t)b * K + k) * VPN_PARAM_STRIDE;
+    if (threadIdx.x == 0) load_prim(P, prm, kinds[k], n);
+    __syncthreads();
+    const float tx = prm[7], ty = prm[8], tz = prm[9];
+    const float* ub = u ? u + ((size_t)b * K + k) * n * 3 : nullptr;
+    float* out = points + ((size_t)b * K + k) * n * 3;
+    for (int p = threadIdx.x; p < n; p += SAMP_BLOCK) {
+        float uu[3];
+        if (ub) { uu[0] = ub[p * 3]; uu[1] = ub[p * 3 + 1]; uu[2] = ub[p * 3 + 2]; }
+        else philox_uniform3(seed, sample_base + (uint64_t)b, (uint32_t)k, (uint32_t)p, uu);
+        float c[3];
+        canonical_coeff(P, p, uu, c);
+        float x = c[0] * P.v[0], y = c[1] * P.v[1], z = c[2] * P.v[2];
+        const Mat3& R = P.pose.R;
+        out[p * 3 + 0] = (R.m[0][0] * x + R.m[0][1] * y + R.m[0][2] * z) + tx;   // rotate.py:22-23, translate.py:8
+        out[p * 3 + 1] = (R.m[1][0] * x + R.m[1][1] * y + R.m[1][2] * z) + ty;
+        out[p * 3 + 2] = (R.m[2][0] * x + R.m[2][1] * y + R.m[2][2] * z) + tz;
+    }
+}
+
+__global__ __launch_bounds__(SAMP_BLOCK) void sample_bwd_kernel(
+    const float* __restrict__ params, const int32_t* __restrict__ kinds, const float* __restrict__ u,
+    uint64_t seed, uint64_t sample_base, int K, int n, const float* __restrict__ grad_points,
+    float* __restrict__ grad_params) {
+    __shared__ PrimLds P;
+    __shared__ float red[SAMP_BLOCK / 64][12];
+    const int k = blockIdx.x, b = blockIdx.y;
+    const float* prm = params + ((size_t)b * K + k) * VPN_PARAM_STRIDE;
+    if (threadIdx.x == 0) load_prim(P, prm, kinds[k], n);
+    __syncthreads();
+    const float* ub = u ? u + ((size_t)b * K + k) * n * 3 : nullptr;
+    const float* gp = grad_points + ((size_t)b * K + k) * n * 3;
+    // acc[0..8] = G[b][a] = sum g_b c_a ; acc[9..11] = sum g
+    float acc[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc[i] = 0.0f;
+    for (int p = threadIdx.x; p < n; p += SAMP_BLOCK) {
+        float uu[3];
+        if (ub) { uu[0] = ub[p * 3]; uu[1] = ub[p * 3 + 1]; uu[2] = ub[p * 3 + 2]; }
+        else philox_uniform3(seed, sample_base + (uint64_t)b, (uint32_t)k, (uint32_t)p, uu);
+        float c[3];
+        canonical_coeff(P, p, uu, c);
+        float g[3] = {gp[p * 3], gp[p * 3 + 1], gp[p * 3 + 2]};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) acc[r * 3 + a] += g[r] * c[a];
+            acc[9 + r] += g[r];
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        float s = wave_sum(acc[i]);
+        if (lane == 0) red[wave][i] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float G[3][3], gt[3];
+        for (int r = 0; r < 3; ++r) {
+            for (int a = 0; a < 3; ++a) {
+                float s = 0.0f;
+                for (int w = 0; w < SAMP_BLOCK / 64; ++w) s += red[w][r * 3 + a];
+                G[r][a] = s;
+            }
+            float s = 0.0f;
+            for (int w = 0; w < SAMP_BLOCK / 64; ++w) s += red[w][9 + r];
+            gt[r] = s;
+        }
+        const Mat3& R = P.pose.R;
+        float gR[3][3], gv[3], gq[4];
+        for (int a = 0; a < 3; ++a) {
+            gv[a] = R.m[0][a] * G[0][a] + R.m[1][a] * G[1][a] + R.m[2][a] * G[2][a];   // p = R (c*v) + t
+            for (int r = 0; r < 3; ++r) gR[r][a] = G[r][a] * P.v[a];
+        }
+        pose_backward(P.pose, prm[3], prm[4], prm[5], gR, gq);
+        float* o = grad_params + ((size_t)b * K + k) * VPN_PARAM_STRIDE;
+        o[0] = gv[0]; o[1] = gv[1]; o[2] = gv[2];
+        o[3] = gq[0]; o[4] = gq[1]; o[5] = gq[2]; o[6] = gq[3];
+        o[7] = gt[0]; o[8] = gt[1]; o[9] = gt[2];
+    }
+}
+
+// ---- standalone transform (modules/transform/transform.py:6-9): out = R(q) p + t
+constexpr int TR_BLOCK = 256;
+
+__global__ __launch_bounds__(TR_BLOCK) void transform_fwd_kernel(
+    const float* __restrict__ pts, const float* __restrict__ q, const float* __restrict__ t, int N,
+    float* __restrict__ out) {
+    __shared__ Pose S;
+    const int b = blockIdx.y;
+    if (threadIdx.x == 0) S = make_pose(q[b * 4], q[b * 4 + 1], q[b * 4 + 2], q[b * 4 + 3]);
+    __syncthreads();
+    float tx = 0.f, ty = 0.f, tz = 0.f;
+    if (t) { tx = t[b * 3]; ty = t[b * 3 + 1]; tz = t[b * 3 + 2]; }
+    const Mat3& R = S.R;
+    for (int p = blockIdx.x * TR_BLOCK + threadIdx.x; p < N; p += gridDim.x * TR_BLOCK) {
+        const float* pp = pts + ((size_t)b * N + p) * 3;
+        float x = pp[0], y = pp[1], z = pp[2];
+        float* o = out + ((size_t)b * N + p) * 3;
+        float ox = R.m[0][0] * x + R.m[0][1] * y + R.m[0][2] * z;
+        float oy = R.m[1][0] * x + R.m[1][1] * y + R.m[1][2] * z;
+        float oz = R.m[2][0] * x + R.m[2][1] * y + R.m[2][2] * z;
+        if (t) { ox += tx; oy += ty; oz += tz; }
+        o[0] = ox; o[1] = oy; o[2] = oz;
+    }
+}
+
+// one workgroup per sample: grad_points = R^T g; G = sum g p^T; sum g
+__global__ __launch_bounds__(TR_BLOCK) void transform_bwd_kernel(
+    const float* __restrict__ pts, const float* __restrict__ q, const float* __restrict__ gout, int N,
+    float* __restrict__ gpts, float* __restrict__ gq, float* __restrict__ gt) {
+    __shared__ Pose S;
+    __shared__ float red[TR_BLOCK / 64][12];
+    const int b = blockIdx.x;
+    if (threadIdx.x == 0) S = make_pose(q[b * 4], q[b * 4 + 1], q[b * 4 + 2], q[b * 4 + 3]);
+    __syncthreads();
+    const Mat3& R = S.R;
+    float acc[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc[i] = 0.0f;
+    for (int p = threadIdx.x; p < N; p += TR_BLOCK) {
+        const float* gg = gout + ((size_t)b * N + p) * 3;
+        const float* pp = pts + ((size_t)b * N + p) * 3;
+        float g[3] = {gg[0], gg[1], gg[2]};
+        float c[3] = {pp[0], pp[1], pp[2]};
+        if (gpts) {
+            float* o = gpts + ((size_t)b * N + p) * 3;
+            o[0] = R.m[0][0] * g[0] + R.m[1][0] * g[1] + R.m[2][0] * g[2];
+            o[1] = R.m[0][1] * g[0] + R.m[1][1] * g[1] + R.m[2][1] * g[2];
+            o[2] = R.m[0][2] * g[0] + R.m[1][2] * g[1] + R.m[2][2] * g[2];
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) acc[r * 3 + a] += g[r] * c[a];
+            acc[9 + r] += g[r];
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        float s = wave_sum(acc[i]);
+        if (lane == 0) red[wave][i] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float G[3][3], st[3];
+        for (int r = 0; r < 3; ++r) {
+            for (int a = 0; a < 3; ++a) {
+                float s = 0.0f;
+                for (int w = 0; w < TR_BLOCK / 64; ++w) s += red[w][r * 3 + a];
+                G[r][a] = s;
+            }
+            float s = 0.0f;
+            for (int w = 0; w < TR_BLOCK / 64; ++w) s += red[w][9 + r];
+            st[r] = s;
+        }
+        if (gq) {
+            float o[4];
+            pose_backward(S, q[b * 4], q[b * 4 + 1], q[b * 4 + 2], G, o);
+            gq[b * 4] = o[0]; gq[b * 4 + 1] = o[1]; gq[b * 4 + 2] = o[2]; gq[b * 4 + 3] = o[3];
+        }
+        if (gt) { gt[b * 3] = st[0]; gt[b * 3 + 1] = st[1]; gt[b * 3 + 2] = st[2]; }
+    }
+}
+
+}  // namespace vpn
+
+using namespace vpn;
+
+extern "C" int vpn_sample_fwd(const float* params, const int32_t* kinds, const float* u, uint64_t seed,
+                              uint64_t sample_base, int B, int K, int n, float* points, void* stream) {
+    if (!params || !kinds || !points) return VPN_E_BADARG;
+    if (B <= 0 || K <= 0 || n <= 0) return VPN_E_BADARG;
+    if (B > 65535) return VPN_E_TOOBIG;
+    hipLaunchKernelGGL(sample_fwd_kernel, dim3(K, B), dim3(SAMP_BLOCK), 0, (hipStream_t)stream, params, kinds, u,
+                       seed, sample_base, K, n, points);
+    VPN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vpn_sample_bwd(const float* params, const int32_t* kinds, const float* u, uint64_t seed,
+                              uint64_t sample_base, int B, int K, int n, const float* grad_points,
+                              float* grad_params, void* stream) {
+    if (!params || !kinds || !grad_points || !grad_params) return VPN_E_BADARG;
+    if (B <= 0 || K <= 0 || n <= 0) return VPN_E_BADARG;
+    if (B > 65535) return VPN_E_TOOBIG;
+    hipLaunchKernelGGL(sample_bwd_kernel, dim3(K, B), dim3(SAMP_BLOCK), 0, (hipStream_t)stream, params, kinds, u,
+                       seed, sample_base, K, n, grad_points, grad_params);
+    VPN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vpn_transform_fwd(const float* points, const float* q, const float* t, int B, int N, float* out,
+                                 void* stream) {
+    if (!points || !q || !out) return VPN_E_BADARG;
+    if (B <= 0 || N <= 0) return VPN_E_BADARG;
+    if (B > 65535) return VPN_E_TOOBIG;
+    int gx = (N + TR_BLOCK - 1) / TR_BLOCK;
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(transform_fwd_kernel, dim3(gx, B), dim3(TR_BLOCK), 0, (hipStream_t)stream, points, q, t, N,
+                       out);
+    VPN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vpn_transform_bwd(const float* points, const float* q, const float* grad_out, int B, int N,
+                                 float* grad_points, float* grad_q, float* grad_t, void* stream) {
+    if (!points || !q || !grad_out) return VPN_E_BADARG;
+    if (B <= 0 || N <= 0) return VPN_E_BADARG;
+    hipLaunchKernelGGL(transform_bwd_kernel, dim3(B), dim3(TR_BLOCK), 0, (hipStream_t)stream, points, q, grad_out,
+                       N, grad_points, grad_q, grad_t);
+    VPN_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,64 @@
+"""modules/loss of the reference (chamfer_distance.py, vp_diverse.py, silhouette.py) on
+the HIP Chamfer and raster kernels.  Same class names and forward signatures."""
+import torch
+import torch.nn as nn
+
+from .. import config
+from ..ops import ChamferFunction
+from ..primitives import PrimitivePack
+from .render import VertexRenderer
+
+
+class ChamferDistanceLoss(nn.Module):
+    def __init__(self):
+        super().__init__()
+
+    def forward(self, points1: torch.Tensor, points2: torch.Tensor, each_batch=False,
+                w1=config.CD_W1, w2=config.CD_W2) -> torch.Tensor:
+        """chamfer_distance.py:10-30: w1*mean_i min_j|a_i-b_j| + w2*mean_j min_i|a_i-b_j|
+        (non-squared), per sample if each_batch else the batch mean."""
+        self.check_parameters(points1)
+        self.check_parameters(points2)
+        loss = ChamferFunction.apply(points1, points2, w1, w2)
+        return loss if each_batch else loss.mean()
+
+    @staticmethod
+    def check_parameters(points: torch.Tensor):
+        assert points.ndimension() == 3  # (B, N, 3)        chamfer_distance.py:32-35
+        assert points.size(-1) == 3
+
+
+class VPDiverseLoss(nn.Module):
+    def __init__(self, vp_num=None):
+        super().__init__()
+        self.cd_loss_func = ChamferDistanceLoss()
+        self.vp_num = vp_num             # the reference asserts len == config.VP_NUM (vp_diverse.py:23)
+
+    def forward(self, translates: list, gt_points: torch.Tensor) -> torch.Tensor:
+        """vp_diverse.py:12-18."""
+        self.check_parameters(translates)
+        vp_center_points = torch.cat([t[:, None, :] for t in translates], 1)
+        return self.cd_loss_func(vp_center_points, gt_points, w1=0.5, w2=1.0)
+
+    def check_parameters(self, translates):
+        assert isinstance(translates, list)
+        if self.vp_num is not None:
+            assert len(translates) == self.vp_num
+
+
+class SilhouetteLoss(nn.Module):
+    def __init__(self, loss_func=config.SILHOUETTE_LOSS_FUNC):
+        super().__init__()
+        self.loss_func = nn.L1Loss() if loss_func == 'L1' else nn.MSELoss()     # silhouette.py:11
+
+    def forward(self, predict_meshes, gt_silhouettes: torch.Tensor,
+                dists: torch.Tensor, elevs: torch.Tensor, azims: torch.Tensor) -> torch.Tensor:
+        """silhouette.py:13-23.  `predict_meshes` is a PrimitivePack for the batch (or a list of
+        per-sample packs, the shape of the reference's list of meshes); the B sequential
+        renders of silhouette.py:16-18 become one launch at the GT silhouette's resolution."""
+        if isinstance(predict_meshes, (list, tuple)):
+            predict_meshes = PrimitivePack.stack(list(predict_meshes))
+        H, W = gt_silhouettes.shape[-2:]
+        _, alpha, _ = VertexRenderer.render(predict_meshes, dists, elevs, azims, image_size=(H, W))
+        predict_silhouettes = alpha.permute(0, 3, 1, 2)                          # silhouette.py:18
+        return self.loss_func(predict_silhouettes, gt_silhouettes)

@@ -1,0 +1,46 @@
+"""modules/render of the reference (vertex_renderer.py) on the HIP primitive raster."""
+import torch
+
+from .. import config
+from ..ops import RasterFunction
+from ..primitives import PrimitivePack
+
+
+def _as_batch(x, B, device):
+    if isinstance(x, torch.Tensor):
+        x = x.to(device=device, dtype=torch.float32).reshape(-1)
+        return x.expand(B) if x.numel() == 1 else x
+    return torch.full((B,), float(x), dtype=torch.float32, device=device)
+
+
+class VertexRenderer:
+    """Same entry point as the reference (vertex_renderer.py:10-26).  Differences, all forced
+    by the reference rendering through kaolin (absent): `mesh` is a PrimitivePack, a whole
+    batch renders in one call, the camera travels with the call instead of mutating a
+    module-global renderer (vertex_renderer.py:7,18), the image size is an argument instead of
+    the hard-wired 128x128 (vertex_renderer.py:7), and the third output is the soft-min depth
+    map instead of kaolin's face normals."""
+    image_size = (config.IMG_SIZE, config.IMG_SIZE)
+    sigma = config.RASTER_SIGMA
+    gamma = config.RASTER_GAMMA
+    z_far = config.RASTER_Z_FAR
+
+    def __init__(self):
+        pass
+
+    @classmethod
+    def render(cls, mesh, dist, elev, azim, colors=None, image_size=None):
+        if not isinstance(mesh, PrimitivePack):
+            raise TypeError('VertexRenderer.render takes a PrimitivePack (primitive parameters); triangle meshes '
+                            'are the reference-side adapter (SURVEY.md 8f, row f2)')
+        B = len(mesh)
+        dev = mesh.params.device
+        cam = torch.stack([_as_batch(dist, B, dev), _as_batch(elev, B, dev), _as_batch(azim, B, dev)], 1)
+        H, W = image_size or cls.image_size
+        alpha, depth = RasterFunction.apply(mesh.params, mesh.kinds, cam, H, W, cls.sigma, cls.gamma, cls.z_far)
+        render_alphas = alpha[..., None]                       # (B,H,W,1)  vertex_renderer.py:24
+        if colors is None:
+            render_rgbs = render_alphas.expand(B, H, W, 3)     # colours default to ones (vertex_renderer.py:22)
+        else:
+            render_rgbs = render_alphas * colors.reshape(-1, 1, 1, 3)
+        return render_rgbs, render_alphas, depth[..., None]

@@ -1,0 +1,181 @@
+"""torch.autograd.Function wrappers over the C ABI (include/vpn_hip.h).
+
+Pattern follows the reference's own native op, emdFunction (modules/loss/emd/
+emd_module.py:29-70): forward allocates the outputs, calls native code, saves what
+backward needs; backward returns one gradient per tensor input and None for the rest.
+Unlike it, a non-zero return code raises."""
+import torch
+from torch.autograd import Function
+
+from . import _lib
+
+SPHERE, CUBOID = 0, 1
+PARAM_STRIDE = 10
+
+
+def _f32c(t):
+    if not t.is_cuda:
+        raise RuntimeError('vpn_amd operators run on the GPU only (got a %s tensor); there is no CPU path'
+                           % t.device.type)
+    return t.contiguous().float()          # emd_module.py:41-42 does the same to its inputs
+
+
+def kinds_tensor(kinds, device):
+    """int32 device tensor of primitive kinds; rejects cones (sampling.py:39-45 is `pass`)."""
+    if isinstance(kinds, torch.Tensor):
+        host = kinds.detach().cpu().tolist() if kinds.device.type != device.type else None
+        if host is None:
+            return kinds.to(torch.int32).contiguous()
+        kinds = host
+    kinds = [int(k) for k in kinds]
+    if any(k not in (SPHERE, CUBOID) for k in kinds):
+        raise ValueError('unknown primitive kind in %r (0 = sphere, 1 = cuboid; cones are not implemented '
+                         'in the reference either)' % (kinds,))
+    return torch.tensor(kinds, dtype=torch.int32, device=device)
+
+
+class SampleFunction(Function):
+    """Sampling.{sphere,cuboid}_sampling + transform_points + torch.cat over K primitives
+    (sampling.py:11-37, train.py:105-120) -> points [B, K*n, 3]."""
+
+    @staticmethod
+    def forward(ctx, params, kinds, u, seed, sample_base, n):
+        params = _f32c(params)
+        B, K, S = params.shape
+        assert S == PARAM_STRIDE and kinds.numel() == K
+        if u is not None:
+            u = _f32c(u)
+            assert u.shape == (B, K, n, 3)
+        points = torch.empty((B, K * n, 3), dtype=torch.float32, device=params.device)
+        _lib.call('vpn_sample_fwd', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(u), int(seed), int(sample_base),
+                                    B, K, n, _lib.ptr(points), _lib.stream())
+        ctx.save_for_backward(params, kinds, u if u is not None else torch.empty(0, device=params.device))
+        ctx.has_u = u is not None
+        ctx.meta = (int(seed), int(sample_base), B, K, n)
+        return points
+
+    @staticmethod
+    def backward(ctx, grad_points):
+        params, kinds, u = ctx.saved_tensors
+        seed, base, B, K, n = ctx.meta
+        grad_points = _f32c(grad_points)
+        grad_params = torch.empty_like(params)
+        _lib.call('vpn_sample_bwd', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(u) if ctx.has_u else None, seed,
+                                    base, B, K, n, _lib.ptr(grad_points), _lib.ptr(grad_params), _lib.stream())
+        return grad_params, None, None, None, None, None
+
+
+class TransformFunction(Function):
+    """transform_points / rotate_points (transform.py:6-9, rotate.py:7-25): R(q) p (+ t)."""
+
+    @staticmethod
+    def forward(ctx, points, q, t):
+        points, q = _f32c(points), _f32c(q)
+        t = _f32c(t) if t is not None else None
+        B, N, _ = points.shape
+        out = torch.empty_like(points)
+        _lib.call('vpn_transform_fwd', _lib.ptr(points), _lib.ptr(q), _lib.ptr(t), B, N, _lib.ptr(out),
+                                       _lib.stream())
+        ctx.save_for_backward(points, q)
+        ctx.has_t = t is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        points, q = ctx.saved_tensors
+        B, N, _ = points.shape
+        grad_out = _f32c(grad_out)
+        need_p, need_q, need_t = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_t and ctx.needs_input_grad[2]
+        gp = torch.empty_like(points) if need_p else None
+        gq = torch.empty_like(q) if need_q else None
+        gt = torch.empty((B, 3), dtype=torch.float32, device=points.device) if need_t else None
+        _lib.call('vpn_transform_bwd', _lib.ptr(points), _lib.ptr(q), _lib.ptr(grad_out), B, N, _lib.ptr(gp),
+                                       _lib.ptr(gq), _lib.ptr(gt), _lib.stream())
+        return gp, gq, gt
+
+
+class ChamferFunction(Function):
+    """ChamferDistanceLoss.forward up to the per-sample loss (chamfer_distance.py:14-28).
+    Returns loss_b [B]; the caller takes .mean() unless each_batch (chamfer_distance.py:30)."""
+
+    @staticmethod
+    def forward(ctx, p1, p2, w1, w2):
+        p1, p2 = _f32c(p1), _f32c(p2)
+        B, N, _ = p1.shape
+        M = p2.shape[1]
+        dev = p1.device
+        d1 = torch.empty((B, N), dtype=torch.float32, device=dev)
+        d2 = torch.empty((B, M), dtype=torch.float32, device=dev)
+        i1 = torch.empty((B, N), dtype=torch.int32, device=dev)
+        i2 = torch.empty((B, M), dtype=torch.int32, device=dev)
+        loss_b = torch.empty((B,), dtype=torch.float32, device=dev)
+        s = _lib.stream()
+        _lib.call('vpn_chamfer_nn', _lib.ptr(p1), _lib.ptr(p2), B, N, M, _lib.ptr(d1), _lib.ptr(i1), s)
+        _lib.call('vpn_chamfer_nn', _lib.ptr(p2), _lib.ptr(p1), B, M, N, _lib.ptr(d2), _lib.ptr(i2), s)
+        _lib.call('vpn_chamfer_loss', _lib.ptr(d1), _lib.ptr(d2), B, N, M, float(w1), float(w2), _lib.ptr(loss_b), s)
+        ctx.save_for_backward(p1, p2, d1, i1, d2, i2)
+        ctx.w = (float(w1), float(w2))
+        return loss_b
+
+    @staticmethod
+    def backward(ctx, grad_loss_b):
+        p1, p2, d1, i1, d2, i2 = ctx.saved_tensors
+        B, N, _ = p1.shape
+        M = p2.shape[1]
+        g = _f32c(grad_loss_b)
+        g1 = torch.empty_like(p1) if ctx.needs_input_grad[0] else None
+        g2 = torch.empty_like(p2) if ctx.needs_input_grad[1] else None
+        _lib.call('vpn_chamfer_bwd', _lib.ptr(p1), _lib.ptr(p2), _lib.ptr(d1), _lib.ptr(i1), _lib.ptr(d2),
+                                     _lib.ptr(i2), _lib.ptr(g), B, N, M, ctx.w[0], ctx.w[1], _lib.ptr(g1),
+                                     _lib.ptr(g2), _lib.stream())
+        return g1, g2, None, None
+
+
+def chamfer_nn(p1, p2):
+    """Nearest-neighbour distances and indices in both directions (no autograd):
+    (dist1 [B,N], idx1 [B,N] int32, dist2 [B,M], idx2 [B,M] int32)."""
+    p1, p2 = _f32c(p1.detach()), _f32c(p2.detach())
+    B, N, _ = p1.shape
+    M = p2.shape[1]
+    dev = p1.device
+    d1 = torch.empty((B, N), dtype=torch.float32, device=dev)
+    d2 = torch.empty((B, M), dtype=torch.float32, device=dev)
+    i1 = torch.empty((B, N), dtype=torch.int32, device=dev)
+    i2 = torch.empty((B, M), dtype=torch.int32, device=dev)
+    _lib.call('vpn_chamfer_fwd', _lib.ptr(p1), _lib.ptr(p2), B, N, M, _lib.ptr(d1), _lib.ptr(i1),
+                                         _lib.ptr(d2), _lib.ptr(i2), _lib.stream())
+    return d1, i1, d2, i2
+
+
+class RasterFunction(Function):
+    """Primitive soft raster behind VertexRenderer.render (vertex_renderer.py:14-26):
+    params [B,K,10], cam [B,3] = (dist, elev_deg, azim_deg) -> alpha, depth [B,H,W]."""
+
+    @staticmethod
+    def forward(ctx, params, kinds, cam, H, W, sigma, gamma, z_far):
+        params, cam = _f32c(params), _f32c(cam)
+        B, K, S = params.shape
+        assert S == PARAM_STRIDE and kinds.numel() == K and cam.shape == (B, 3)
+        dev = params.device
+        alpha = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+        depth = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+        aux = torch.empty((B, 3, H, W), dtype=torch.float32, device=dev)
+        _lib.call('vpn_raster_fwd', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(cam), B, K, H, W,
+                                            float(sigma), float(gamma), float(z_far), _lib.ptr(alpha),
+                                            _lib.ptr(depth), _lib.ptr(aux), _lib.stream())
+        ctx.save_for_backward(params, kinds, cam, aux)
+        ctx.meta = (B, K, H, W, float(sigma), float(gamma), float(z_far))
+        return alpha, depth
+
+    @staticmethod
+    def backward(ctx, grad_alpha, grad_depth):
+        params, kinds, cam, aux = ctx.saved_tensors
+        B, K, H, W, sigma, gamma, z_far = ctx.meta
+        ga = _f32c(grad_alpha) if grad_alpha is not None else None
+        gd = _f32c(grad_depth) if grad_depth is not None else None
+        ws = torch.empty((_lib.lib().vpn_raster_bwd_workspace(B, K, H, W) // 4,), dtype=torch.float32, device=params.device)
+        grad_params = torch.empty_like(params)
+        _lib.call('vpn_raster_bwd', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(cam), B, K, H, W, sigma, gamma,
+                                    z_far, _lib.ptr(aux), _lib.ptr(ga), _lib.ptr(gd), _lib.ptr(ws),
+                                    _lib.ptr(grad_params), _lib.stream())
+        return grad_params, None, None, None, None, None, None, None

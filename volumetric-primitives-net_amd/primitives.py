@@ -1,0 +1,50 @@
+"""Packed primitive tensor shared by the sampler and the raster.
+
+The reference carries K python lists of (B,3) volumes, (B,4) axis-angle rotations and
+(B,3) translations (vpnet_one_resnet.py:28-43, train.py:117); the kernels want one
+contiguous [B,K,10] tensor so a whole batch x primitive set is one coalesced read."""
+import torch
+
+from .ops import SPHERE, CUBOID, PARAM_STRIDE, kinds_tensor
+
+
+def pack_primitives(volumes, rotates, translates):
+    """K lists of (B,3),(B,4),(B,3) (the network's output format) -> [B,K,10].  Differentiable."""
+    assert len(volumes) == len(rotates) == len(translates)
+    return torch.stack([torch.cat([v, q, t], 1) for v, q, t in zip(volumes, rotates, translates)], 1)
+
+
+def kinds_from_counts(cuboid_num, sphere_num, cone_num=0):
+    """Primitive order of train.py:106-116: cuboids first, then spheres (cones must be 0:
+    sampling.py:39-45 and meshing.py:22-25 are stubs in the reference)."""
+    if cone_num:
+        raise ValueError('cone primitives are not implemented (reference stubs: sampling.py:39-45)')
+    return [CUBOID] * cuboid_num + [SPHERE] * sphere_num
+
+
+class PrimitivePack:
+    """What the renderer consumes in place of the reference's kaolin TriangleMesh
+    (vertex_renderer.py:16): params [B,K,10] (or [K,10] for one image) + kinds [K]."""
+
+    def __init__(self, params, kinds):
+        if params.dim() == 2:
+            params = params[None]
+        assert params.dim() == 3 and params.size(-1) == PARAM_STRIDE
+        self.params = params
+        self.kinds = kinds_tensor(kinds, params.device)
+        assert self.kinds.numel() == params.size(1)
+
+    @classmethod
+    def from_lists(cls, volumes, rotates, translates, kinds):
+        return cls(pack_primitives(volumes, rotates, translates), kinds)
+
+    def __len__(self):
+        return self.params.size(0)
+
+    def __getitem__(self, b):
+        """Per-sample view, so `predict_meshes[i]` of silhouette.py:17 keeps working."""
+        return PrimitivePack(self.params[b], self.kinds)
+
+    @staticmethod
+    def stack(packs):
+        return PrimitivePack(torch.cat([p.params for p in packs], 0), packs[0].kinds)
