@@ -113,18 +113,23 @@ int vpn_chamfer_bwd(const float* p1, const float* p2,
  * reference meshes the primitives first, modules/meshing/sphere.py:8-27, and
  * rasterises the mesh with kaolin's DIBRenderer, which is not in its tree).
  *   cam [B,3] = (dist, elev_deg, azim_deg)   (vertex_renderer.py:18)
- *   alpha, depth [B,H,W]; aux [B,3,H,W] = (prod(1-a), zbar, sum w) saved for bwd.
+ *   alpha, depth [B,H,W]; aux [B,3,H,W] = (prod(1-a), zbar, sum w) saved for bwd;
+ *   records: vpn_raster_records_size(B,K) bytes, 16-byte aligned, written by fwd (the
+ *   per-primitive camera-space ray coefficients + pixel bounding boxes) and read
+ *   again by bwd — keep it alive with aux.
  */
+size_t vpn_raster_records_size(int B, int K);
 int vpn_raster_fwd(const float* params, const int32_t* kinds, const float* cam,
                    int B, int K, int H, int W, float sigma, float gamma, float z_far,
-                   float* alpha, float* depth, float* aux, void* stream);
-/* bytes of workspace vpn_raster_bwd needs */
+                   float* alpha, float* depth, float* aux, void* records, void* stream);
+/* bytes of workspace vpn_raster_bwd needs (16-byte aligned, contents scratch) */
 size_t vpn_raster_bwd_workspace(int B, int K, int H, int W);
 /* grad_alpha / grad_depth [B,H,W] (either may be NULL = zero); grad_params
- * [B,K,10] is written. */
+ * [B,K,10] is written.  Bitwise reproducible (no atomics). */
 int vpn_raster_bwd(const float* params, const int32_t* kinds, const float* cam,
                    int B, int K, int H, int W, float sigma, float gamma, float z_far,
-                   const float* aux, const float* grad_alpha, const float* grad_depth,
+                   const float* aux, const void* records,
+                   const float* grad_alpha, const float* grad_depth,
                    void* workspace, float* grad_params, void* stream);
 
 #ifdef __cplusplus

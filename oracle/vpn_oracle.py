@@ -203,6 +203,22 @@ def chamfer_nn(p1, p2):
     return m1, i1, m2, i2
 
 
+def chamfer_nn_ieee(p1, p2):
+    """Same as chamfer_nn but with an IEEE-754 correctly rounded sqrt (numpy).  torch.sqrt on
+    CPU goes through MKL VML (HA mode, <= 1 ulp, NOT correctly rounded) for large contiguous
+    tensors: about 0.6 % of its results are 1 ulp off and which ones depends on tensor size and
+    CPU, so the reference's CPU distances are only defined to 1 ulp.  d2 (sub, mul, add) is exact
+    in both; this variant is what the kernels are compared with bit-for-bit (it is also what the
+    reference computes on its own CUDA device, where sqrt is correctly rounded)."""
+    import numpy as np
+    diff = p1[:, :, None, :] - p2[:, None, :, :]
+    dist = torch.sum(diff * diff, dim=3)
+    s = torch.from_numpy(np.sqrt(dist.numpy()))
+    m1, i1 = torch.min(s, dim=2)
+    m2, i2 = torch.min(torch.transpose(s, 1, 2), dim=2)
+    return m1, i1, m2, i2
+
+
 def chamfer_loss(p1, p2, each_batch=False, w1=1.0, w2=1.0):
     """ChamferDistanceLoss.forward (chamfer_distance.py:10-30), same expression
     (dense B*N*M, differentiable through torch autograd exactly like the

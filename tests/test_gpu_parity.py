@@ -149,12 +149,23 @@ def test_transforms_golden(vpn):
 
 
 # ----------------------------------------------------------------------------- Chamfer
-def _chamfer_exact(vpn, p1, p2):
+def ulp_diff(a, b):
+    return int((a.contiguous().view(torch.int32) - b.contiguous().view(torch.int32)).abs().max())
+
+
+def _chamfer_exact(vpn, p1, p2, torch_sqrt_too=True):
+    """Bit-exact against the reference expression evaluated with IEEE sqrt; against torch's own
+    CPU sqrt (MKL VML, <= 1 ulp, see vpn_oracle.chamfer_nn_ieee) indices must still agree and
+    distances agree to 1 ulp."""
     d1, i1, d2, i2 = vpn.chamfer_nn(g(p1), g(p2))
-    m1, j1, m2, j2 = O.chamfer_nn(p1, p2)
+    m1, j1, m2, j2 = O.chamfer_nn_ieee(p1, p2)
     assert torch.equal(i1.cpu().long(), j1), 'argmin direction 1 differs'
     assert torch.equal(i2.cpu().long(), j2), 'argmin direction 2 differs'
     assert torch.equal(d1.cpu(), m1) and torch.equal(d2.cpu(), m2), 'distances not bit-exact'
+    if torch_sqrt_too:
+        t1, k1, t2, k2 = O.chamfer_nn(p1, p2)
+        assert torch.equal(i1.cpu().long(), k1) and torch.equal(i2.cpu().long(), k2)
+        assert ulp_diff(d1.cpu(), t1) <= 1 and ulp_diff(d2.cpu(), t2) <= 1
 
 
 @pytest.mark.parametrize('name', ['g4_chamfer_b4_n128_m96', 'g4_chamfer_b2_n257_m2048', 'g4_chamfer_ties'])
@@ -162,7 +173,11 @@ def test_chamfer_golden(vpn, name):
     gd = load_golden(name)
     d1, i1, d2, i2 = vpn.chamfer_nn(g(gd['p1']), g(gd['p2']))
     assert torch.equal(i1.cpu(), gd['idx1']) and torch.equal(i2.cpu(), gd['idx2'])
-    assert torch.equal(d1.cpu(), gd['min1']) and torch.equal(d2.cpu(), gd['min2'])
+    # reference distances come from torch's CPU sqrt (MKL VML, <= 1 ulp): equal to 1 ulp, and
+    # bit-equal to the IEEE sqrt of the reference's exact d2
+    assert ulp_diff(d1.cpu(), gd['min1']) <= 1 and ulp_diff(d2.cpu(), gd['min2']) <= 1
+    m1, _, m2, _ = O.chamfer_nn_ieee(gd['p1'], gd['p2'])
+    assert torch.equal(d1.cpu(), m1) and torch.equal(d2.cpu(), m2)
     p1 = g(gd['p1']).requires_grad_(True)
     p2 = g(gd['p2']).requires_grad_(True)
     loss = vpn.ChamferDistanceLoss()(p1, p2)
@@ -195,29 +210,37 @@ def test_chamfer_lattice_ties(vpn):
 def test_chamfer_sqrt_bucket_tie(vpn):
     """Forces the rare branch: two DIFFERENT squared distances that round to the SAME sqrt.
     The reference compares after sqrt, so the earlier index wins although its d2 is larger."""
-    r = np.float32(0.3)
+    f32 = np.float32
     found = None
-    x = r
-    for _ in range(200000):
-        y = np.nextafter(x, np.float32(1), dtype=np.float32)
-        a, b = np.float32(x * x), np.float32(y * y)
-        if a != b and np.sqrt(a) == np.sqrt(b):
-            found = (float(y), float(x))     # larger first
+    a = f32(0.3)
+    for _ in range(100000):
+        A = f32(a * a)
+        An = np.nextafter(A, f32(1), dtype=np.float32)
+        if np.sqrt(A) == np.sqrt(An):
+            c = f32(np.sqrt(np.float64(An) - np.float64(A)))       # c*c ~ ulp(A)
+            for c2 in (c, f32(c * f32(1.2)), f32(c * f32(0.9)), f32(c * f32(1.4))):
+                if f32(A + f32(c2 * c2)) == An:
+                    found = (float(a), float(c2))
+                    break
+        if found:
             break
-        x = y
+        a = np.nextafter(a, f32(1), dtype=np.float32)
     assert found is not None
-    big, small = found
+    a, c = found
     p1 = torch.zeros(1, 300, 3)
-    p1[0, 1:, 0] = 5.0                       # only query 0 matters; others far away
+    p1[0, 1:, 0] = 5.0                       # only query 0 matters; the others are far away
     p2 = torch.full((1, 1500, 3), 9.0)
-    p2[0, 3] = torch.tensor([big, 0.0, 0.0])         # earlier index, larger d2, same sqrt
-    p2[0, 1200] = torch.tensor([small, 0.0, 0.0])    # later index (second LDS tile), strictly smaller d2
-    m1, j1, _, _ = O.chamfer_nn(p1, p2)
-    assert j1[0, 0].item() == 3              # the oracle (reference expression) picks the earlier one
-    _chamfer_exact(vpn, p1, p2)
-    # and with the order swapped the plain scan already gives the right answer
+    p2[0, 3] = torch.tensor([a, c, 0.0])     # earlier index, d2 = next(A): larger, same sqrt
+    p2[0, 1200] = torch.tensor([a, 0.0, 0.0])   # later index (second LDS tile), d2 = A: strictly smaller
+    m1, j1, _, _ = O.chamfer_nn_ieee(p1, p2)
+    diff = p1[0, 0] - p2[0, [3, 1200]]
+    d2 = ((diff * diff)[:, 0] + (diff * diff)[:, 1]) + (diff * diff)[:, 2]
+    assert d2[0] > d2[1] and np.sqrt(d2[0].numpy()) == np.sqrt(d2[1].numpy())
+    assert j1[0, 0].item() == 3              # the reference expression picks the earlier one
+    _chamfer_exact(vpn, p1, p2, torch_sqrt_too=False)
+    # with the order swapped the plain d2 scan already gives the right answer
     p2[0, 3], p2[0, 1200] = p2[0, 1200].clone(), p2[0, 3].clone()
-    _chamfer_exact(vpn, p1, p2)
+    _chamfer_exact(vpn, p1, p2, torch_sqrt_too=False)
 
 
 def test_chamfer_grad_vs_oracle(vpn):
@@ -271,9 +294,12 @@ def test_chamfer_full_size_properties(vpn):
     e2, j2, e1, j1 = vpn.chamfer_nn(p2, p1)
     assert torch.equal(e1, d1) and torch.equal(j1, i1) and torch.equal(e2, d2) and torch.equal(j2, i2)
     # (4) the oracle on two samples, exact
-    m1, k1, m2, k2 = O.chamfer_nn(p1[:2].cpu(), p2[:2].cpu())
+    m1, k1, m2, k2 = O.chamfer_nn_ieee(p1[:2].cpu(), p2[:2].cpu())
     assert torch.equal(i1[:2].cpu().long(), k1) and torch.equal(i2[:2].cpu().long(), k2)
     assert torch.equal(d1[:2].cpu(), m1) and torch.equal(d2[:2].cpu(), m2)
+    t1, l1, t2, l2 = O.chamfer_nn(p1[:2].cpu(), p2[:2].cpu())        # torch's own sqrt: same argmin, <= 1 ulp
+    assert torch.equal(k1, l1) and torch.equal(k2, l2)
+    assert ulp_diff(d1[:2].cpu(), t1) <= 1 and ulp_diff(d2[:2].cpu(), t2) <= 1
     # (5) run-to-run determinism of the forward
     f1 = vpn.chamfer_nn(p1, p2)
     assert all(torch.equal(x, y) for x, y in zip(f1, (d1, i1, d2, i2)))

@@ -119,3 +119,14 @@ def test_philox_known_answer():
     assert u.shape == (2, 3, 5, 3) and float(u.min()) >= 0 and float(u.max()) < 1
     # sharding invariance: samples [1,2) of a 2-batch == a 1-batch with sample_base=1
     assert torch.equal(u[1:2], O.philox_uniforms(1234, 1, 1, 3, 5))
+
+
+def test_chamfer_ieee_variant_matches_reference_indices():
+    """torch's CPU sqrt is MKL VML (<= 1 ulp, not correctly rounded): the IEEE-sqrt variant of the
+    oracle gives the same argmin on every fixture and distances within 1 ulp."""
+    for name in ('g4_chamfer_b4_n128_m96', 'g4_chamfer_b2_n257_m2048', 'g4_chamfer_ties'):
+        g = load_golden(name)
+        m1, i1, m2, i2 = O.chamfer_nn_ieee(g['p1'], g['p2'])
+        assert torch.equal(i1.int(), g['idx1']) and torch.equal(i2.int(), g['idx2'])
+        for a, b in ((m1, g['min1']), (m2, g['min2'])):
+            assert int((a.view(torch.int32) - b.view(torch.int32)).abs().max()) <= 1

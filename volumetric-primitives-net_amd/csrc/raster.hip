@@ -9,20 +9,25 @@
 // specification is oracle/vpn_oracle.py::raster (parity unpinned w.r.t. kaolin).
 //
 // Work decomposition (CDNA4):
-//   * workgroup = 256 threads = 16x16 pixel block of one image; each of its 4 waves owns a
-//     16x4 pixel tile, one pixel per lane;
-//   * the K primitives of the image are pre-transformed once per workgroup (pose from q,
-//     camera-space ray coefficients, conservative screen bounding box) and staged in LDS as
-//     five float4 per primitive; inside the per-primitive loop every LDS read is a
-//     wave-uniform broadcast;
-//   * per wave, each lane tests one primitive's box against the wave's tile and a 64-bit
-//     ballot drives the loop, so a wave only evaluates primitives whose coverage can exceed
-//     sigmoid(-X_CUT) ~ 1e-14 on its tile;
-//   * backward: per-pixel gradients w.r.t. the 12 per-primitive ray coefficients (o~, Mr, Mu,
-//     Mf) are reduced over the wave with a transposing butterfly (17 shuffles for 12 values),
-//     accumulated in LDS, written once per workgroup as partials [B,nblk,K,12] (plain stores,
-//     deterministic), and a finishing kernel sums the partials and applies the chain rule to
-//     (v,q,t).  No global atomics.
+//   * prep kernel: one lane per (image, primitive): pose from q, camera-space ray
+//     coefficients (o~, Mr, Mu, Mf) and a conservative pixel bounding box -> a 5 x float4
+//     record [B,K,5] in HBM (2.5 KB per image at K=32), reused by forward and backward;
+//   * raster kernels: ONE WAVEFRONT PER 16x16 PIXEL TILE (workgroup = 64 threads); the
+//     image's K records are staged into LDS with coalesced float4 loads; inside the
+//     per-primitive loop every LDS read is a wave-uniform broadcast.  Lane l owns column
+//     l&15 and rows (l>>4)+4s, s=0..3: four pixels per lane give ILP across the
+//     transcendental chains and let backward accumulate 4 pixels in registers before the
+//     cross-lane reduction;
+//   * culling: each lane tests one primitive's box against the tile and a 64-bit ballot
+//     drives the loop; the four 16x4 row groups are skipped individually (wave-uniform
+//     branch).  A primitive is skipped only where its coverage logit is below -X_CUT
+//     (coverage < 1.3e-14), so the result matches the dense specification to ~1e-6;
+//   * backward: the per-pixel gradients w.r.t. the 12 ray coefficients of a primitive are
+//     summed over the lane's pixels, reduced over the wave with a transposing butterfly (17
+//     shuffles for 12 values), parked in LDS and written once per tile as partials
+//     [B,tiles,K,12] with plain coalesced stores; a finishing kernel sums the partials in a
+//     fixed order and applies the chain rule to (v,q,t).  No atomics anywhere: the
+//     gradient is bitwise reproducible.
 #include "vpn_common.h"
 
 namespace vpn {
@@ -34,14 +39,14 @@ constexpr float R_EPS_Z = 1e-4f;
 constexpr float R_DELTA_S0 = 1e-12f;
 constexpr float R_EPS_D = 1e-9f;
 constexpr float R_X_CUT = 32.0f;     // primitives whose coverage logit is below -X_CUT on a tile are skipped
-constexpr int R_BW = 16, R_BH = 16;  // pixel block per workgroup
-constexpr int R_REC = 5;             // float4 per primitive record in LDS
+constexpr int R_TW = 16, R_TH = 16;  // pixel tile per wave
+constexpr int R_PPL = 4;             // pixels per lane (row groups of 4 rows)
+constexpr int R_REC = 5;             // float4 per primitive record
 
 struct Camera {
     float eye[3], right[3], up[3], fwd[3];
     float dist;
 };
-static_assert(sizeof(Camera) <= 64, "Camera must fit R_CAM_BYTES");
 
 // look-at camera of vertex_renderer.py:18 (set_look_at_parameters([azim],[elev],[dist]), degrees)
 __device__ inline Camera make_camera(const float* cam) {
@@ -79,49 +84,53 @@ __device__ inline void prim_geometry(const Camera& C, const Mat3& R, const float
     }
 }
 
-// Stage the image's K primitives in LDS: rec[k*5 + 0..3] = (o|kind, Mr, Mu, Mf), rec[k*5+4] = pixel bbox.
-__device__ inline void stage_primitives(const float* __restrict__ params, const int32_t* __restrict__ kinds,
-                                        const Camera& C, int K, int H, int W, float sigma, float4* rec) {
+// rec[(b*K+k)*5 + 0..3] = (o~|kind, Mr, Mu, Mf), rec[..+4] = pixel bbox (jmin, jmax, imin, imax as int bits)
+__global__ __launch_bounds__(256) void raster_prep_kernel(const float* __restrict__ params,
+                                                          const int32_t* __restrict__ kinds,
+                                                          const float* __restrict__ cam, int BK, int K, int H, int W,
+                                                          float sigma, float4* __restrict__ rec) {
+    const int bk = blockIdx.x * 256 + threadIdx.x;
+    if (bk >= BK) return;
+    const int b = bk / K, k = bk - b * K;
+    const Camera C = make_camera(cam + b * 3);
+    const float* prm = params + (size_t)bk * VPN_PARAM_STRIDE;
+    float v[3] = {prm[0], prm[1], prm[2]};
+    float t[3] = {prm[7], prm[8], prm[9]};
+    Pose P = make_pose(prm[3], prm[4], prm[5], prm[6]);
+    PrimGeo G;
+    prim_geometry(C, P.R, v, t, G);
+    const int kind = kinds[k];
+    float4* out = rec + (size_t)bk * R_REC;
+    out[0] = make_float4(G.o[0], G.o[1], G.o[2], __int_as_float(kind));
+    out[1] = make_float4(G.Mr[0], G.Mr[1], G.Mr[2], 0.f);
+    out[2] = make_float4(G.Mu[0], G.Mu[1], G.Mu[2], 0.f);
+    out[3] = make_float4(G.Mf[0], G.Mf[1], G.Mf[2], 0.f);
+    // conservative screen box of the bounding sphere of the primitive inflated by lam_cut:
+    // outside it the coverage logit (1 - m2)/sigma is below -X_CUT
     const float lam_cut = sqrtf(1.0f + R_X_CUT * sigma);
     const float txs = R_TAN_HALF_FOV * (float)W / (float)H;
-    for (int k = threadIdx.x; k < K; k += blockDim.x) {
-        const float* prm = params + (size_t)k * VPN_PARAM_STRIDE;
-        float v[3] = {prm[0], prm[1], prm[2]};
-        float t[3] = {prm[7], prm[8], prm[9]};
-        Pose P = make_pose(prm[3], prm[4], prm[5], prm[6]);
-        PrimGeo G;
-        prim_geometry(C, P.R, v, t, G);
-        const int kind = kinds[k];
-        rec[k * R_REC + 0] = make_float4(G.o[0], G.o[1], G.o[2], __int_as_float(kind));
-        rec[k * R_REC + 1] = make_float4(G.Mr[0], G.Mr[1], G.Mr[2], 0.f);
-        rec[k * R_REC + 2] = make_float4(G.Mu[0], G.Mu[1], G.Mu[2], 0.f);
-        rec[k * R_REC + 3] = make_float4(G.Mf[0], G.Mf[1], G.Mf[2], 0.f);
-        // conservative screen box of the bounding sphere of the primitive inflated by lam_cut
-        float rad = kind == VPN_SPHERE ? fmaxf(v[0], fmaxf(v[1], v[2]))
-                                       : sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-        rad *= lam_cut * 1.001f;
-        float e[3] = {t[0] - C.eye[0], t[1] - C.eye[1], t[2] - C.eye[2]};
-        float cx = e[0] * C.right[0] + e[1] * C.right[1] + e[2] * C.right[2];
-        float cy = e[0] * C.up[0] + e[1] * C.up[1] + e[2] * C.up[2];
-        float cz = e[0] * C.fwd[0] + e[1] * C.fwd[1] + e[2] * C.fwd[2];
-        int jmin = 0, jmax = W - 1, imin = 0, imax = H - 1;
-        if (cz - rad > 1e-3f && rad == rad) {   // fully in front of the camera: tangent slopes of the sphere
-            float den = cz * cz - rad * rad;
-            float dx = rad * sqrtf(fmaxf(cx * cx + den, 0.f));
-            float dy = rad * sqrtf(fmaxf(cy * cy + den, 0.f));
-            float pxl = (cx * cz - dx) / den, pxh = (cx * cz + dx) / den;
-            float pyl = (cy * cz - dy) / den, pyh = (cy * cz + dy) / den;
-            float jl = (pxl / txs + 1.0f) * (0.5f * W) - 0.5f, jh = (pxh / txs + 1.0f) * (0.5f * W) - 0.5f;
-            float il = (1.0f - pyh / R_TAN_HALF_FOV) * (0.5f * H) - 0.5f;
-            float ih = (1.0f - pyl / R_TAN_HALF_FOV) * (0.5f * H) - 0.5f;
-            jmin = (int)fminf(fmaxf(floorf(jl) - 1.0f, -1.0e6f), 1.0e6f);
-            jmax = (int)fminf(fmaxf(ceilf(jh) + 1.0f, -1.0e6f), 1.0e6f);
-            imin = (int)fminf(fmaxf(floorf(il) - 1.0f, -1.0e6f), 1.0e6f);
-            imax = (int)fminf(fmaxf(ceilf(ih) + 1.0f, -1.0e6f), 1.0e6f);
-        }
-        rec[k * R_REC + 4] = make_float4(__int_as_float(jmin), __int_as_float(jmax), __int_as_float(imin),
-                                         __int_as_float(imax));
+    float rad = kind == VPN_SPHERE ? fmaxf(v[0], fmaxf(v[1], v[2])) : sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    rad *= lam_cut * 1.001f;
+    float e[3] = {t[0] - C.eye[0], t[1] - C.eye[1], t[2] - C.eye[2]};
+    float cx = e[0] * C.right[0] + e[1] * C.right[1] + e[2] * C.right[2];
+    float cy = e[0] * C.up[0] + e[1] * C.up[1] + e[2] * C.up[2];
+    float cz = e[0] * C.fwd[0] + e[1] * C.fwd[1] + e[2] * C.fwd[2];
+    int jmin = 0, jmax = W - 1, imin = 0, imax = H - 1;
+    if (cz - rad > 1e-3f && rad == rad) {   // fully in front of the camera: tangent slopes of the sphere
+        float den = cz * cz - rad * rad;
+        float dx = rad * sqrtf(fmaxf(cx * cx + den, 0.f));
+        float dy = rad * sqrtf(fmaxf(cy * cy + den, 0.f));
+        float pxl = (cx * cz - dx) / den, pxh = (cx * cz + dx) / den;
+        float pyl = (cy * cz - dy) / den, pyh = (cy * cz + dy) / den;
+        float jl = (pxl / txs + 1.0f) * (0.5f * W) - 0.5f, jh = (pxh / txs + 1.0f) * (0.5f * W) - 0.5f;
+        float il = (1.0f - pyh / R_TAN_HALF_FOV) * (0.5f * H) - 0.5f;
+        float ih = (1.0f - pyl / R_TAN_HALF_FOV) * (0.5f * H) - 0.5f;
+        jmin = (int)fminf(fmaxf(floorf(jl) - 1.0f, -1.0e6f), 1.0e6f);
+        jmax = (int)fminf(fmaxf(ceilf(jh) + 1.0f, -1.0e6f), 1.0e6f);
+        imin = (int)fminf(fmaxf(floorf(il) - 1.0f, -1.0e6f), 1.0e6f);
+        imax = (int)fminf(fmaxf(ceilf(ih) + 1.0f, -1.0e6f), 1.0e6f);
     }
+    out[4] = make_float4(__int_as_float(jmin), __int_as_float(jmax), __int_as_float(imin), __int_as_float(imax));
 }
 
 // per pixel x primitive forward quantities
@@ -194,70 +203,138 @@ __device__ inline void eval_prim(const float4 r0, const float4 r1, const float4 
     q.wgt = q.a * q.E;
 }
 
-// visibility mask of primitives [k0, k0+64) for this wave's pixel tile
-__device__ inline unsigned long long tile_mask(const float4* rec, int k0, int K, int c0, int c1, int r0, int r1) {
+// gradient of the loss w.r.t. the primitive's ray coefficients through one pixel:
+// go = dL/do~ (3), gd = dL/dd~ (3), given gz = dL/dz and gm2 = dL/dm2 of this pixel x primitive
+__device__ inline void prim_backward(const float4 r0, const PixPrim& q, float gz, float gm2, float go[3],
+                                     float gd[3]) {
+    const float o[3] = {r0.x, r0.y, r0.z};
+    if (__float_as_int(r0.w) == VPN_SPHERE) {
+        const float hoc = 0.5f / q.chord;
+        const float gchord = -gz;                       // z = s - chord, chord = sqrt(h * invA)
+        const float gh = gchord * hoc * q.invA;
+        float ginvA = gchord * hoc * q.h;
+        if (q.hpos > 0.0f) gm2 -= gh;                   // h = relu(1 - m2) + eps
+        float gs = gz;
+        const float gwv[3] = {2.0f * gm2 * q.wv[0], 2.0f * gm2 * q.wv[1], 2.0f * gm2 * q.wv[2]};   // m2 = w.w
+        gs += gwv[0] * q.d[0] + gwv[1] * q.d[1] + gwv[2] * q.d[2];                                  // w = o + s d
+        const float gBq = -gs * q.invA;                 // s = -Bq * invA
+        ginvA -= gs * q.Bq;
+        const float gAq = -ginvA * q.invA * q.invA;     // invA = 1 / (d.d)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            go[i] = gwv[i] + gBq * q.d[i];
+            gd[i] = q.s * gwv[i] + 2.0f * gAq * q.d[i] + gBq * o[i];
+        }
+    } else {
+        // z = tn[zi] = -(L sg + o_zi) / dsafe
+        const int zi = q.zi;
+        const float dzi = zi == 0 ? q.d[0] : (zi == 1 ? q.d[1] : q.d[2]);
+        const float sg = dzi < 0.0f ? -1.0f : 1.0f;
+        const float ids = 1.0f / q.dsafe;
+        const float gL = -gz * sg * ids;
+        const float go_z = -gz * ids;
+        const float gd_z = fabsf(dzi) < R_EPS_D ? 0.0f : -gz * q.tn * ids;
+        float glam = 2.0f * q.lam * gm2;                // m2 = lam^2
+        if (q.lam >= 1.0f) glam += gL;                  // L = max(lam, 1)
+        // lam = |n| / den
+        const float sn = q.n > 0.0f ? 1.0f : (q.n < 0.0f ? -1.0f : 0.0f);
+        const float gn = glam * sn / q.den;
+        const float gden = -glam * q.lam / q.den;
+        // pair (i,j): sel 0 -> (0,1), 1 -> (0,2), 2 -> (1,2);  n = o_j d_i - o_i d_j, den = |d_i| + |d_j| + eps
+        const int pi = q.sel == 2 ? 1 : 0, pj = q.sel == 0 ? 1 : 2;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            float g_o = 0.f, g_d = 0.f;
+            const float sd = q.d[i] > 0.0f ? 1.0f : (q.d[i] < 0.0f ? -1.0f : 0.0f);
+            if (i == pi) {
+                const float oj = pj == 1 ? o[1] : o[2], dj = pj == 1 ? q.d[1] : q.d[2];
+                g_d += gn * oj + gden * sd;
+                g_o -= gn * dj;
+            }
+            if (i == pj) {
+                const float oi = pi == 0 ? o[0] : o[1], di = pi == 0 ? q.d[0] : q.d[1];
+                g_o += gn * di;
+                g_d += -gn * oi + gden * sd;
+            }
+            if (i == zi) { g_o += go_z; g_d += gd_z; }
+            go[i] = g_o; gd[i] = g_d;
+        }
+    }
+}
+
+// stage the image's K records into LDS (coalesced float4 loads)
+__device__ inline void stage_records(const float4* __restrict__ rec_b, int K, float4* lds) {
+    for (int i = threadIdx.x; i < K * R_REC; i += 64) lds[i] = rec_b[i];
+    __syncthreads();
+}
+
+// visibility mask of primitives [k0, k0+64) for this wave's 16x16 tile
+__device__ inline unsigned long long tile_mask(const float4* lds, int k0, int K, int c0, int r0) {
     const int lane = threadIdx.x & 63;
     bool vis = false;
     if (k0 + lane < K) {
-        float4 bb = rec[(k0 + lane) * R_REC + 4];
+        float4 bb = lds[(k0 + lane) * R_REC + 4];
         int jmin = __float_as_int(bb.x), jmax = __float_as_int(bb.y);
         int imin = __float_as_int(bb.z), imax = __float_as_int(bb.w);
-        vis = (jmin <= c1) && (jmax >= c0) && (imin <= r1) && (imax >= r0);
+        vis = (jmin <= c0 + R_TW - 1) && (jmax >= c0) && (imin <= r0 + R_TH - 1) && (imax >= r0);
     }
     return __ballot(vis);
 }
 
-__device__ inline void pixel_slopes(int col, int row, int H, int W, float& px, float& py) {
-    px = ((2.0f * ((float)col + 0.5f) / (float)W) - 1.0f) * (R_TAN_HALF_FOV * (float)W / (float)H);
-    py = (1.0f - (2.0f * ((float)row + 0.5f) / (float)H)) * R_TAN_HALF_FOV;
-}
-
-__global__ __launch_bounds__(256) void raster_fwd_kernel(const float* __restrict__ params,
-                                                         const int32_t* __restrict__ kinds,
-                                                         const float* __restrict__ cam, int K, int H, int W,
-                                                         float sigma, float gamma, float z_far,
-                                                         float* __restrict__ alpha, float* __restrict__ depth,
-                                                         float* __restrict__ aux) {
-    // dynamic LDS only (no static __shared__ in front of it: keeps the base 16-byte aligned)
-    extern __shared__ __attribute__((aligned(16))) float4 rec[];   // [K*5] records | Camera
-    Camera& C = *reinterpret_cast<Camera*>(rec + (size_t)K * R_REC);
+__global__ __launch_bounds__(64) void raster_fwd_kernel(const float4* __restrict__ rec, const float* __restrict__ cam,
+                                                        int K, int H, int W, float sigma, float gamma, float z_far,
+                                                        float* __restrict__ alpha, float* __restrict__ depth,
+                                                        float* __restrict__ aux) {
+    extern __shared__ __attribute__((aligned(16))) float4 lds[];   // [K*5]
     const int b = blockIdx.z;
-    if (threadIdx.x == 0) C = make_camera(cam + b * 3);
-    __syncthreads();
-    stage_primitives(params + (size_t)b * K * VPN_PARAM_STRIDE, kinds, C, K, H, W, sigma, rec);
-    __syncthreads();
+    stage_records(rec + (size_t)b * K * R_REC, K, lds);
+    const int lane = threadIdx.x;
+    const int c0 = blockIdx.x * R_TW, r0 = blockIdx.y * R_TH;
+    const int col = c0 + (lane & 15), rbase = r0 + (lane >> 4);
+    const float px = ((2.0f * ((float)col + 0.5f) / (float)W) - 1.0f) * (R_TAN_HALF_FOV * (float)W / (float)H);
+    float py[R_PPL];
+#pragma unroll
+    for (int s = 0; s < R_PPL; ++s)
+        py[s] = (1.0f - (2.0f * ((float)(rbase + 4 * s) + 0.5f) / (float)H)) * R_TAN_HALF_FOV;
+    const float inv_sigma = 1.0f / sigma, inv_gamma = 1.0f / gamma, zref = cam[b * 3];
 
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int c0 = blockIdx.x * R_BW, r0 = blockIdx.y * R_BH + wave * 4;
-    const int col = c0 + (lane & 15), row = r0 + (lane >> 4);
-    float px, py;
-    pixel_slopes(col, row, H, W, px, py);
-    const float inv_sigma = 1.0f / sigma, inv_gamma = 1.0f / gamma, zref = C.dist;
-
-    float P = 1.0f, S0 = 0.0f, S1 = 0.0f;
+    float P[R_PPL], S0[R_PPL], S1[R_PPL];
+#pragma unroll
+    for (int s = 0; s < R_PPL; ++s) { P[s] = 1.0f; S0[s] = 0.0f; S1[s] = 0.0f; }
     for (int k0 = 0; k0 < K; k0 += 64) {
-        unsigned long long m = tile_mask(rec, k0, K, c0, c0 + R_BW - 1, r0, r0 + 3);
+        unsigned long long m = tile_mask(lds, k0, K, c0, r0);
         while (m) {
             const int k = k0 + __builtin_ctzll(m);
             m &= m - 1;
-            PixPrim q;
-            eval_prim(rec[k * R_REC], rec[k * R_REC + 1], rec[k * R_REC + 2], rec[k * R_REC + 3], px, py,
-                      inv_sigma, inv_gamma, zref, q);
-            P *= q.c;
-            S0 += q.wgt;
-            S1 += q.wgt * q.z;
+            const float4 q0 = lds[k * R_REC], q1 = lds[k * R_REC + 1], q2 = lds[k * R_REC + 2],
+                         q3 = lds[k * R_REC + 3], bb = lds[k * R_REC + 4];
+            const int imin = __float_as_int(bb.z), imax = __float_as_int(bb.w);
+#pragma unroll
+            for (int s = 0; s < R_PPL; ++s) {
+                if (imin > r0 + 4 * s + 3 || imax < r0 + 4 * s) continue;   // wave-uniform: row group not touched
+                PixPrim q;
+                eval_prim(q0, q1, q2, q3, px, py[s], inv_sigma, inv_gamma, zref, q);
+                P[s] *= q.c;
+                S0[s] += q.wgt;
+                S1[s] += q.wgt * q.z;
+            }
         }
     }
-    if (col < W && row < H) {
-        const float A = 1.0f - P;
-        const float S = S0 + R_DELTA_S0;
-        const float zbar = S1 / S;
-        const size_t hw = (size_t)H * W, pix = (size_t)row * W + col;
-        alpha[b * hw + pix] = A;
-        depth[b * hw + pix] = z_far + A * (zbar - z_far);
-        aux[(b * 3 + 0) * hw + pix] = P;
-        aux[(b * 3 + 1) * hw + pix] = zbar;
-        aux[(b * 3 + 2) * hw + pix] = S;
+    const size_t hw = (size_t)H * W;
+#pragma unroll
+    for (int s = 0; s < R_PPL; ++s) {
+        const int row = rbase + 4 * s;
+        if (col < W && row < H) {
+            const float A = 1.0f - P[s];
+            const float S = S0[s] + R_DELTA_S0;
+            const float zbar = S1[s] / S;
+            const size_t pix = (size_t)row * W + col;
+            alpha[b * hw + pix] = A;
+            depth[b * hw + pix] = z_far + A * (zbar - z_far);
+            aux[(b * 3 + 0) * hw + pix] = P[s];
+            aux[(b * 3 + 1) * hw + pix] = zbar;
+            aux[(b * 3 + 2) * hw + pix] = S;
+        }
     }
 }
 
@@ -299,133 +376,86 @@ __device__ inline float wave_reduce16(float v[16]) {
     return r;
 }
 
-__global__ __launch_bounds__(256) void raster_bwd_kernel(const float* __restrict__ params,
-                                                         const int32_t* __restrict__ kinds,
-                                                         const float* __restrict__ cam, int K, int H, int W,
-                                                         float sigma, float gamma, float z_far,
-                                                         const float* __restrict__ aux,
-                                                         const float* __restrict__ galpha,
-                                                         const float* __restrict__ gdepth,
-                                                         float* __restrict__ partial) {
-    extern __shared__ __attribute__((aligned(16))) float4 rec[];   // [K*5] records | accum [K][12] | Camera
-    float* accum = reinterpret_cast<float*>(rec + (size_t)K * R_REC);
-    Camera& C = *reinterpret_cast<Camera*>(accum + (size_t)K * 12);
+__global__ __launch_bounds__(64) void raster_bwd_kernel(const float4* __restrict__ rec, const float* __restrict__ cam,
+                                                        int K, int H, int W, float sigma, float gamma, float z_far,
+                                                        const float* __restrict__ aux,
+                                                        const float* __restrict__ galpha,
+                                                        const float* __restrict__ gdepth,
+                                                        float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float4 lds[];   // [K*5] records | accum [K][12]
+    float* accum = reinterpret_cast<float*>(lds + (size_t)K * R_REC);
     const int b = blockIdx.z;
-    if (threadIdx.x == 0) C = make_camera(cam + b * 3);
-    for (int i = threadIdx.x; i < K * 12; i += 256) accum[i] = 0.0f;
-    __syncthreads();
-    stage_primitives(params + (size_t)b * K * VPN_PARAM_STRIDE, kinds, C, K, H, W, sigma, rec);
-    __syncthreads();
+    for (int i = threadIdx.x; i < K * 12; i += 64) accum[i] = 0.0f;
+    stage_records(rec + (size_t)b * K * R_REC, K, lds);
+    const int lane = threadIdx.x;
+    const int c0 = blockIdx.x * R_TW, r0 = blockIdx.y * R_TH;
+    const int col = c0 + (lane & 15), rbase = r0 + (lane >> 4);
+    const float px = ((2.0f * ((float)col + 0.5f) / (float)W) - 1.0f) * (R_TAN_HALF_FOV * (float)W / (float)H);
+    const float inv_sigma = 1.0f / sigma, inv_gamma = 1.0f / gamma, zref = cam[b * 3];
+    const size_t hw = (size_t)H * W;
 
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int c0 = blockIdx.x * R_BW, r0 = blockIdx.y * R_BH + wave * 4;
-    const int col = c0 + (lane & 15), row = r0 + (lane >> 4);
-    float px, py;
-    pixel_slopes(col, row, H, W, px, py);
-    const float inv_sigma = 1.0f / sigma, inv_gamma = 1.0f / gamma, zref = C.dist;
-
-    float gAtot = 0.0f, gZbar = 0.0f, P = 1.0f, zbar = 0.0f, invS = 0.0f;
-    if (col < W && row < H) {
-        const size_t hw = (size_t)H * W, pix = (size_t)row * W + col;
-        P = aux[(b * 3 + 0) * hw + pix];
-        zbar = aux[(b * 3 + 1) * hw + pix];
-        invS = 1.0f / aux[(b * 3 + 2) * hw + pix];
-        const float gA = galpha ? galpha[b * hw + pix] : 0.0f;
-        const float gD = gdepth ? gdepth[b * hw + pix] : 0.0f;
-        gAtot = gA + gD * (zbar - z_far);     // depth = z_far + A (zbar - z_far)
-        gZbar = gD * (1.0f - P);
+    float py[R_PPL], gAtot[R_PPL], gZbar[R_PPL], P[R_PPL], zbar[R_PPL], invS[R_PPL];
+#pragma unroll
+    for (int s = 0; s < R_PPL; ++s) {
+        const int row = rbase + 4 * s;
+        py[s] = (1.0f - (2.0f * ((float)row + 0.5f) / (float)H)) * R_TAN_HALF_FOV;
+        gAtot[s] = 0.0f; gZbar[s] = 0.0f; P[s] = 1.0f; zbar[s] = 0.0f; invS[s] = 0.0f;
+        if (col < W && row < H) {
+            const size_t pix = (size_t)row * W + col;
+            P[s] = aux[(b * 3 + 0) * hw + pix];
+            zbar[s] = aux[(b * 3 + 1) * hw + pix];
+            invS[s] = 1.0f / aux[(b * 3 + 2) * hw + pix];
+            const float gA = galpha ? galpha[b * hw + pix] : 0.0f;
+            const float gD = gdepth ? gdepth[b * hw + pix] : 0.0f;
+            gAtot[s] = gA + gD * (zbar[s] - z_far);     // depth = z_far + A (zbar - z_far)
+            gZbar[s] = gD * (1.0f - P[s]);
+        }
     }
 
     for (int k0 = 0; k0 < K; k0 += 64) {
-        unsigned long long m = tile_mask(rec, k0, K, c0, c0 + R_BW - 1, r0, r0 + 3);
+        unsigned long long m = tile_mask(lds, k0, K, c0, r0);
         while (m) {
             const int k = k0 + __builtin_ctzll(m);
             m &= m - 1;
-            const float4 q0 = rec[k * R_REC];
-            PixPrim q;
-            eval_prim(q0, rec[k * R_REC + 1], rec[k * R_REC + 2], rec[k * R_REC + 3], px, py, inv_sigma,
-                      inv_gamma, zref, q);
-            const float o[3] = {q0.x, q0.y, q0.z};
-            // composite backward
-            const float gw = gZbar * (q.z - zbar) * invS;
-            float gz = gZbar * q.wgt * invS;
-            if (q.ein) gz -= gw * q.wgt * inv_gamma;
-            const float ga = gAtot * (P / q.c) + gw * q.E;
-            const float gx = q.xin ? ga * q.a * q.c : 0.0f;
-            float gm2 = -gx * inv_sigma;
-            float go[3] = {0.f, 0.f, 0.f}, gd[3] = {0.f, 0.f, 0.f};
-            if (__float_as_int(q0.w) == VPN_SPHERE) {
-                const float hoc = 0.5f / q.chord;
-                const float gchord = -gz;
-                const float gh = gchord * hoc * q.invA;
-                float ginvA = gchord * hoc * q.h;
-                if (q.hpos > 0.0f) gm2 -= gh;
-                float gs = gz;
-                const float gwv[3] = {2.0f * gm2 * q.wv[0], 2.0f * gm2 * q.wv[1], 2.0f * gm2 * q.wv[2]};
-                gs += gwv[0] * q.d[0] + gwv[1] * q.d[1] + gwv[2] * q.d[2];
-                const float gBq = -gs * q.invA;
-                ginvA -= gs * q.Bq;
-                const float gAq = -ginvA * q.invA * q.invA;
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    go[i] = gwv[i] + gBq * q.d[i];
-                    gd[i] = q.s * gwv[i] + 2.0f * gAq * q.d[i] + gBq * o[i];
-                }
-            } else {
-                // z = tn[zi] = -(L sg + o_zi) / dsafe
-                const int zi = q.zi;
-                const float dzi = zi == 0 ? q.d[0] : (zi == 1 ? q.d[1] : q.d[2]);
-                const float sg = dzi < 0.0f ? -1.0f : 1.0f;
-                const float ids = 1.0f / q.dsafe;
-                const float gL = -gz * sg * ids;
-                const float go_z = -gz * ids;
-                const float gd_z = fabsf(dzi) < R_EPS_D ? 0.0f : -gz * q.tn * ids;
-                float glam = 2.0f * q.lam * gm2;
-                if (q.lam >= 1.0f) glam += gL;
-                // lam = |n| / den
-                const float sn = q.n > 0.0f ? 1.0f : (q.n < 0.0f ? -1.0f : 0.0f);
-                const float gn = glam * sn / q.den;
-                const float gden = -glam * q.lam / q.den;
-                // pair (i,j): sel 0 -> (0,1), 1 -> (0,2), 2 -> (1,2);  n = o_j d_i - o_i d_j
-                const int pi = q.sel == 2 ? 1 : 0, pj = q.sel == 0 ? 1 : 2;
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    float g_o = 0.f, g_d = 0.f;
-                    const float sd = q.d[i] > 0.0f ? 1.0f : (q.d[i] < 0.0f ? -1.0f : 0.0f);
-                    if (i == pi) {
-                        const float oj = pj == 1 ? o[1] : o[2], dj = pj == 1 ? q.d[1] : q.d[2];
-                        g_d += gn * oj + gden * sd;
-                        g_o -= gn * dj;
-                    }
-                    if (i == pj) {
-                        const float oi = pi == 0 ? o[0] : o[1], di = pi == 0 ? q.d[0] : q.d[1];
-                        g_o += gn * di;
-                        g_d += -gn * oi + gden * sd;
-                    }
-                    if (i == zi) { g_o += go_z; g_d += gd_z; }
-                    go[i] = g_o; gd[i] = g_d;
-                }
-            }
+            const float4 q0 = lds[k * R_REC], q1 = lds[k * R_REC + 1], q2 = lds[k * R_REC + 2],
+                         q3 = lds[k * R_REC + 3], bb = lds[k * R_REC + 4];
+            const int imin = __float_as_int(bb.z), imax = __float_as_int(bb.w);
             float v[16];
-            v[0] = go[0]; v[1] = go[1]; v[2] = go[2];
-            v[3] = px * gd[0]; v[4] = px * gd[1]; v[5] = px * gd[2];
-            v[6] = py * gd[0]; v[7] = py * gd[1]; v[8] = py * gd[2];
-            v[9] = gd[0]; v[10] = gd[1]; v[11] = gd[2];
-            v[12] = 0.f; v[13] = 0.f; v[14] = 0.f; v[15] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < R_PPL; ++s) {
+                if (imin > r0 + 4 * s + 3 || imax < r0 + 4 * s) continue;
+                PixPrim q;
+                eval_prim(q0, q1, q2, q3, px, py[s], inv_sigma, inv_gamma, zref, q);
+                // composite backward
+                const float gw = gZbar[s] * (q.z - zbar[s]) * invS[s];
+                float gz = gZbar[s] * q.wgt * invS[s];
+                if (q.ein) gz -= gw * q.wgt * inv_gamma;
+                const float ga = gAtot[s] * (P[s] / q.c) + gw * q.E;
+                const float gx = q.xin ? ga * q.a * q.c : 0.0f;
+                const float gm2 = -gx * inv_sigma;
+                float go[3], gd[3];
+                prim_backward(q0, q, gz, gm2, go, gd);
+                v[0] += go[0]; v[1] += go[1]; v[2] += go[2];
+                v[3] += px * gd[0]; v[4] += px * gd[1]; v[5] += px * gd[2];
+                v[6] += py[s] * gd[0]; v[7] += py[s] * gd[1]; v[8] += py[s] * gd[2];
+                v[9] += gd[0]; v[10] += gd[1]; v[11] += gd[2];
+            }
             const float tot = wave_reduce16(v);
-            if ((lane & 3) == 0 && (lane >> 2) < 12) atomicAdd(&accum[k * 12 + (lane >> 2)], tot);
+            if ((lane & 3) == 0 && (lane >> 2) < 12) accum[k * 12 + (lane >> 2)] = tot;   // one writer per slot
         }
     }
     __syncthreads();
-    const int nblk = gridDim.x * gridDim.y, blk = blockIdx.y * gridDim.x + blockIdx.x;
-    float* out = partial + ((size_t)b * nblk + blk) * K * 12;
-    for (int i = threadIdx.x; i < K * 12; i += 256) out[i] = accum[i];
+    const int ntile = gridDim.x * gridDim.y, tile = blockIdx.y * gridDim.x + blockIdx.x;
+    float* out = partial + ((size_t)b * ntile + tile) * K * 12;
+    for (int i = threadIdx.x; i < K * 12; i += 64) out[i] = accum[i];
 }
 
-// one wave per (b,k): sum the per-block partials, then chain rule to (v,q,t)
+// one wave per (b,k): sum the per-tile partials in a fixed order, then chain rule to (v,q,t)
 __global__ __launch_bounds__(256) void raster_bwd_finish_kernel(const float* __restrict__ params,
                                                                 const float* __restrict__ cam, int BK, int K,
-                                                                int nblk, const float* __restrict__ partial,
+                                                                int ntile, const float* __restrict__ partial,
                                                                 float* __restrict__ gparams) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int bk = blockIdx.x * 4 + wave;
@@ -434,10 +464,12 @@ __global__ __launch_bounds__(256) void raster_bwd_finish_kernel(const float* __r
     float v[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) v[i] = 0.0f;
-    for (int blk = lane; blk < nblk; blk += 64) {
-        const float* src = partial + (((size_t)b * nblk + blk) * K + k) * 12;
-#pragma unroll
-        for (int i = 0; i < 12; ++i) v[i] += src[i];
+    for (int tile = lane; tile < ntile; tile += 64) {
+        const float4* src = reinterpret_cast<const float4*>(partial + (((size_t)b * ntile + tile) * K + k) * 12);
+        const float4 a = src[0], c = src[1], d = src[2];
+        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+        v[4] += c.x; v[5] += c.y; v[6] += c.z; v[7] += c.w;
+        v[8] += d.x; v[9] += d.y; v[10] += d.z; v[11] += d.w;
     }
     const float tot = wave_reduce16(v);
     // gather the 12 totals into lane 0
@@ -475,9 +507,9 @@ __global__ __launch_bounds__(256) void raster_bwd_finish_kernel(const float* __r
     o[7] = gt[0]; o[8] = gt[1]; o[9] = gt[2];
 }
 
-constexpr size_t R_CAM_BYTES = 64;   // Camera (13 floats) rounded up
-static inline size_t fwd_lds(int K) { return (size_t)K * R_REC * sizeof(float4) + R_CAM_BYTES; }
-static inline size_t bwd_lds(int K) { return (size_t)K * (R_REC * sizeof(float4) + 12 * sizeof(float)) + R_CAM_BYTES; }
+static inline dim3 raster_grid(int B, int H, int W) { return dim3((W + R_TW - 1) / R_TW, (H + R_TH - 1) / R_TH, B); }
+static inline size_t fwd_lds(int K) { return (size_t)K * R_REC * sizeof(float4); }
+static inline size_t bwd_lds(int K) { return (size_t)K * (R_REC * sizeof(float4) + 12 * sizeof(float)); }
 
 // kernels may need more than the 64 KB default of dynamic LDS (K up to VPN_MAX_PRIMS)
 static int raise_lds_limit() {
@@ -493,8 +525,6 @@ static int raise_lds_limit() {
     return 0;
 }
 
-static inline dim3 raster_grid(int B, int H, int W) { return dim3((W + R_BW - 1) / R_BW, (H + R_BH - 1) / R_BH, B); }
-
 }  // namespace vpn
 
 using namespace vpn;
@@ -503,20 +533,30 @@ static int raster_check(const void* params, const void* kinds, const void* cam, 
                         float sigma, float gamma) {
     if (!params || !kinds || !cam) return VPN_E_BADARG;
     if (B <= 0 || K <= 0 || H <= 0 || W <= 0 || !(sigma > 0.f) || !(gamma > 0.f)) return VPN_E_BADARG;
-    if (K > VPN_MAX_PRIMS || B > 65535 || (H + R_BH - 1) / R_BH > 65535) return VPN_E_TOOBIG;
+    if (K > VPN_MAX_PRIMS || B > 65535 || (H + R_TH - 1) / R_TH > 65535) return VPN_E_TOOBIG;
     return 0;
+}
+
+extern "C" size_t vpn_raster_records_size(int B, int K) {
+    if (B <= 0 || K <= 0) return 0;
+    return (size_t)B * K * R_REC * sizeof(float4);
 }
 
 extern "C" int vpn_raster_fwd(const float* params, const int32_t* kinds, const float* cam, int B, int K, int H,
                               int W, float sigma, float gamma, float z_far, float* alpha, float* depth, float* aux,
-                              void* stream) {
+                              void* records, void* stream) {
     int rc = raster_check(params, kinds, cam, B, K, H, W, sigma, gamma);
     if (rc) return rc;
-    if (!alpha || !depth || !aux) return VPN_E_BADARG;
+    if (!alpha || !depth || !aux || !records) return VPN_E_BADARG;
+    if (((uintptr_t)records & 15) != 0) return VPN_E_BADARG;
+    const int BK = B * K;
+    hipLaunchKernelGGL(raster_prep_kernel, dim3((BK + 255) / 256), dim3(256), 0, (hipStream_t)stream, params, kinds,
+                       cam, BK, K, H, W, sigma, (float4*)records);
+    VPN_LAUNCH_CHECK();
     size_t lds = fwd_lds(K);
     if (lds > 65536 && (rc = raise_lds_limit())) return rc;
-    hipLaunchKernelGGL(raster_fwd_kernel, raster_grid(B, H, W), dim3(256), lds, (hipStream_t)stream, params, kinds,
-                       cam, K, H, W, sigma, gamma, z_far, alpha, depth, aux);
+    hipLaunchKernelGGL(raster_fwd_kernel, raster_grid(B, H, W), dim3(64), lds, (hipStream_t)stream,
+                       (const float4*)records, cam, K, H, W, sigma, gamma, z_far, alpha, depth, aux);
     VPN_LAUNCH_CHECK();
     return 0;
 }
@@ -528,16 +568,17 @@ extern "C" size_t vpn_raster_bwd_workspace(int B, int K, int H, int W) {
 }
 
 extern "C" int vpn_raster_bwd(const float* params, const int32_t* kinds, const float* cam, int B, int K, int H,
-                              int W, float sigma, float gamma, float z_far, const float* aux,
+                              int W, float sigma, float gamma, float z_far, const float* aux, const void* records,
                               const float* grad_alpha, const float* grad_depth, void* workspace,
                               float* grad_params, void* stream) {
     int rc = raster_check(params, kinds, cam, B, K, H, W, sigma, gamma);
     if (rc) return rc;
-    if (!aux || !workspace || !grad_params) return VPN_E_BADARG;
+    if (!aux || !records || !workspace || !grad_params) return VPN_E_BADARG;
+    if (((uintptr_t)records & 15) != 0 || ((uintptr_t)workspace & 15) != 0) return VPN_E_BADARG;
     dim3 g = raster_grid(B, H, W);
     size_t lds = bwd_lds(K);
     if (lds > 65536 && (rc = raise_lds_limit())) return rc;
-    hipLaunchKernelGGL(raster_bwd_kernel, g, dim3(256), lds, (hipStream_t)stream, params, kinds, cam, K, H, W,
+    hipLaunchKernelGGL(raster_bwd_kernel, g, dim3(64), lds, (hipStream_t)stream, (const float4*)records, cam, K, H, W,
                        sigma, gamma, z_far, aux, grad_alpha, grad_depth, (float*)workspace);
     VPN_LAUNCH_CHECK();
     const int BK = B * K;

@@ -11,24 +11,16 @@ from ..primitives import pack_primitives
 
 
 class Sampling:
-    # The reference draws from torch's global generator (sphere.py:26-27, cuboid.py:66).
-    # Here draws come from Philox keyed by (seed, call counter, sample, point): the seed is
-    # torch's (torch.manual_seed -> train.py:25), the counter advances per call so successive
-    # primitives get different draws, and restarts when the seed changes.
-    _seed = None
-    _calls = 0
-
+    # The reference draws its uniforms from torch's global generator (sphere.py:26-27,
+    # cuboid.py:66).  Here the uniforms come from in-kernel Philox; the 63-bit key of each call
+    # is drawn from torch's global (CPU) generator, so torch.manual_seed (train.py:25) makes a
+    # run reproducible and successive calls get independent streams, like the reference.
     def __init__(self):
         pass
 
-    @classmethod
-    def _next_stream(cls):
-        seed = torch.initial_seed()
-        if seed != cls._seed:
-            cls._seed, cls._calls = seed, 0
-        cls._calls += 1
-        # fold the call counter into the key so every call is an independent stream
-        return (seed ^ (cls._calls * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
+    @staticmethod
+    def _next_stream():
+        return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
 
     @classmethod
     def _single(cls, kind, v, q, t, num_points, u, seed, sample_base):

@@ -160,22 +160,23 @@ class RasterFunction(Function):
         alpha = torch.empty((B, H, W), dtype=torch.float32, device=dev)
         depth = torch.empty((B, H, W), dtype=torch.float32, device=dev)
         aux = torch.empty((B, 3, H, W), dtype=torch.float32, device=dev)
+        rec = torch.empty((_lib.lib().vpn_raster_records_size(B, K) // 4,), dtype=torch.float32, device=dev)
         _lib.call('vpn_raster_fwd', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(cam), B, K, H, W,
-                                            float(sigma), float(gamma), float(z_far), _lib.ptr(alpha),
-                                            _lib.ptr(depth), _lib.ptr(aux), _lib.stream())
-        ctx.save_for_backward(params, kinds, cam, aux)
+                  float(sigma), float(gamma), float(z_far), _lib.ptr(alpha), _lib.ptr(depth), _lib.ptr(aux),
+                  _lib.ptr(rec), _lib.stream())
+        ctx.save_for_backward(params, kinds, cam, aux, rec)
         ctx.meta = (B, K, H, W, float(sigma), float(gamma), float(z_far))
         return alpha, depth
 
     @staticmethod
     def backward(ctx, grad_alpha, grad_depth):
-        params, kinds, cam, aux = ctx.saved_tensors
+        params, kinds, cam, aux, rec = ctx.saved_tensors
         B, K, H, W, sigma, gamma, z_far = ctx.meta
         ga = _f32c(grad_alpha) if grad_alpha is not None else None
         gd = _f32c(grad_depth) if grad_depth is not None else None
         ws = torch.empty((_lib.lib().vpn_raster_bwd_workspace(B, K, H, W) // 4,), dtype=torch.float32, device=params.device)
         grad_params = torch.empty_like(params)
         _lib.call('vpn_raster_bwd', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(cam), B, K, H, W, sigma, gamma,
-                                    z_far, _lib.ptr(aux), _lib.ptr(ga), _lib.ptr(gd), _lib.ptr(ws),
-                                    _lib.ptr(grad_params), _lib.stream())
+                  z_far, _lib.ptr(aux), _lib.ptr(rec), _lib.ptr(ga), _lib.ptr(gd), _lib.ptr(ws),
+                  _lib.ptr(grad_params), _lib.stream())
         return grad_params, None, None, None, None, None, None, None
