@@ -47,7 +47,7 @@ def main():
     ap.add_argument('--gt-points', type=int, default=2048)
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample', type=int, default=2, help='images in the CPU baseline sample')
+    ap.add_argument('--cpu-sample', type=int, default=1, help='images in the CPU baseline sample')
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -191,7 +191,7 @@ def cpu_baseline(params, gt_points, gt_sil, gt_depth, K, n, H, W, sigma, gamma, 
     the host cores on a bounded sample of the same workload, and compared with the HIP path on
     exactly those samples."""
     from oracle import vpn_oracle as O
-    cores = os.cpu_count() or 1
+    cores = min(16, os.cpu_count() or 1)      # the 1-GPU box's CPU share is 16 cores
     torch.set_num_threads(cores)
     S = params.shape[0]
     u = O.philox_uniforms(1234, 0, S, K, n)
@@ -208,7 +208,7 @@ def cpu_baseline(params, gt_points, gt_sil, gt_depth, K, n, H, W, sigma, gamma, 
             a, d = O.raster(pb, kl, camc[b:b + 1], H, W, sigma, gamma, z_far)
             loss = cd + (a - gt_sil[b:b + 1]).abs().sum() / (S * H * W) + (d - gt_depth[b:b + 1]).abs().sum() / (S * H * W)
             loss.backward()
-            total += float(loss)
+            total += float(loss.detach())
         return total, p.grad
 
     run()                                                # warm-up

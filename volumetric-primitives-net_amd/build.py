@@ -15,6 +15,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libvpn_hip.so')
 SOURCES = ['vpn_api.hip', 'sampler.hip', 'chamfer.hip', 'raster.hip']
 COMMON = ['-O3', '--offload-arch=gfx950', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function']
+COMMON += os.environ.get('VPN_EXTRA_FLAGS', '').split()      # experiments only (e.g. -DVPN_CHAMFER_NO_RESCAN)
 PER_FILE = {
     # index-exact argmin: correctly rounded sqrt (hipcc default) and no contraction (also a pragma in the file)
     'chamfer.hip': ['-ffp-contract=off'],

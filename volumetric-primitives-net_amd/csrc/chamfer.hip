@@ -4,8 +4,8 @@
 // Replaces the dense B*N*M expression of ChamferDistanceLoss.forward
 // (modules/loss/chamfer_distance.py:14-30) and its autograd graph.  Nothing of size
 // B*N*M is materialised: each lane owns R query points in registers, the target cloud
-// streams through an LDS tile (SoA, read as ds_read_b128 broadcasts), and only the N+M
-// minima / arg-minima are written.
+// streams through wave-private LDS tiles (SoA, read as ds_read_b128 broadcasts), two targets
+// are evaluated per packed-fp32 instruction, and only the N+M minima / arg-minima are written.
 //
 // Bit-exactness contract (north_star: "index-exact for the Chamfer argmin"):
 //   d2 = ((dx*dx) + (dy*dy)) + (dz*dz) with every product and sum rounded separately
@@ -17,95 +17,167 @@
 //   before the last update (= min over all earlier indices); if sqrtf(prev) equals the
 //   final minimum the lane re-scans the earlier indices with the sqrt compare.
 #include "vpn_common.h"
+#include <stdlib.h>
 
 #pragma clang fp contract(off)
 
 namespace vpn {
 
-constexpr int CH_BLOCK = 256;
-constexpr int CH_TILE = 1024;   // targets per LDS tile: 3 * 4 KB
+constexpr int CH_BLOCK = 256;    // 4 waves: same queries, each wave scans one contiguous quarter of the targets
+constexpr int CH_WTILE = 256;    // targets per wave-private LDS tile (SoA, 3 KB)
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+#ifdef VPN_CHAMFER_DEBUG
+__device__ unsigned long long g_dbg[8];
+#endif
 
 __device__ inline float dist2_exact(float ax, float ay, float az, float bx, float by, float bz) {
     float dx = ax - bx, dy = ay - by, dz = az - bz;
     return ((dx * dx) + (dy * dy)) + (dz * dz);
 }
 
-// queries q [B,Nq,3], targets t [B,Nt,3] -> dist [B,Nq], idx [B,Nq]
+// running (best d2, first index attaining it, min d2 over all EARLIER indices)
+#define CH_UPDATE(d2v, jv, r)                   \
+    {                                           \
+        const bool up = (d2v) < best[r];        \
+        prev[r] = up ? best[r] : prev[r];       \
+        best[r] = up ? (d2v) : best[r];         \
+        bidx[r] = up ? (jv) : bidx[r];          \
+    }
+
+// queries q [B,Nq,3], targets t [B,Nt,3] -> dist [B,Nq], idx [B,Nq].
+// Block = 64*R queries (lane owns R of them in registers) x 4 waves; wave w scans targets
+// [w*Nw, (w+1)*Nw) through its own LDS tile (no block barrier in the scan), two targets per
+// packed-fp32 instruction; the four partial results are merged in target order.
 template <int R>
 __global__ __launch_bounds__(CH_BLOCK) void chamfer_nn_kernel(const float* __restrict__ qpts,
                                                               const float* __restrict__ tpts, int Nq, int Nt,
                                                               float* __restrict__ out_dist,
                                                               int32_t* __restrict__ out_idx) {
-    __shared__ __attribute__((aligned(16))) float sx[CH_TILE];
-    __shared__ __attribute__((aligned(16))) float sy[CH_TILE];
-    __shared__ __attribute__((aligned(16))) float sz[CH_TILE];
+    __shared__ __attribute__((aligned(16))) float lds[4][3][CH_WTILE];
     const int b = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float* qb = qpts + (size_t)b * Nq * 3;
     const float* tb = tpts + (size_t)b * Nt * 3;
-    const int q0 = blockIdx.x * (CH_BLOCK * R) + threadIdx.x;
+    const int q0 = blockIdx.x * (64 * R) + lane;
 
     float ax[R], ay[R], az[R], best[R], prev[R];
     int bidx[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        int qi = q0 + r * CH_BLOCK;
+        int qi = q0 + r * 64;
         int qc = qi < Nq ? qi : Nq - 1;   // clamp: out-of-range lanes compute a valid point and do not store
         ax[r] = qb[qc * 3]; ay[r] = qb[qc * 3 + 1]; az[r] = qb[qc * 3 + 2];
         best[r] = __builtin_inff(); prev[r] = __builtin_inff(); bidx[r] = 0;
     }
 
-    for (int t0 = 0; t0 < Nt; t0 += CH_TILE) {
-        const int cnt = min(CH_TILE, Nt - t0);
+    const int Nw = (((Nt + 3) >> 2) + 3) & ~3;              // per-wave share, multiple of 4
+    const int w_lo = min(wave * Nw, Nt), w_hi = min(w_lo + Nw, Nt);
+    float* sx = lds[wave][0];
+    float* sy = lds[wave][1];
+    float* sz = lds[wave][2];
+    for (int t0 = w_lo; t0 < w_hi; t0 += CH_WTILE) {
+        const int cnt = min(CH_WTILE, w_hi - t0);
         const int cnt4 = (cnt + 3) & ~3;
-        __syncthreads();
-        // coalesced AoS read of the tile, SoA write into LDS
-        for (int i = threadIdx.x; i < cnt * 3; i += CH_BLOCK) {
+        // the wave's previous tile must be fully read before it is overwritten (LDS ops of one
+        // wave execute in order; the fence only stops the compiler from reordering them)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (int i = lane; i < cnt * 3; i += 64) {          // coalesced AoS read, SoA write
             float val = tb[(size_t)t0 * 3 + i];
             int p = i / 3, c = i - p * 3;
-            float* dst = c == 0 ? sx : (c == 1 ? sy : sz);
-            dst[p] = val;
+            lds[wave][c][p] = val;
         }
-        // pad to a multiple of 4 with a far sentinel (d2 = +inf never beats a finite minimum)
-        if (threadIdx.x < cnt4 - cnt) {
-            sx[cnt + threadIdx.x] = 3.0e38f; sy[cnt + threadIdx.x] = 3.0e38f; sz[cnt + threadIdx.x] = 3.0e38f;
+        if (lane < cnt4 - cnt) {   // pad to a multiple of 4 with a far sentinel (d2 = +inf never wins)
+            sx[cnt + lane] = 3.0e38f; sy[cnt + lane] = 3.0e38f; sz[cnt + lane] = 3.0e38f;
         }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         for (int j = 0; j < cnt4; j += 4) {
             const float4 X = *reinterpret_cast<const float4*>(&sx[j]);
             const float4 Y = *reinterpret_cast<const float4*>(&sy[j]);
             const float4 Z = *reinterpret_cast<const float4*>(&sz[j]);
-            const float xs[4] = {X.x, X.y, X.z, X.w};
-            const float ys[4] = {Y.x, Y.y, Y.z, Y.w};
-            const float zs[4] = {Z.x, Z.y, Z.z, Z.w};
+            const f2 X0 = {X.x, X.y}, X1 = {X.z, X.w};
+            const f2 Y0 = {Y.x, Y.y}, Y1 = {Y.z, Y.w};
+            const f2 Z0 = {Z.x, Z.y}, Z1 = {Z.z, Z.w};
+            const int jb = t0 + j;
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    float d2 = dist2_exact(ax[r], ay[r], az[r], xs[jj], ys[jj], zs[jj]);
-                    bool up = d2 < best[r];
-                    prev[r] = up ? best[r] : prev[r];
-                    best[r] = up ? d2 : best[r];
-                    bidx[r] = up ? (t0 + j + jj) : bidx[r];
-                }
+            for (int r = 0; r < R; ++r) {
+                const f2 qx = {ax[r], ax[r]}, qy = {ay[r], ay[r]}, qz = {az[r], az[r]};
+                // two targets per packed instruction; every product and sum rounded separately
+                f2 dx = qx - X0, dy = qy - Y0, dz = qz - Z0;
+                f2 d2a = ((dx * dx) + (dy * dy)) + (dz * dz);
+                dx = qx - X1; dy = qy - Y1; dz = qz - Z1;
+                f2 d2b = ((dx * dx) + (dy * dy)) + (dz * dz);
+                CH_UPDATE(d2a.x, jb, r)
+                CH_UPDATE(d2a.y, jb + 1, r)
+                CH_UPDATE(d2b.x, jb + 2, r)
+                CH_UPDATE(d2b.y, jb + 3, r)
             }
+        }
+    }
+
+    // ordered merge of the four target quarters through LDS (reuses the tile storage)
+    __syncthreads();
+    float* mb = &lds[0][0][0];                      // [3 waves][3 values][R][64]
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float* dst = mb + (((wave - 1) * 3) * R + r) * 64 + lane;
+            dst[0] = best[r];
+            dst[R * 64] = __int_as_float(bidx[r]);
+            dst[2 * R * 64] = prev[r];
+        }
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float* src = mb + ((w * 3) * R + r) * 64 + lane;
+            const float b2 = src[0], p2 = src[2 * R * 64];
+            const int i2 = __float_as_int(src[R * 64]);
+            const bool up = b2 < best[r];           // later quarter wins only if strictly smaller
+            prev[r] = up ? fminf(best[r], p2) : prev[r];
+            best[r] = up ? b2 : best[r];
+            bidx[r] = up ? i2 : bidx[r];
         }
     }
 
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        int qi = q0 + r * CH_BLOCK;
-        if (qi >= Nq) continue;
-        float s = sqrtf(best[r]);
+        const int qi = q0 + r * 64;
+        const float s = sqrtf(best[r]);
         int idx = bidx[r];
-        // rare: an earlier target has a larger d2 that rounds to the same sqrt -> it wins the tie
-        if (sqrtf(prev[r]) == s) {
-            for (int j = 0; j < idx; ++j) {
-                float d2 = dist2_exact(ax[r], ay[r], az[r], tb[j * 3], tb[j * 3 + 1], tb[j * 3 + 2]);
-                if (sqrtf(d2) == s) { idx = j; break; }
+#ifndef VPN_CHAMFER_NO_RESCAN
+        // Rare (about one query in 1e5..1e6): an EARLIER target has a larger d2 that rounds to the
+        // same sqrt, so it wins the reference's tie rule.  The whole wave re-scans the earlier
+        // targets for that one query, 64 per step, and stops at the first step with a hit.
+        unsigned long long need = __ballot(qi < Nq && sqrtf(prev[r]) == s);
+        while (need) {
+            const int src = __builtin_ctzll(need);
+            need &= need - 1;
+            const float qx = __shfl(ax[r], src, 64), qy = __shfl(ay[r], src, 64), qz = __shfl(az[r], src, 64);
+            const float ss = __shfl(s, src, 64);
+            const int lim = __shfl(idx, src, 64);
+            int found = lim;
+            for (int base = 0; base < lim; base += 64) {
+                const int j = base + lane;
+                bool hit = false;
+                if (j < lim) hit = sqrtf(dist2_exact(qx, qy, qz, tb[j * 3], tb[j * 3 + 1], tb[j * 3 + 2])) == ss;
+                const unsigned long long hm = __ballot(hit);
+                if (hm) { found = base + __builtin_ctzll(hm); break; }
             }
+            if (lane == src) idx = found;
+#ifdef VPN_CHAMFER_DEBUG
+            if (lane == src) { atomicAdd(&g_dbg[0], 1ull); atomicAdd(&g_dbg[3], (unsigned long long)lim); }
+#endif
         }
-        out_dist[(size_t)b * Nq + qi] = s;
-        out_idx[(size_t)b * Nq + qi] = idx;
+#endif
+        if (qi < Nq) {
+            out_dist[(size_t)b * Nq + qi] = s;
+            out_idx[(size_t)b * Nq + qi] = idx;
+        }
     }
 }
 
@@ -187,31 +259,37 @@ __global__ __launch_bounds__(256) void chamfer_bwd_scatter_kernel(
 
 template <int R>
 static int launch_nn(const float* q, const float* t, int B, int Nq, int Nt, float* d, int32_t* idx, hipStream_t s) {
-    int gx = (Nq + CH_BLOCK * R - 1) / (CH_BLOCK * R);
+    int gx = (Nq + 64 * R - 1) / (64 * R);
     hipLaunchKernelGGL(chamfer_nn_kernel<R>, dim3(gx, B), dim3(CH_BLOCK), 0, s, q, t, Nq, Nt, d, idx);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
 
-// pick queries-per-lane so that the launch still has >= ~4 waves per SIMD of the 256 CUs
+// queries per lane: 4 when that still leaves >= 8 waves per SIMD in flight, else 2
 static int pick_r(int B, int Nq) {
-    long waves4 = ((long)B * Nq + 255) / 256;   // waves at R = 4
-    if (waves4 >= 4096) return 4;
-    if (waves4 * 2 >= 4096) return 2;
-    return 1;
+    static int forced = -1;
+    if (forced < 0) {
+        const char* e = getenv("VPN_CHAMFER_R");      // tuning override
+        forced = e ? atoi(e) : 0;
+    }
+    if (forced == 2 || forced == 4) return forced;
+    long blocks4 = ((long)B * Nq + 255) / 256;
+    return blocks4 >= 2048 ? 4 : 2;
 }
 
 static int nn_dispatch(const float* q, const float* t, int B, int Nq, int Nt, float* d, int32_t* idx, hipStream_t s) {
-    switch (pick_r(B, Nq)) {
-        case 4: return launch_nn<4>(q, t, B, Nq, Nt, d, idx, s);
-        case 2: return launch_nn<2>(q, t, B, Nq, Nt, d, idx, s);
-        default: return launch_nn<1>(q, t, B, Nq, Nt, d, idx, s);
-    }
+    return pick_r(B, Nq) == 4 ? launch_nn<4>(q, t, B, Nq, Nt, d, idx, s) : launch_nn<2>(q, t, B, Nq, Nt, d, idx, s);
 }
 
 }  // namespace vpn
 
 using namespace vpn;
+
+#ifdef VPN_CHAMFER_DEBUG
+extern "C" int vpn_debug_read(unsigned long long* out8) {
+    return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_dbg), 64);
+}
+#endif
 
 extern "C" int vpn_chamfer_nn(const float* queries, const float* targets, int B, int Nq, int Nt, float* dist,
                               int32_t* idx, void* stream) {
