@@ -13,9 +13,9 @@
 //   dist = correctly rounded sqrtf(d2);
 //   argmin = lowest index among equal *sqrt* values, which is what torch.min(dim)
 //   returns on sqrt(dist) (chamfer_distance.py:19-23).  sqrt can map two different d2
-//   onto one float, so the scan on d2 also tracks `prev` = the running minimum just
-//   before the last update (= min over all earlier indices); if sqrtf(prev) equals the
-//   final minimum the lane re-scans the earlier indices with the sqrt compare.
+//   onto one float, so the scan on d2 also tracks the running minimum just before the
+//   last update (= min over all targets of earlier groups); if its sqrt equals the final
+//   minimum the wave re-scans the earlier targets with the sqrt compare.
 #include "vpn_common.h"
 #include <stdlib.h>
 
@@ -37,19 +37,13 @@ __device__ inline float dist2_exact(float ax, float ay, float az, float bx, floa
     return ((dx * dx) + (dy * dy)) + (dz * dz);
 }
 
-// running (best d2, first index attaining it, min d2 over all EARLIER indices)
-#define CH_UPDATE(d2v, jv, r)                   \
-    {                                           \
-        const bool up = (d2v) < best[r];        \
-        prev[r] = up ? best[r] : prev[r];       \
-        best[r] = up ? (d2v) : best[r];         \
-        bidx[r] = up ? (jv) : bidx[r];          \
-    }
-
 // queries q [B,Nq,3], targets t [B,Nt,3] -> dist [B,Nq], idx [B,Nq].
 // Block = 64*R queries (lane owns R of them in registers) x 4 waves; wave w scans targets
-// [w*Nw, (w+1)*Nw) through its own LDS tile (no block barrier in the scan), two targets per
-// packed-fp32 instruction; the four partial results are merged in target order.
+// [w*Nw, (w+1)*Nw) through its own LDS tile (no block barrier in the scan).
+// Per group of 8 targets: 8 d2 (two per packed instruction), v_min3 tree, ONE compare and three
+// selects: the scan tracks (best d2, base index of the group that last lowered it, best before
+// that group).  The exact index inside the group and the sqrt tie rule are resolved in the
+// epilogue.  The four partial results are merged in target order.
 template <int R>
 __global__ __launch_bounds__(CH_BLOCK) void chamfer_nn_kernel(const float* __restrict__ qpts,
                                                               const float* __restrict__ tpts, int Nq, int Nt,
@@ -62,24 +56,24 @@ __global__ __launch_bounds__(CH_BLOCK) void chamfer_nn_kernel(const float* __res
     const float* tb = tpts + (size_t)b * Nt * 3;
     const int q0 = blockIdx.x * (64 * R) + lane;
 
-    float ax[R], ay[R], az[R], best[R], prev[R];
-    int bidx[R];
+    float ax[R], ay[R], az[R], best[R], gprev[R];
+    int gidx[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         int qi = q0 + r * 64;
         int qc = qi < Nq ? qi : Nq - 1;   // clamp: out-of-range lanes compute a valid point and do not store
         ax[r] = qb[qc * 3]; ay[r] = qb[qc * 3 + 1]; az[r] = qb[qc * 3 + 2];
-        best[r] = __builtin_inff(); prev[r] = __builtin_inff(); bidx[r] = 0;
+        best[r] = __builtin_inff(); gprev[r] = __builtin_inff(); gidx[r] = 0;
     }
 
-    const int Nw = (((Nt + 3) >> 2) + 3) & ~3;              // per-wave share, multiple of 4
+    const int Nw = (((Nt + 3) >> 2) + 7) & ~7;              // per-wave share, multiple of 8
     const int w_lo = min(wave * Nw, Nt), w_hi = min(w_lo + Nw, Nt);
     float* sx = lds[wave][0];
     float* sy = lds[wave][1];
     float* sz = lds[wave][2];
     for (int t0 = w_lo; t0 < w_hi; t0 += CH_WTILE) {
         const int cnt = min(CH_WTILE, w_hi - t0);
-        const int cnt4 = (cnt + 3) & ~3;
+        const int cnt8 = (cnt + 7) & ~7;
         // the wave's previous tile must be fully read before it is overwritten (LDS ops of one
         // wave execute in order; the fence only stops the compiler from reordering them)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -88,30 +82,35 @@ __global__ __launch_bounds__(CH_BLOCK) void chamfer_nn_kernel(const float* __res
             int p = i / 3, c = i - p * 3;
             lds[wave][c][p] = val;
         }
-        if (lane < cnt4 - cnt) {   // pad to a multiple of 4 with a far sentinel (d2 = +inf never wins)
+        if (lane < cnt8 - cnt) {   // pad to a multiple of 8 with a far sentinel (d2 = +inf never wins)
             sx[cnt + lane] = 3.0e38f; sy[cnt + lane] = 3.0e38f; sz[cnt + lane] = 3.0e38f;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        for (int j = 0; j < cnt4; j += 4) {
-            const float4 X = *reinterpret_cast<const float4*>(&sx[j]);
-            const float4 Y = *reinterpret_cast<const float4*>(&sy[j]);
-            const float4 Z = *reinterpret_cast<const float4*>(&sz[j]);
-            const f2 X0 = {X.x, X.y}, X1 = {X.z, X.w};
-            const f2 Y0 = {Y.x, Y.y}, Y1 = {Y.z, Y.w};
-            const f2 Z0 = {Z.x, Z.y}, Z1 = {Z.z, Z.w};
+        for (int j = 0; j < cnt8; j += 8) {
+            const float4 Xa = *reinterpret_cast<const float4*>(&sx[j]), Xb = *reinterpret_cast<const float4*>(&sx[j + 4]);
+            const float4 Ya = *reinterpret_cast<const float4*>(&sy[j]), Yb = *reinterpret_cast<const float4*>(&sy[j + 4]);
+            const float4 Za = *reinterpret_cast<const float4*>(&sz[j]), Zb = *reinterpret_cast<const float4*>(&sz[j + 4]);
+            const f2 X[4] = {{Xa.x, Xa.y}, {Xa.z, Xa.w}, {Xb.x, Xb.y}, {Xb.z, Xb.w}};
+            const f2 Y[4] = {{Ya.x, Ya.y}, {Ya.z, Ya.w}, {Yb.x, Yb.y}, {Yb.z, Yb.w}};
+            const f2 Z[4] = {{Za.x, Za.y}, {Za.z, Za.w}, {Zb.x, Zb.y}, {Zb.z, Zb.w}};
             const int jb = t0 + j;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const f2 qx = {ax[r], ax[r]}, qy = {ay[r], ay[r]}, qz = {az[r], az[r]};
-                // two targets per packed instruction; every product and sum rounded separately
-                f2 dx = qx - X0, dy = qy - Y0, dz = qz - Z0;
-                f2 d2a = ((dx * dx) + (dy * dy)) + (dz * dz);
-                dx = qx - X1; dy = qy - Y1; dz = qz - Z1;
-                f2 d2b = ((dx * dx) + (dy * dy)) + (dz * dz);
-                CH_UPDATE(d2a.x, jb, r)
-                CH_UPDATE(d2a.y, jb + 1, r)
-                CH_UPDATE(d2b.x, jb + 2, r)
-                CH_UPDATE(d2b.y, jb + 3, r)
+                f2 d[4];
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {   // every product and sum rounded separately (contract off)
+                    const f2 dx = qx - X[h], dy = qy - Y[h], dz = qz - Z[h];
+                    d[h] = ((dx * dx) + (dy * dy)) + (dz * dz);
+                }
+                float m = __builtin_fminf(__builtin_fminf(d[0].x, d[0].y), d[1].x);
+                m = __builtin_fminf(__builtin_fminf(m, d[1].y), d[2].x);
+                m = __builtin_fminf(__builtin_fminf(m, d[2].y), d[3].x);
+                m = __builtin_fminf(m, d[3].y);
+                const bool up = m < best[r];            // strict: an equal d2 in a later group never wins
+                gprev[r] = up ? best[r] : gprev[r];
+                best[r] = up ? m : best[r];
+                gidx[r] = up ? jb : gidx[r];
             }
         }
     }
@@ -124,8 +123,8 @@ __global__ __launch_bounds__(CH_BLOCK) void chamfer_nn_kernel(const float* __res
         for (int r = 0; r < R; ++r) {
             float* dst = mb + (((wave - 1) * 3) * R + r) * 64 + lane;
             dst[0] = best[r];
-            dst[R * 64] = __int_as_float(bidx[r]);
-            dst[2 * R * 64] = prev[r];
+            dst[R * 64] = __int_as_float(gidx[r]);
+            dst[2 * R * 64] = gprev[r];
         }
     }
     __syncthreads();
@@ -138,9 +137,9 @@ __global__ __launch_bounds__(CH_BLOCK) void chamfer_nn_kernel(const float* __res
             const float b2 = src[0], p2 = src[2 * R * 64];
             const int i2 = __float_as_int(src[R * 64]);
             const bool up = b2 < best[r];           // later quarter wins only if strictly smaller
-            prev[r] = up ? fminf(best[r], p2) : prev[r];
+            gprev[r] = up ? fminf(best[r], p2) : gprev[r];   // everything in earlier quarters precedes its group
             best[r] = up ? b2 : best[r];
-            bidx[r] = up ? i2 : bidx[r];
+            gidx[r] = up ? i2 : gidx[r];
         }
     }
 
@@ -148,19 +147,29 @@ __global__ __launch_bounds__(CH_BLOCK) void chamfer_nn_kernel(const float* __res
     for (int r = 0; r < R; ++r) {
         const int qi = q0 + r * 64;
         const float s = sqrtf(best[r]);
-        int idx = bidx[r];
+        // inside the winning group: the first target whose sqrt equals s (this covers both the
+        // first target attaining best and an earlier in-group target that ties after sqrt)
+        const int g = gidx[r];
+        int idx = g;
+#pragma unroll
+        for (int e = 7; e >= 0; --e) {
+            const int j = min(g + e, Nt - 1);
+            const float d2 = dist2_exact(ax[r], ay[r], az[r], tb[j * 3], tb[j * 3 + 1], tb[j * 3 + 2]);
+            if (g + e < Nt && sqrtf(d2) == s) idx = g + e;
+        }
 #ifndef VPN_CHAMFER_NO_RESCAN
-        // Rare (about one query in 1e5..1e6): an EARLIER target has a larger d2 that rounds to the
-        // same sqrt, so it wins the reference's tie rule.  The whole wave re-scans the earlier
-        // targets for that one query, 64 per step, and stops at the first step with a hit.
-        unsigned long long need = __ballot(qi < Nq && sqrtf(prev[r]) == s);
+        // Rare (about one query in 1e5..1e6): a target of an EARLIER group has a larger d2 that
+        // rounds to the same sqrt, so it wins the reference's tie rule.  gprev = min d2 over all
+        // earlier groups; the whole wave re-scans them for that one query, 64 per step, and
+        // stops at the first step with a hit.
+        unsigned long long need = __ballot(qi < Nq && sqrtf(gprev[r]) == s);
         while (need) {
             const int src = __builtin_ctzll(need);
             need &= need - 1;
             const float qx = __shfl(ax[r], src, 64), qy = __shfl(ay[r], src, 64), qz = __shfl(az[r], src, 64);
             const float ss = __shfl(s, src, 64);
-            const int lim = __shfl(idx, src, 64);
-            int found = lim;
+            const int lim = __shfl(g, src, 64);
+            int found = -1;
             for (int base = 0; base < lim; base += 64) {
                 const int j = base + lane;
                 bool hit = false;
@@ -168,7 +177,7 @@ __global__ __launch_bounds__(CH_BLOCK) void chamfer_nn_kernel(const float* __res
                 const unsigned long long hm = __ballot(hit);
                 if (hm) { found = base + __builtin_ctzll(hm); break; }
             }
-            if (lane == src) idx = found;
+            if (lane == src && found >= 0) idx = found;
 #ifdef VPN_CHAMFER_DEBUG
             if (lane == src) { atomicAdd(&g_dbg[0], 1ull); atomicAdd(&g_dbg[3], (unsigned long long)lim); }
 #endif
