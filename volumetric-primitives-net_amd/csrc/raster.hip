@@ -41,7 +41,8 @@ constexpr float R_EPS_D = 1e-9f;
 constexpr float R_X_CUT = 32.0f;     // primitives whose coverage logit is below -X_CUT on a tile are skipped
 constexpr int R_TW = 16, R_TH = 16;  // pixel tile per wave
 constexpr int R_PPL = 4;             // pixels per lane (row groups of 4 rows)
-constexpr int R_REC = 5;             // float4 per primitive record
+constexpr int R_REC = 7;             // float4 per primitive record in HBM
+constexpr int R_LREC = 5;            // float4 per primitive staged in LDS (ray coefficients + pixel bbox)
 
 struct Camera {
     float eye[3], right[3], up[3], fwd[3];
@@ -105,32 +106,76 @@ __global__ __launch_bounds__(256) void raster_prep_kernel(const float* __restric
     out[1] = make_float4(G.Mr[0], G.Mr[1], G.Mr[2], 0.f);
     out[2] = make_float4(G.Mu[0], G.Mu[1], G.Mu[2], 0.f);
     out[3] = make_float4(G.Mf[0], G.Mf[1], G.Mf[2], 0.f);
-    // conservative screen box of the bounding sphere of the primitive inflated by lam_cut:
-    // outside it the coverage logit (1 - m2)/sigma is below -X_CUT
-    const float lam_cut = sqrtf(1.0f + R_X_CUT * sigma);
+    // Culling region: rays whose squared miss distance m2 (scaled frame) is <= L2 = lam_cut^2, outside
+    // of which the coverage logit (1 - m2)/sigma is below -X_CUT.  With d~ = M p, p = (px, py, 1) and
+    // M = [Mr Mu Mf]:  m2 <= L2  <=>  q(p) = (u.p)^2 - c p^T G p >= 0,  u = M^T o~, G = M^T M,
+    // c = |o~|^2 - L2: a conic in the image plane (an ellipse when the camera is outside the inflated
+    // primitive).  A cuboid is bounded by the sphere of radius sqrt(3) lam in its scaled frame.
+    float L2 = (1.0f + R_X_CUT * sigma) * 1.004f;
+    if (kind != VPN_SPHERE) L2 *= 3.0f;
     const float txs = R_TAN_HALF_FOV * (float)W / (float)H;
-    float rad = kind == VPN_SPHERE ? fmaxf(v[0], fmaxf(v[1], v[2])) : sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-    rad *= lam_cut * 1.001f;
-    float e[3] = {t[0] - C.eye[0], t[1] - C.eye[1], t[2] - C.eye[2]};
-    float cx = e[0] * C.right[0] + e[1] * C.right[1] + e[2] * C.right[2];
-    float cy = e[0] * C.up[0] + e[1] * C.up[1] + e[2] * C.up[2];
-    float cz = e[0] * C.fwd[0] + e[1] * C.fwd[1] + e[2] * C.fwd[2];
+    const float* col[3] = {G.Mr, G.Mu, G.Mf};
+    float u[3], Gm[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        u[i] = col[i][0] * G.o[0] + col[i][1] * G.o[1] + col[i][2] * G.o[2];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) Gm[i][j] = col[i][0] * col[j][0] + col[i][1] * col[j][1] + col[i][2] * col[j][2];
+    }
+    const float c = (G.o[0] * G.o[0] + G.o[1] * G.o[1] + G.o[2] * G.o[2]) - L2;
+    float Q[3][3], qmax = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { Q[i][j] = u[i] * u[j] - c * Gm[i][j]; qmax = fmaxf(qmax, fabsf(Q[i][j])); }
+    const float qs = 1.0f / qmax;                       // positive scaling keeps the sign of q
+    const float A00 = Q[0][0] * qs, A01 = Q[0][1] * qs, A11 = Q[1][1] * qs;
+    const float b0 = Q[0][2] * qs, b1 = Q[1][2] * qs, c0 = Q[2][2] * qs;
+    const float det = A00 * A11 - A01 * A01;
     int jmin = 0, jmax = W - 1, imin = 0, imax = H - 1;
-    if (cz - rad > 1e-3f && rad == rad) {   // fully in front of the camera: tangent slopes of the sphere
-        float den = cz * cz - rad * rad;
-        float dx = rad * sqrtf(fmaxf(cx * cx + den, 0.f));
-        float dy = rad * sqrtf(fmaxf(cy * cy + den, 0.f));
-        float pxl = (cx * cz - dx) / den, pxh = (cx * cz + dx) / den;
-        float pyl = (cy * cz - dy) / den, pyh = (cy * cz + dy) / den;
-        float jl = (pxl / txs + 1.0f) * (0.5f * W) - 0.5f, jh = (pxh / txs + 1.0f) * (0.5f * W) - 0.5f;
-        float il = (1.0f - pyh / R_TAN_HALF_FOV) * (0.5f * H) - 0.5f;
-        float ih = (1.0f - pyl / R_TAN_HALF_FOV) * (0.5f * H) - 0.5f;
-        jmin = (int)fminf(fmaxf(floorf(jl) - 1.0f, -1.0e6f), 1.0e6f);
-        jmax = (int)fminf(fmaxf(ceilf(jh) + 1.0f, -1.0e6f), 1.0e6f);
-        imin = (int)fminf(fmaxf(floorf(il) - 1.0f, -1.0e6f), 1.0e6f);
-        imax = (int)fminf(fmaxf(ceilf(ih) + 1.0f, -1.0e6f), 1.0e6f);
+    float valid = 0.0f;
+    if (c > 0.0f && A00 < 0.0f && det > 1e-12f) {       // proper ellipse; anything else: keep the full image
+        const float xs = -(A11 * b0 - A01 * b1) / det, ys = -(A00 * b1 - A01 * b0) / det;
+        const float qstar = c0 + b0 * xs + b1 * ys;     // value at the centre
+        if (qstar > 0.0f) {
+            const float hx = sqrtf(qstar * (-A11) / det), hy = sqrtf(qstar * (-A00) / det);
+            const float jl = ((xs - hx) / txs + 1.0f) * (0.5f * W) - 0.5f, jh = ((xs + hx) / txs + 1.0f) * (0.5f * W) - 0.5f;
+            const float il = (1.0f - (ys + hy) / R_TAN_HALF_FOV) * (0.5f * H) - 0.5f;
+            const float ih = (1.0f - (ys - hy) / R_TAN_HALF_FOV) * (0.5f * H) - 0.5f;
+            jmin = (int)fminf(fmaxf(floorf(jl) - 1.0f, -1.0e6f), 1.0e6f);
+            jmax = (int)fminf(fmaxf(ceilf(jh) + 1.0f, -1.0e6f), 1.0e6f);
+            imin = (int)fminf(fmaxf(floorf(il) - 1.0f, -1.0e6f), 1.0e6f);
+            imax = (int)fminf(fmaxf(ceilf(ih) + 1.0f, -1.0e6f), 1.0e6f);
+            valid = 1.0f;
+        } else if (qstar < 0.0f) {                       // empty region: never visible
+            jmin = 1; jmax = 0; imin = 1; imax = 0;
+            valid = 1.0f;
+        }
     }
     out[4] = make_float4(__int_as_float(jmin), __int_as_float(jmax), __int_as_float(imin), __int_as_float(imax));
+    out[5] = make_float4(A00, A01, A11, valid);
+    out[6] = make_float4(b0, b1, c0, det);
+}
+
+// does the region q >= 0 of the conic touch the rectangle [x0,x1] x [y0,y1] (slope units)?  Exact for an
+// ellipse: the centre if it is inside, otherwise the maximum of the concave quadratic over the 4 edges.
+__device__ inline bool conic_hits_rect(const float4 qa, const float4 qb, float x0, float x1, float y0, float y1) {
+    const float A00 = qa.x, A01 = qa.y, A11 = qa.z, b0 = qb.x, b1 = qb.y, c0 = qb.z, det = qb.w;
+    const float xs = -(A11 * b0 - A01 * b1) / det, ys = -(A00 * b1 - A01 * b0) / det;
+    if (xs >= x0 && xs <= x1 && ys >= y0 && ys <= y1) return true;
+    float best = -1.0f;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const float x = e ? x1 : x0;                                         // vertical edges
+        const float lin = A01 * x + b1, cst = (A00 * x + 2.0f * b0) * x + c0;
+        const float yv = fminf(fmaxf(-lin / A11, y0), y1);
+        best = fmaxf(best, (A11 * yv + 2.0f * lin) * yv + cst);
+        const float y = e ? y1 : y0;                                         // horizontal edges
+        const float lin2 = A01 * y + b0, cst2 = (A11 * y + 2.0f * b1) * y + c0;
+        const float xv = fminf(fmaxf(-lin2 / A00, x0), x1);
+        best = fmaxf(best, (A00 * xv + 2.0f * lin2) * xv + cst2);
+    }
+    return best >= 0.0f;
 }
 
 // per pixel x primitive forward quantities
@@ -262,21 +307,37 @@ __device__ inline void prim_backward(const float4 r0, const PixPrim& q, float gz
     }
 }
 
-// stage the image's K records into LDS (coalesced float4 loads)
+// stage the ray coefficients + pixel box of the image's K primitives into LDS
 __device__ inline void stage_records(const float4* __restrict__ rec_b, int K, float4* lds) {
-    for (int i = threadIdx.x; i < K * R_REC; i += 64) lds[i] = rec_b[i];
+    for (int i = threadIdx.x; i < K * R_LREC; i += 64) {
+        const int k = i / R_LREC, f = i - k * R_LREC;
+        lds[i] = rec_b[k * R_REC + f];
+    }
     __syncthreads();
 }
 
-// visibility mask of primitives [k0, k0+64) for this wave's 16x16 tile
-__device__ inline unsigned long long tile_mask(const float4* lds, int k0, int K, int c0, int r0) {
+// visibility mask of primitives [k0, k0+64) for this wave's 16x16 tile: pixel box first, then the
+// exact conic-vs-tile test (one primitive per lane)
+__device__ inline unsigned long long tile_mask(const float4* lds, const float4* __restrict__ rec_b, int k0, int K,
+                                               int c0, int r0, int H, int W) {
     const int lane = threadIdx.x & 63;
     bool vis = false;
     if (k0 + lane < K) {
-        float4 bb = lds[(k0 + lane) * R_REC + 4];
+        float4 bb = lds[(k0 + lane) * R_LREC + 4];
         int jmin = __float_as_int(bb.x), jmax = __float_as_int(bb.y);
         int imin = __float_as_int(bb.z), imax = __float_as_int(bb.w);
         vis = (jmin <= c0 + R_TW - 1) && (jmax >= c0) && (imin <= r0 + R_TH - 1) && (imax >= r0);
+        if (vis) {
+            const float4 qa = rec_b[(k0 + lane) * R_REC + 5];
+            if (qa.w != 0.0f) {
+                const float4 qb = rec_b[(k0 + lane) * R_REC + 6];
+                // tile rectangle in slope units, half a pixel of margin on every side
+                const float sx = 2.0f * (R_TAN_HALF_FOV * (float)W / (float)H) / (float)W, sy = 2.0f * R_TAN_HALF_FOV / (float)H;
+                const float x0 = ((float)c0 - 0.5f * (float)W) * sx, x1 = ((float)(c0 + R_TW) - 0.5f * (float)W) * sx;
+                const float y1 = (0.5f * (float)H - (float)r0) * sy, y0 = (0.5f * (float)H - (float)(r0 + R_TH)) * sy;
+                vis = conic_hits_rect(qa, qb, x0, x1, y0, y1);
+            }
+        }
     }
     return __ballot(vis);
 }
@@ -285,7 +346,7 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(const float4* __restrict
                                                         int K, int H, int W, float sigma, float gamma, float z_far,
                                                         float* __restrict__ alpha, float* __restrict__ depth,
                                                         float* __restrict__ aux) {
-    extern __shared__ __attribute__((aligned(16))) float4 lds[];   // [K*5]
+    extern __shared__ __attribute__((aligned(16))) float4 lds[];   // [K*5]: ray coefficients + pixel box
     const int b = blockIdx.z;
     stage_records(rec + (size_t)b * K * R_REC, K, lds);
     const int lane = threadIdx.x;
@@ -302,12 +363,12 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(const float4* __restrict
 #pragma unroll
     for (int s = 0; s < R_PPL; ++s) { P[s] = 1.0f; S0[s] = 0.0f; S1[s] = 0.0f; }
     for (int k0 = 0; k0 < K; k0 += 64) {
-        unsigned long long m = tile_mask(lds, k0, K, c0, r0);
+        unsigned long long m = tile_mask(lds, rec + (size_t)b * K * R_REC, k0, K, c0, r0, H, W);
         while (m) {
             const int k = k0 + __builtin_ctzll(m);
             m &= m - 1;
-            const float4 q0 = lds[k * R_REC], q1 = lds[k * R_REC + 1], q2 = lds[k * R_REC + 2],
-                         q3 = lds[k * R_REC + 3], bb = lds[k * R_REC + 4];
+            const float4 q0 = lds[k * R_LREC], q1 = lds[k * R_LREC + 1], q2 = lds[k * R_LREC + 2],
+                         q3 = lds[k * R_LREC + 3], bb = lds[k * R_LREC + 4];
             const int imin = __float_as_int(bb.z), imax = __float_as_int(bb.w);
 #pragma unroll
             for (int s = 0; s < R_PPL; ++s) {
@@ -382,8 +443,8 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(const float4* __restrict
                                                         const float* __restrict__ galpha,
                                                         const float* __restrict__ gdepth,
                                                         float* __restrict__ partial) {
-    extern __shared__ __attribute__((aligned(16))) float4 lds[];   // [K*5] records | accum [K][12]
-    float* accum = reinterpret_cast<float*>(lds + (size_t)K * R_REC);
+    extern __shared__ __attribute__((aligned(16))) float4 lds[];   // [K*5]: ray coefficients + pixel box records | accum [K][12]
+    float* accum = reinterpret_cast<float*>(lds + (size_t)K * R_LREC);
     const int b = blockIdx.z;
     for (int i = threadIdx.x; i < K * 12; i += 64) accum[i] = 0.0f;
     stage_records(rec + (size_t)b * K * R_REC, K, lds);
@@ -413,12 +474,12 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(const float4* __restrict
     }
 
     for (int k0 = 0; k0 < K; k0 += 64) {
-        unsigned long long m = tile_mask(lds, k0, K, c0, r0);
+        unsigned long long m = tile_mask(lds, rec + (size_t)b * K * R_REC, k0, K, c0, r0, H, W);
         while (m) {
             const int k = k0 + __builtin_ctzll(m);
             m &= m - 1;
-            const float4 q0 = lds[k * R_REC], q1 = lds[k * R_REC + 1], q2 = lds[k * R_REC + 2],
-                         q3 = lds[k * R_REC + 3], bb = lds[k * R_REC + 4];
+            const float4 q0 = lds[k * R_LREC], q1 = lds[k * R_LREC + 1], q2 = lds[k * R_LREC + 2],
+                         q3 = lds[k * R_LREC + 3], bb = lds[k * R_LREC + 4];
             const int imin = __float_as_int(bb.z), imax = __float_as_int(bb.w);
             float v[16];
 #pragma unroll
@@ -508,8 +569,8 @@ __global__ __launch_bounds__(256) void raster_bwd_finish_kernel(const float* __r
 }
 
 static inline dim3 raster_grid(int B, int H, int W) { return dim3((W + R_TW - 1) / R_TW, (H + R_TH - 1) / R_TH, B); }
-static inline size_t fwd_lds(int K) { return (size_t)K * R_REC * sizeof(float4); }
-static inline size_t bwd_lds(int K) { return (size_t)K * (R_REC * sizeof(float4) + 12 * sizeof(float)); }
+static inline size_t fwd_lds(int K) { return (size_t)K * R_LREC * sizeof(float4); }
+static inline size_t bwd_lds(int K) { return (size_t)K * (R_LREC * sizeof(float4) + 12 * sizeof(float)); }
 
 // kernels may need more than the 64 KB default of dynamic LDS (K up to VPN_MAX_PRIMS)
 static int raise_lds_limit() {
