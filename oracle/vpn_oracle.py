@@ -297,7 +297,7 @@ def philox_uniforms(seed, sample_base, B, K, n):
 FOVY_DEG = 49.13434207744484   # kaolin v0.1 DIBRenderer default field of view (recalled)
 X_CLAMP = 80.0                 # clamp of the coverage logit
 E_CLAMP = 8.0                  # clamp of the soft-min depth logit
-EPS_Z = 1e-4                   # smoothing inside the chord-length sqrt
+EPS_H = 1e-3                   # squareplus smoothing of relu(1 - m2) inside the chord-length sqrt
 DELTA_S0 = 1e-12               # guard of the soft-min normaliser
 EPS_D = 1e-9                   # guard for ray components parallel to a box face
 
@@ -341,7 +341,10 @@ def raster(params, types, cam, H, W, sigma=0.05, gamma=0.1, z_far=2.0):
     in the primitive's scaled frame  o~ = R^T(o - t)/v,  d~ = R^T d / v :
       ellipsoid:  s* = -(o~.d~)/(d~.d~),  w = o~ + s* d~,  m2 = w.w  (squared miss
                   distance of the line from the unit sphere's centre);
-                  z = s* - sqrt((relu(1-m2)+EPS_Z)/(d~.d~))       (entry depth)
+                  z = s* - sqrt(h/(d~.d~)),  h = squareplus(1-m2) = (u + sqrt(u^2+EPS_H))/2
+                  (smooth relu: the entry depth inside, ~s* outside, no kink at the
+                  silhouette edge - a relu there makes the gradient jump by 0.5/sqrt(eps)
+                  exactly where fp32 cannot resolve the sign of 1-m2)
       cuboid:     lam = max over axis pairs (i<j) of |o~_j d~_i - o~_i d~_j| /
                   (|d~_i|+|d~_j|)  (smallest inflation of the unit box the line
                   touches; first pair wins ties), m2 = lam^2;
@@ -377,7 +380,11 @@ def raster(params, types, cam, H, W, sigma=0.05, gamma=0.1, z_far=2.0):
     s_star = -Bq / A
     wv = o + s_star[..., None] * dtl
     m2_s = (wv * wv).sum(-1)
-    z_s = s_star - torch.sqrt((torch.relu(1 - m2_s) + EPS_Z) / A)
+    uu = 1 - m2_s
+    rr = torch.sqrt(uu * uu + EPS_H)
+    # squareplus(u) = (u + sqrt(u^2 + eps)) / 2, written without cancellation for u < 0
+    hh = torch.where(uu >= 0, 0.5 * (uu + rr), (0.5 * EPS_H) / (rr - uu))
+    z_s = s_star - torch.sqrt(hh / A)
 
     if bool(is_box.any()):
         ad = dtl.abs()

@@ -360,6 +360,26 @@ def test_raster_config1_single_sphere(vpn):
     _raster_case(vpn, 4, 1, 64, 64, [0], [1.0, 0.0, 0.0], seed=7)
 
 
+def test_raster_silhouette_edge_conditioning(vpn):
+    """Regression: at 256x256 this primitive has a pixel centre with |1 - m2| ~ 8e-7, below fp32
+    resolution.  A relu(1 - m2) under the chord sqrt made the depth gradient jump there (one pixel
+    changed a gradient component by 0.2 %); the squareplus in the specification removes the kink."""
+    prm = torch.tensor([[[0.11865890771150589, 0.07216037809848785, 0.05546025186777115, 0.7659704685211182,
+                          0.23245269060134888, 0.8456827402114868, 0.648593544960022, 0.1845417320728302,
+                          0.196951225399971, -0.3370204269886017]]])
+    H = W = 256
+    cam = torch.tensor([[1.0, 0.0, 0.0]])
+    Wd = torch.randn(1, H, W, generator=torch.Generator().manual_seed(5))
+    p64 = prm.double().requires_grad_(True)
+    a64, d64 = O.raster(p64, [0], cam.double(), H, W, 0.05, 0.1, 2.0)
+    assert float((a64 - 0.5).abs().min()) < 1e-5          # the ill-conditioned pixel is really there
+    (d64 * Wd.double()).sum().backward()
+    pg = g(prm).requires_grad_(True)
+    a, d = vpn.RasterFunction.apply(pg, vpn.kinds_tensor([0], torch.device(DEV)), g(cam), H, W, 0.05, 0.1, 2.0)
+    (d * g(Wd)).sum().backward()
+    assert rel_err(pg.grad.cpu(), p64.grad) <= RTOL
+
+
 def test_silhouette_loss_and_renderer_surface(vpn):
     gen = torch.Generator().manual_seed(11)
     B, K, H, W = 3, 4, 48, 48

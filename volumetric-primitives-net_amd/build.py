@@ -20,7 +20,7 @@ PER_FILE = {
     # index-exact argmin: correctly rounded sqrt (hipcc default) and no contraction (also a pragma in the file)
     'chamfer.hip': ['-ffp-contract=off'],
     # the raster is compared with a 1e-4 tolerance: 1-ulp v_rcp/v_sqrt instead of the IEEE sequences
-    'raster.hip': ['-fno-hip-fp32-correctly-rounded-divide-sqrt'],
+    'raster.hip': [] if os.environ.get('VPN_RASTER_IEEE') else ['-fno-hip-fp32-correctly-rounded-divide-sqrt'],
 }
 
 

@@ -30,15 +30,24 @@
 //     gradient is bitwise reproducible.
 #include "vpn_common.h"
 
+#ifdef VPN_RASTER_PRECISE_EXP
+#define R_EXP(x) expf(x)
+#else
+#define R_EXP(x) __expf(x)
+#endif
+
 namespace vpn {
 
 constexpr float R_TAN_HALF_FOV = 0.4571428511950223f;   // tan(49.13434207744484 deg / 2): kaolin v0.1 default fov
 constexpr float R_X_CLAMP = 80.0f;
 constexpr float R_E_CLAMP = 8.0f;
-constexpr float R_EPS_Z = 1e-4f;
+constexpr float R_EPS_H = 1e-3f;     // squareplus smoothing of relu(1 - m2) under the chord sqrt
 constexpr float R_DELTA_S0 = 1e-12f;
 constexpr float R_EPS_D = 1e-9f;
-constexpr float R_X_CUT = 32.0f;     // primitives whose coverage logit is below -X_CUT on a tile are skipped
+#ifndef VPN_RASTER_X_CUT
+#define VPN_RASTER_X_CUT 32.0f
+#endif
+constexpr float R_X_CUT = VPN_RASTER_X_CUT;     // primitives whose coverage logit is below -X_CUT on a tile are skipped
 constexpr int R_TW = 16, R_TH = 16;  // pixel tile per wave
 constexpr int R_PPL = 4;             // pixels per lane (row groups of 4 rows)
 constexpr int R_REC = 7;             // float4 per primitive record in HBM
@@ -185,7 +194,7 @@ struct PixPrim {
     float a, c, E, wgt;
     bool xin, ein;
     // ellipsoid intermediates
-    float invA, Bq, s, wv[3], hpos, h, chord;
+    float A, invA, Bq, s, wv[3], rr, h, chord;
     // cuboid intermediates
     float lam, n, den, L, tn, dsafe;
     int sel, zi;
@@ -199,14 +208,15 @@ __device__ inline void eval_prim(const float4 r0, const float4 r1, const float4 
     q.d[1] = r3.y + px * r1.y + py * r2.y;
     q.d[2] = r3.z + px * r1.z + py * r2.z;
     if (kind == VPN_SPHERE) {
-        float A = q.d[0] * q.d[0] + q.d[1] * q.d[1] + q.d[2] * q.d[2];
+        q.A = q.d[0] * q.d[0] + q.d[1] * q.d[1] + q.d[2] * q.d[2];
         q.Bq = o[0] * q.d[0] + o[1] * q.d[1] + o[2] * q.d[2];
-        q.invA = 1.0f / A;
+        q.invA = 1.0f / q.A;
         q.s = -q.Bq * q.invA;
         q.wv[0] = o[0] + q.s * q.d[0]; q.wv[1] = o[1] + q.s * q.d[1]; q.wv[2] = o[2] + q.s * q.d[2];
         q.m2 = q.wv[0] * q.wv[0] + q.wv[1] * q.wv[1] + q.wv[2] * q.wv[2];
-        q.hpos = 1.0f - q.m2;
-        q.h = fmaxf(q.hpos, 0.0f) + R_EPS_Z;
+        const float u = 1.0f - q.m2;                 // h = squareplus(u), cancellation-free for u < 0
+        q.rr = sqrtf(u * u + R_EPS_H);
+        q.h = u >= 0.0f ? 0.5f * (u + q.rr) : (0.5f * R_EPS_H) / (q.rr - u);
         q.chord = sqrtf(q.h * q.invA);
         q.z = q.s - q.chord;
     } else {
@@ -236,7 +246,7 @@ __device__ inline void eval_prim(const float4 r0, const float4 r1, const float4 
     float xr = (1.0f - q.m2) * inv_sigma;
     q.xin = (xr >= -R_X_CLAMP) && (xr <= R_X_CLAMP);
     float x = fminf(fmaxf(xr, -R_X_CLAMP), R_X_CLAMP);
-    float ex = __expf(-fabsf(x));
+    float ex = R_EXP(-fabsf(x));
     float dn = 1.0f / (1.0f + ex);
     float big = dn, small = ex * dn;
     q.a = x >= 0.0f ? big : small;
@@ -244,7 +254,7 @@ __device__ inline void eval_prim(const float4 r0, const float4 r1, const float4 
     float er = (zref - q.z) * inv_gamma;
     q.ein = (er >= -R_E_CLAMP) && (er <= R_E_CLAMP);
     float e = fminf(fmaxf(er, -R_E_CLAMP), R_E_CLAMP);
-    q.E = __expf(e);
+    q.E = R_EXP(e);
     q.wgt = q.a * q.E;
 }
 
@@ -254,11 +264,10 @@ __device__ inline void prim_backward(const float4 r0, const PixPrim& q, float gz
                                      float gd[3]) {
     const float o[3] = {r0.x, r0.y, r0.z};
     if (__float_as_int(r0.w) == VPN_SPHERE) {
-        const float hoc = 0.5f / q.chord;
         const float gchord = -gz;                       // z = s - chord, chord = sqrt(h * invA)
-        const float gh = gchord * hoc * q.invA;
-        float ginvA = gchord * hoc * q.h;
-        if (q.hpos > 0.0f) gm2 -= gh;                   // h = relu(1 - m2) + eps
+        // d chord/d u = (0.5/chord) invA dh/du with dh/du = h/r  ->  0.5 chord / r ;  u = 1 - m2
+        gm2 -= gchord * 0.5f * q.chord / q.rr;
+        float ginvA = gchord * 0.5f * q.chord * q.A;    // d chord/d invA = 0.5 h / chord = 0.5 chord A
         float gs = gz;
         const float gwv[3] = {2.0f * gm2 * q.wv[0], 2.0f * gm2 * q.wv[1], 2.0f * gm2 * q.wv[2]};   // m2 = w.w
         gs += gwv[0] * q.d[0] + gwv[1] * q.d[1] + gwv[2] * q.d[2];                                  // w = o + s d
