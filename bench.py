@@ -47,6 +47,7 @@ def main():
     ap.add_argument('--gt-points', type=int, default=2048)
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='launch every step eagerly instead of replaying a HIP graph')
     ap.add_argument('--cpu-sample', type=int, default=32, help='images in the CPU baseline sample')
     args = ap.parse_args()
 
@@ -94,8 +95,9 @@ def main():
         params.grad = None
         pts = vpn_amd.Sampling.sample_primitives(params, kinds, n, seed=1234 + i, sample_base=rank * B)
         cd = cd_fn(pts, gt_points)
-        alpha, depth = vpn_amd.RasterFunction.apply(params, kinds, cam, H, W, sigma, gamma, z_far)
-        loss = cd + (alpha - gt_sil).abs().mean() + (depth - gt_depth).abs().mean()
+        # SilhouetteLoss (L1, silhouette.py:11) + L1 depth loss, fused into the raster pass
+        img = vpn_amd.RasterLossFunction.apply(params, kinds, cam, gt_sil, gt_depth, H, W, sigma, gamma, z_far, False)
+        loss = cd + img[0] + img[1]
         loss.backward()
         if reducer is not None:
             return reducer.reduce(params.grad, loss)
@@ -106,12 +108,44 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The step is launch-bound on the host when issued eagerly (about 20 launches of 5-200 us), so the
+    # compute part is captured once into a HIP graph and replayed; the RCCL all-reduce stays outside.
+    use_graph = not args.no_graph
+    run_step = step
+    if use_graph:
+        def compute(i):
+            params.grad = None
+            pts = vpn_amd.Sampling.sample_primitives(params, kinds, n, seed=1234 + i, sample_base=rank * B)
+            cd = cd_fn(pts, gt_points)
+            img = vpn_amd.RasterLossFunction.apply(params, kinds, cam, gt_sil, gt_depth, H, W, sigma, gamma, z_far, False)
+            loss = cd + img[0] + img[1]
+            loss.backward()
+            return loss
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for i in range(3):
+                compute(i)                       # warm the allocator / autograd on the capture stream
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        params.grad = None
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            g_loss = compute(0)
+        g_grad = params.grad
+
+        def run_step(i):
+            graph.replay()
+            if reducer is not None:
+                return reducer.reduce(g_grad, g_loss)
+            return g_grad, g_loss
+
     for i in range(args.warmup):
-        step(i)
+        run_step(i)
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(args.warmup + i)
+        run_step(args.warmup + i)
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -128,28 +162,22 @@ def main():
             step(i)
     ktimes = kt.summary()          # name -> (calls, mean ms); vpn_chamfer_nn mixes both directions
     # split the two chamfer directions (first call of a step = p1->p2, second = p2->p1)
-    nn = [a.elapsed_time(b) for name, a, b in kt.records if name == 'vpn_chamfer_nn']
-    nn_fwd = sum(nn[0::2]) / max(1, len(nn[0::2]))
-    nn_rev = sum(nn[1::2]) / max(1, len(nn[1::2]))
     phases = {k: round(v[1] * 1e3, 2) for k, v in ktimes.items()}      # microseconds
-    phases['vpn_chamfer_nn[p1->p2]'] = round(nn_fwd * 1e3, 2)
-    phases['vpn_chamfer_nn[p2->p1]'] = round(nn_rev * 1e3, 2)
-    phases.pop('vpn_chamfer_nn', None)
 
     # algorithmic bytes per launch (SURVEY.md 8d per-image figures x B; stated in DESIGN.md)
     N = K * n
     alg = {
-        'vpn_chamfer_nn[p1->p2]': B * (12 * (N + M) + 8 * N),
-        'vpn_chamfer_nn[p2->p1]': B * (12 * (N + M) + 8 * M),
+        'vpn_chamfer_fwd_ws': B * (12 * (N + M) + 8 * (N + M)),    # both directions: clouds in, minima + arg-minima out
         'vpn_raster_fwd': B * (40 * K + 8 * H * W),
         'vpn_raster_bwd': B * (8 * H * W + 40 * K + 40 * K),
+        'vpn_raster_loss_fwd': B * (40 * K + 8 * H * W),          # reads the two GT images instead of writing two
+        'vpn_raster_loss_bwd': B * (8 * H * W + 40 * K + 40 * K),
         'vpn_sample_fwd': B * (40 * K + 12 * N),
         'vpn_sample_bwd': B * (12 * N + 40 * K + 40 * K),
         'vpn_chamfer_bwd': B * (12 * (N + M) + 8 * (N + M) + 12 * N),
     }
     flops = {   # fp32 vector ops actually issued per launch (for the VALU view)
-        'vpn_chamfer_nn[p1->p2]': 12.0 * B * N * M,
-        'vpn_chamfer_nn[p2->p1]': 12.0 * B * N * M,
+
     }
     dom = max((k for k in phases if k in alg), key=lambda k: phases[k])
     dom_s = phases[dom] * 1e-6
@@ -172,6 +200,7 @@ def main():
             'metric': 'render+Chamfer fwd+bwd images/sec', 'value': round(value, 1), 'unit': 'images/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'launch': 'hip-graph replay' if use_graph else 'eager',
             'config': {'workload': 'C3: B=%d/GPU, K=%d sphere primitives, %dx%d silhouette+depth, n=%d pts/prim '
                                    '(N=%d) vs M=%d GT points, Chamfer+L1 fwd+bwd' % (B, K, H, W, n, N, M),
                        'global_batch': B * world, 'parallelism': 'dp%d' % world,
@@ -219,8 +248,9 @@ def cpu_baseline(params, gt_points, gt_sil, gt_depth, K, n, H, W, sigma, gamma, 
     pg = gpu_params[:S].detach().clone().requires_grad_(True)
     pts = vpn_amd.Sampling.sample_primitives(pg, kinds, n, seed=1234, sample_base=0)
     cd = vpn_amd.ChamferDistanceLoss()(pts, gpu_gt_points[:S])
-    a, d = vpn_amd.RasterFunction.apply(pg, kinds, cam[:S].contiguous(), H, W, sigma, gamma, z_far)
-    loss_g = cd + (a - gpu_gt_sil[:S]).abs().mean() + (d - gpu_gt_depth[:S]).abs().mean()
+    img = vpn_amd.RasterLossFunction.apply(pg, kinds, cam[:S].contiguous(), gpu_gt_sil[:S].contiguous(),
+                                           gpu_gt_depth[:S].contiguous(), H, W, sigma, gamma, z_far, False)
+    loss_g = cd + img[0] + img[1]
     loss_g.backward()
     gerr = float((pg.grad.cpu() - grad_c).abs().max() / grad_c.abs().max())
     lerr = abs(float(loss_g) - loss_c) / abs(loss_c)

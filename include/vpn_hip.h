@@ -94,6 +94,14 @@ int vpn_chamfer_fwd(const float* p1, const float* p2, int B, int N, int M,
  * queries [B,Nq,3], targets [B,Nt,3] -> dist [B,Nq], idx [B,Nq].  vpn_chamfer_fwd is two of these. */
 int vpn_chamfer_nn(const float* queries, const float* targets, int B, int Nq, int Nt,
                    float* dist, int32_t* idx, void* stream);
+/* Both directions with a caller-provided workspace of vpn_chamfer_workspace(B,N,M) bytes: each
+ * cloud is Morton-sorted once per call and both scans prune target chunks whose bounding box is
+ * farther than the current best (exact: same outputs as vpn_chamfer_fwd, bit for bit).
+ * mode: 0 automatic, 1 brute force (workspace unused, may be NULL), 2 pruned. */
+size_t vpn_chamfer_workspace(int B, int N, int M);
+int vpn_chamfer_fwd_ws(const float* p1, const float* p2, int B, int N, int M,
+                       float* dist1, int32_t* idx1, float* dist2, int32_t* idx2,
+                       void* workspace, int mode, void* stream);
 /* loss_b[b] = w1*mean_i dist1[b,i] + w2*mean_j dist2[b,j]   (chamfer_distance.py:25-28) */
 int vpn_chamfer_loss(const float* dist1, const float* dist2, int B, int N, int M,
                      float w1, float w2, float* loss_b, void* stream);
@@ -131,6 +139,27 @@ int vpn_raster_bwd(const float* params, const int32_t* kinds, const float* cam,
                    const float* aux, const void* records,
                    const float* grad_alpha, const float* grad_depth,
                    void* workspace, float* grad_params, void* stream);
+
+/* ------------------------------------------------ raster with fused image losses
+ * SilhouetteLoss.forward (modules/loss/silhouette.py:13-23: render, then L1Loss or MSELoss mean
+ * against the GT silhouette) in one pass, optionally with an L1 depth loss: the losses are
+ * evaluated where the pixel is produced, so alpha/depth and their gradients never travel through HBM.
+ *   gt_sil, gt_depth [B,H,W] (either may be NULL -> that loss is 0); sil_mse: 0 = L1, 1 = MSE;
+ *   losses [2] = (mean silhouette loss, mean |depth - gt_depth|);
+ *   loss_ws: vpn_raster_loss_workspace(B,H,W) bytes of scratch; aux/records as for vpn_raster_fwd.
+ */
+size_t vpn_raster_loss_workspace(int B, int H, int W);
+int vpn_raster_loss_fwd(const float* params, const int32_t* kinds, const float* cam,
+                        int B, int K, int H, int W, float sigma, float gamma, float z_far,
+                        const float* gt_sil, const float* gt_depth, int sil_mse,
+                        float* aux, void* records, void* loss_ws, float* losses, void* stream);
+/* grad_losses [2] (device): upstream gradients of the two scalar losses; workspace as for
+ * vpn_raster_bwd; grad_params [B,K,10] is written. */
+int vpn_raster_loss_bwd(const float* params, const int32_t* kinds, const float* cam,
+                        int B, int K, int H, int W, float sigma, float gamma, float z_far,
+                        const float* aux, const void* records,
+                        const float* gt_sil, const float* gt_depth, int sil_mse,
+                        const float* grad_losses, void* workspace, float* grad_params, void* stream);
 
 #ifdef __cplusplus
 }

@@ -43,6 +43,7 @@ def test_argument_validation_needs_no_gpu():
     assert L.vpn_raster_records_size(2, 3) == 2 * 3 * 7 * 16
     assert L.vpn_raster_bwd_workspace(2, 3, 32, 32) == 2 * 4 * 3 * 12 * 4
     assert L.vpn_raster_bwd_workspace(0, 3, 32, 32) == 0
+    assert L.vpn_raster_loss_workspace(2, 32, 32) == 2 * 4 * 2 * 4
     assert b'null pointer' in L.vpn_error_string(-1)
     with pytest.raises(RuntimeError):
         lib.check(-2)

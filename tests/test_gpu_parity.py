@@ -157,11 +157,12 @@ def _chamfer_exact(vpn, p1, p2, torch_sqrt_too=True):
     """Bit-exact against the reference expression evaluated with IEEE sqrt; against torch's own
     CPU sqrt (MKL VML, <= 1 ulp, see vpn_oracle.chamfer_nn_ieee) indices must still agree and
     distances agree to 1 ulp."""
-    d1, i1, d2, i2 = vpn.chamfer_nn(g(p1), g(p2))
     m1, j1, m2, j2 = O.chamfer_nn_ieee(p1, p2)
-    assert torch.equal(i1.cpu().long(), j1), 'argmin direction 1 differs'
-    assert torch.equal(i2.cpu().long(), j2), 'argmin direction 2 differs'
-    assert torch.equal(d1.cpu(), m1) and torch.equal(d2.cpu(), m2), 'distances not bit-exact'
+    for mode in ('brute', 'pruned'):          # both scan strategies must give the same bits
+        d1, i1, d2, i2 = vpn.chamfer_nn(g(p1), g(p2), mode=mode)
+        assert torch.equal(i1.cpu().long(), j1), 'argmin direction 1 differs (%s)' % mode
+        assert torch.equal(i2.cpu().long(), j2), 'argmin direction 2 differs (%s)' % mode
+        assert torch.equal(d1.cpu(), m1) and torch.equal(d2.cpu(), m2), 'distances not bit-exact (%s)' % mode
     if torch_sqrt_too:
         t1, k1, t2, k2 = O.chamfer_nn(p1, p2)
         assert torch.equal(i1.cpu().long(), k1) and torch.equal(i2.cpu().long(), k2)
@@ -171,7 +172,9 @@ def _chamfer_exact(vpn, p1, p2, torch_sqrt_too=True):
 @pytest.mark.parametrize('name', ['g4_chamfer_b4_n128_m96', 'g4_chamfer_b2_n257_m2048', 'g4_chamfer_ties'])
 def test_chamfer_golden(vpn, name):
     gd = load_golden(name)
-    d1, i1, d2, i2 = vpn.chamfer_nn(g(gd['p1']), g(gd['p2']))
+    for mode in ('brute', 'pruned'):
+        d1, i1, d2, i2 = vpn.chamfer_nn(g(gd['p1']), g(gd['p2']), mode=mode)
+        assert torch.equal(i1.cpu(), gd['idx1']) and torch.equal(i2.cpu(), gd['idx2'])
     assert torch.equal(i1.cpu(), gd['idx1']) and torch.equal(i2.cpu(), gd['idx2'])
     # reference distances come from torch's CPU sqrt (MKL VML, <= 1 ulp): equal to 1 ulp, and
     # bit-equal to the IEEE sqrt of the reference's exact d2
@@ -279,7 +282,10 @@ def test_chamfer_full_size_properties(vpn):
     B, N, M = 64, 8192, 2048
     p1 = g(torch.rand(B, N, 3, generator=gen) - 0.5)
     p2 = g(torch.rand(B, M, 3, generator=gen) - 0.5)
-    d1, i1, d2, i2 = vpn.chamfer_nn(p1, p2)
+    d1, i1, d2, i2 = vpn.chamfer_nn(p1, p2, mode='pruned')
+    e1, j1, e2, j2 = vpn.chamfer_nn(p1, p2, mode='brute')
+    assert torch.equal(d1, e1) and torch.equal(i1, j1) and torch.equal(d2, e2) and torch.equal(i2, j2), \
+        'pruned and brute-force scans disagree'
     # (1) the reported distance is the distance to the reported index (same fp32 expression)
     def dist_to(a, b, idx):
         diff = a - torch.gather(b, 1, idx.long()[..., None].expand(-1, -1, 3))
@@ -408,6 +414,48 @@ def test_silhouette_loss_and_renderer_surface(vpn):
     assert rgb.shape == (1, 128, 128, 3) and alpha.shape == (1, 128, 128, 1) and depth.shape == (1, 128, 128, 1)
     with pytest.raises(TypeError):
         vpn.VertexRenderer.render(object(), 1.0, 0.0, 0.0)
+
+
+def test_raster_fused_losses(vpn):
+    """vpn_raster_loss_{fwd,bwd}: render + L1/MSE silhouette loss + L1 depth loss in one pass equals the
+    image path followed by torch losses, and the oracle."""
+    gen = torch.Generator().manual_seed(21)
+    B, K, H, W = 3, 6, 40, 56
+    params = rand_params(gen, B, K)
+    kinds = [0, 1, 0, 0, 1, 0]
+    cam = torch.tensor([[1.1, 15.0, 200.0]]).expand(B, 3).contiguous()
+    gt_sil = (torch.rand(B, 1, H, W, generator=gen) > 0.5).float()
+    gt_dep = 2.0 - torch.rand(B, H, W, generator=gen)
+    gt_dep[:, :5] = 2.0                                   # exact ties depth == gt in the background: sign(0) = 0
+    wts = torch.tensor([0.7, 1.9])
+    kt = vpn.kinds_tensor(kinds, torch.device(DEV))
+    for mse in (False, True):
+        pc = params.clone().requires_grad_(True)
+        a, d = O.raster(pc, kinds, cam, H, W, 0.05, 0.1, 2.0)
+        ref = torch.stack([O.silhouette_loss(a, gt_sil, 'MSE' if mse else 'L1'), (d - gt_dep).abs().mean()])
+        (ref * wts).sum().backward()
+        pg = g(params).requires_grad_(True)
+        out = vpn.RasterLossFunction.apply(pg, kt, g(cam), g(gt_sil), g(gt_dep), H, W, 0.05, 0.1, 2.0, mse)
+        (out * g(wts)).sum().backward()
+        assert rel_err(out.detach().cpu(), ref.detach()) <= RTOL
+        assert rel_err(pg.grad.cpu(), pc.grad) <= RTOL
+        # image path + torch losses on the GPU gives the same numbers
+        pi = g(params).requires_grad_(True)
+        ai, di = vpn.RasterFunction.apply(pi, kt, g(cam), H, W, 0.05, 0.1, 2.0)
+        e = ai[:, None] - g(gt_sil)
+        li = torch.stack([(e * e).mean() if mse else e.abs().mean(), (di - g(gt_dep)).abs().mean()])
+        (li * g(wts)).sum().backward()
+        assert rel_err(out.detach().cpu(), li.detach().cpu()) <= 1e-5
+        assert rel_err(pg.grad.cpu(), pi.grad.cpu()) <= 1e-5
+    # one loss only
+    pg = g(params).requires_grad_(True)
+    out = vpn.RasterLossFunction.apply(pg, kt, g(cam), None, g(gt_dep), H, W, 0.05, 0.1, 2.0, False)
+    assert float(out[0]) == 0.0
+    out[1].backward()
+    pc = params.clone().requires_grad_(True)
+    _, d = O.raster(pc, kinds, cam, H, W, 0.05, 0.1, 2.0)
+    (d - gt_dep).abs().mean().backward()
+    assert rel_err(pg.grad.cpu(), pc.grad) <= RTOL
 
 
 def test_raster_full_size_properties(vpn):

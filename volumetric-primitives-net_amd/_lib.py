@@ -23,12 +23,17 @@ SIGNATURES = {
     'vpn_transform_bwd': (_i, [_c_f, _c_f, _c_f, _i, _i, _c_f, _c_f, _c_f, _c_f]),
     'vpn_chamfer_fwd': (_i, [_c_f, _c_f, _i, _i, _i, _c_f, _c_f, _c_f, _c_f, _c_f]),
     'vpn_chamfer_nn': (_i, [_c_f, _c_f, _i, _i, _i, _c_f, _c_f, _c_f]),
+    'vpn_chamfer_workspace': (_sz, [_i, _i, _i]),
+    'vpn_chamfer_fwd_ws': (_i, [_c_f, _c_f, _i, _i, _i, _c_f, _c_f, _c_f, _c_f, _c_f, _i, _c_f]),
     'vpn_chamfer_loss': (_i, [_c_f, _c_f, _i, _i, _i, _f, _f, _c_f, _c_f]),
     'vpn_chamfer_bwd': (_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i, _i, _i, _f, _f, _c_f, _c_f, _c_f]),
     'vpn_raster_records_size': (_sz, [_i, _i]),
     'vpn_raster_fwd': (_i, [_c_f, _c_f, _c_f, _i, _i, _i, _i, _f, _f, _f, _c_f, _c_f, _c_f, _c_f, _c_f]),
     'vpn_raster_bwd_workspace': (_sz, [_i, _i, _i, _i]),
     'vpn_raster_bwd': (_i, [_c_f, _c_f, _c_f, _i, _i, _i, _i, _f, _f, _f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f]),
+    'vpn_raster_loss_workspace': (_sz, [_i, _i, _i]),
+    'vpn_raster_loss_fwd': (_i, [_c_f, _c_f, _c_f, _i, _i, _i, _i, _f, _f, _f, _c_f, _c_f, _i, _c_f, _c_f, _c_f, _c_f, _c_f]),
+    'vpn_raster_loss_bwd': (_i, [_c_f, _c_f, _c_f, _i, _i, _i, _i, _f, _f, _f, _c_f, _c_f, _c_f, _c_f, _i, _c_f, _c_f, _c_f, _c_f]),
 }
 
 _lib = None

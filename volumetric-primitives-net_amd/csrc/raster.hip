@@ -351,10 +351,25 @@ __device__ inline unsigned long long tile_mask(const float4* lds, const float4* 
     return __ballot(vis);
 }
 
+// Fused image losses (MODE 1 of the raster kernels): SilhouetteLoss (L1 / MSE mean against the GT
+// silhouette, modules/loss/silhouette.py:11,22) and an L1 depth loss are evaluated where the pixel is
+// produced, so alpha / depth and their gradients never travel through HBM.
+struct LossArgs {
+    const float* gt_sil;      // [B,H,W] or null
+    const float* gt_depth;    // [B,H,W] or null
+    int sil_mse;              // 0: L1Loss, 1: MSELoss
+    float inv_count;          // 1 / (B*H*W): both losses are means
+    float* tile_loss;         // fwd out: [B*tiles][2] per-tile sums
+    const float* grad_loss;   // bwd in: [2] upstream gradients of the two scalar losses (device)
+};
+
+__device__ inline float sign0(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }   // torch.sign
+
+template <int MODE>   // 0: write alpha/depth images, 1: fused losses
 __global__ __launch_bounds__(64) void raster_fwd_kernel(const float4* __restrict__ rec, const float* __restrict__ cam,
                                                         int K, int H, int W, float sigma, float gamma, float z_far,
                                                         float* __restrict__ alpha, float* __restrict__ depth,
-                                                        float* __restrict__ aux) {
+                                                        float* __restrict__ aux, LossArgs la) {
     extern __shared__ __attribute__((aligned(16))) float4 lds[];   // [K*5]: ray coefficients + pixel box
     const int b = blockIdx.z;
     stage_records(rec + (size_t)b * K * R_REC, K, lds);
@@ -391,6 +406,7 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(const float4* __restrict
         }
     }
     const size_t hw = (size_t)H * W;
+    float lsil = 0.0f, ldep = 0.0f;
 #pragma unroll
     for (int s = 0; s < R_PPL; ++s) {
         const int row = rbase + 4 * s;
@@ -398,13 +414,51 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(const float4* __restrict
             const float A = 1.0f - P[s];
             const float S = S0[s] + R_DELTA_S0;
             const float zbar = S1[s] / S;
+            const float D = z_far + A * (zbar - z_far);
             const size_t pix = (size_t)row * W + col;
-            alpha[b * hw + pix] = A;
-            depth[b * hw + pix] = z_far + A * (zbar - z_far);
+            if (MODE == 0) {
+                alpha[b * hw + pix] = A;
+                depth[b * hw + pix] = D;
+            } else {
+                if (la.gt_sil) { const float e = A - la.gt_sil[b * hw + pix]; lsil += la.sil_mse ? e * e : fabsf(e); }
+                if (la.gt_depth) ldep += fabsf(D - la.gt_depth[b * hw + pix]);
+            }
             aux[(b * 3 + 0) * hw + pix] = P[s];
             aux[(b * 3 + 1) * hw + pix] = zbar;
             aux[(b * 3 + 2) * hw + pix] = S;
         }
+    }
+    if (MODE == 1) {
+        lsil = wave_sum(lsil);
+        ldep = wave_sum(ldep);
+        if (lane == 0) {
+            const int ntile = gridDim.x * gridDim.y, tile = blockIdx.y * gridDim.x + blockIdx.x;
+            la.tile_loss[((size_t)b * ntile + tile) * 2 + 0] = lsil;
+            la.tile_loss[((size_t)b * ntile + tile) * 2 + 1] = ldep;
+        }
+    }
+}
+
+// fixed-order sum of the per-tile loss partials -> the two mean losses (one workgroup of 1024 lanes,
+// float2 loads, 4 independent accumulators per lane so the loads pipeline)
+__global__ __launch_bounds__(1024) void raster_loss_reduce_kernel(const float2* __restrict__ tile_loss, int n,
+                                                                  float inv_count, float* __restrict__ losses) {
+    __shared__ float red[2][16];
+    float a[4] = {0.f, 0.f, 0.f, 0.f}, c[4] = {0.f, 0.f, 0.f, 0.f};
+    int i = threadIdx.x;
+    for (; i + 3 * 1024 < n; i += 4 * 1024) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const float2 v = tile_loss[i + u * 1024]; a[u] += v.x; c[u] += v.y; }
+    }
+    for (; i < n; i += 1024) { const float2 v = tile_loss[i]; a[0] += v.x; c[0] += v.y; }
+    float sa = wave_sum((a[0] + a[1]) + (a[2] + a[3])), sc = wave_sum((c[0] + c[1]) + (c[2] + c[3]));
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sa; red[1][threadIdx.x >> 6] = sc; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float ta = 0.f, tc = 0.f;
+        for (int w = 0; w < 16; ++w) { ta += red[0][w]; tc += red[1][w]; }
+        losses[0] = ta * inv_count;
+        losses[1] = tc * inv_count;
     }
 }
 
@@ -446,12 +500,13 @@ __device__ inline float wave_reduce16(float v[16]) {
     return r;
 }
 
+template <int MODE>   // 0: incoming gradient images, 1: gradients of the fused losses computed in place
 __global__ __launch_bounds__(64) void raster_bwd_kernel(const float4* __restrict__ rec, const float* __restrict__ cam,
                                                         int K, int H, int W, float sigma, float gamma, float z_far,
                                                         const float* __restrict__ aux,
                                                         const float* __restrict__ galpha,
                                                         const float* __restrict__ gdepth,
-                                                        float* __restrict__ partial) {
+                                                        float* __restrict__ partial, LossArgs la) {
     extern __shared__ __attribute__((aligned(16))) float4 lds[];   // [K*5]: ray coefficients + pixel box records | accum [K][12]
     float* accum = reinterpret_cast<float*>(lds + (size_t)K * R_LREC);
     const int b = blockIdx.z;
@@ -475,8 +530,21 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(const float4* __restrict
             P[s] = aux[(b * 3 + 0) * hw + pix];
             zbar[s] = aux[(b * 3 + 1) * hw + pix];
             invS[s] = 1.0f / aux[(b * 3 + 2) * hw + pix];
-            const float gA = galpha ? galpha[b * hw + pix] : 0.0f;
-            const float gD = gdepth ? gdepth[b * hw + pix] : 0.0f;
+            float gA = 0.0f, gD = 0.0f;
+            if (MODE == 0) {
+                gA = galpha ? galpha[b * hw + pix] : 0.0f;
+                gD = gdepth ? gdepth[b * hw + pix] : 0.0f;
+            } else {
+                const float A = 1.0f - P[s];
+                if (la.gt_sil) {
+                    const float e = A - la.gt_sil[b * hw + pix];
+                    gA = la.grad_loss[0] * la.inv_count * (la.sil_mse ? 2.0f * e : sign0(e));
+                }
+                if (la.gt_depth) {
+                    const float D = z_far + A * (zbar[s] - z_far);
+                    gD = la.grad_loss[1] * la.inv_count * sign0(D - la.gt_depth[b * hw + pix]);
+                }
+            }
             gAtot[s] = gA + gD * (zbar[s] - z_far);     // depth = z_far + A (zbar - z_far)
             gZbar[s] = gD * (1.0f - P[s]);
         }
@@ -585,12 +653,13 @@ static inline size_t bwd_lds(int K) { return (size_t)K * (R_LREC * sizeof(float4
 static int raise_lds_limit() {
     static int done = 0;
     if (done) return 0;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(raster_fwd_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds(VPN_MAX_PRIMS));
-    if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(raster_bwd_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds(VPN_MAX_PRIMS));
-    if (e != hipSuccess) return (int)e;
+    const void* fns[4] = {reinterpret_cast<const void*>(raster_fwd_kernel<0>), reinterpret_cast<const void*>(raster_fwd_kernel<1>),
+                          reinterpret_cast<const void*>(raster_bwd_kernel<0>), reinterpret_cast<const void*>(raster_bwd_kernel<1>)};
+    for (int i = 0; i < 4; ++i) {
+        hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)(i < 2 ? fwd_lds(VPN_MAX_PRIMS) : bwd_lds(VPN_MAX_PRIMS)));
+        if (e != hipSuccess) return (int)e;
+    }
     done = 1;
     return 0;
 }
@@ -625,8 +694,39 @@ extern "C" int vpn_raster_fwd(const float* params, const int32_t* kinds, const f
     VPN_LAUNCH_CHECK();
     size_t lds = fwd_lds(K);
     if (lds > 65536 && (rc = raise_lds_limit())) return rc;
-    hipLaunchKernelGGL(raster_fwd_kernel, raster_grid(B, H, W), dim3(64), lds, (hipStream_t)stream,
-                       (const float4*)records, cam, K, H, W, sigma, gamma, z_far, alpha, depth, aux);
+    hipLaunchKernelGGL(raster_fwd_kernel<0>, raster_grid(B, H, W), dim3(64), lds, (hipStream_t)stream,
+                       (const float4*)records, cam, K, H, W, sigma, gamma, z_far, alpha, depth, aux, LossArgs{});
+    VPN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t vpn_raster_loss_workspace(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    dim3 g = raster_grid(B, H, W);
+    return (size_t)B * g.x * g.y * 2 * sizeof(float);
+}
+
+extern "C" int vpn_raster_loss_fwd(const float* params, const int32_t* kinds, const float* cam, int B, int K, int H,
+                                   int W, float sigma, float gamma, float z_far, const float* gt_sil,
+                                   const float* gt_depth, int sil_mse, float* aux, void* records, void* loss_ws,
+                                   float* losses, void* stream) {
+    int rc = raster_check(params, kinds, cam, B, K, H, W, sigma, gamma);
+    if (rc) return rc;
+    if (!aux || !records || !loss_ws || !losses) return VPN_E_BADARG;
+    if (((uintptr_t)records & 15) != 0) return VPN_E_BADARG;
+    const int BK = B * K;
+    hipLaunchKernelGGL(raster_prep_kernel, dim3((BK + 255) / 256), dim3(256), 0, (hipStream_t)stream, params, kinds,
+                       cam, BK, K, H, W, sigma, (float4*)records);
+    VPN_LAUNCH_CHECK();
+    size_t lds = fwd_lds(K);
+    if (lds > 65536 && (rc = raise_lds_limit())) return rc;
+    dim3 g = raster_grid(B, H, W);
+    LossArgs la{gt_sil, gt_depth, sil_mse, 1.0f / ((float)B * (float)H * (float)W), (float*)loss_ws, nullptr};
+    hipLaunchKernelGGL(raster_fwd_kernel<1>, g, dim3(64), lds, (hipStream_t)stream, (const float4*)records, cam, K, H,
+                       W, sigma, gamma, z_far, (float*)nullptr, (float*)nullptr, aux, la);
+    VPN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(raster_loss_reduce_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float2*)loss_ws,
+                       (int)(B * g.x * g.y), la.inv_count, losses);
     VPN_LAUNCH_CHECK();
     return 0;
 }
@@ -648,8 +748,30 @@ extern "C" int vpn_raster_bwd(const float* params, const int32_t* kinds, const f
     dim3 g = raster_grid(B, H, W);
     size_t lds = bwd_lds(K);
     if (lds > 65536 && (rc = raise_lds_limit())) return rc;
-    hipLaunchKernelGGL(raster_bwd_kernel, g, dim3(64), lds, (hipStream_t)stream, (const float4*)records, cam, K, H, W,
-                       sigma, gamma, z_far, aux, grad_alpha, grad_depth, (float*)workspace);
+    hipLaunchKernelGGL(raster_bwd_kernel<0>, g, dim3(64), lds, (hipStream_t)stream, (const float4*)records, cam, K, H,
+                       W, sigma, gamma, z_far, aux, grad_alpha, grad_depth, (float*)workspace, LossArgs{});
+    VPN_LAUNCH_CHECK();
+    const int BK = B * K;
+    hipLaunchKernelGGL(raster_bwd_finish_kernel, dim3((BK + 3) / 4), dim3(256), 0, (hipStream_t)stream, params, cam,
+                       BK, K, (int)(g.x * g.y), (const float*)workspace, grad_params);
+    VPN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vpn_raster_loss_bwd(const float* params, const int32_t* kinds, const float* cam, int B, int K, int H,
+                                   int W, float sigma, float gamma, float z_far, const float* aux, const void* records,
+                                   const float* gt_sil, const float* gt_depth, int sil_mse, const float* grad_losses,
+                                   void* workspace, float* grad_params, void* stream) {
+    int rc = raster_check(params, kinds, cam, B, K, H, W, sigma, gamma);
+    if (rc) return rc;
+    if (!aux || !records || !grad_losses || !workspace || !grad_params) return VPN_E_BADARG;
+    if (((uintptr_t)records & 15) != 0 || ((uintptr_t)workspace & 15) != 0) return VPN_E_BADARG;
+    dim3 g = raster_grid(B, H, W);
+    size_t lds = bwd_lds(K);
+    if (lds > 65536 && (rc = raise_lds_limit())) return rc;
+    LossArgs la{gt_sil, gt_depth, sil_mse, 1.0f / ((float)B * (float)H * (float)W), nullptr, grad_losses};
+    hipLaunchKernelGGL(raster_bwd_kernel<1>, g, dim3(64), lds, (hipStream_t)stream, (const float4*)records, cam, K, H,
+                       W, sigma, gamma, z_far, aux, (const float*)nullptr, (const float*)nullptr, (float*)workspace, la);
     VPN_LAUNCH_CHECK();
     const int BK = B * K;
     hipLaunchKernelGGL(raster_bwd_finish_kernel, dim3((BK + 3) / 4), dim3(256), 0, (hipStream_t)stream, params, cam,

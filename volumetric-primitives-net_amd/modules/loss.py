@@ -4,7 +4,7 @@ import torch
 import torch.nn as nn
 
 from .. import config
-from ..ops import ChamferFunction
+from ..ops import ChamferFunction, RasterLossFunction
 from ..primitives import PrimitivePack
 from .render import VertexRenderer
 
@@ -50,6 +50,7 @@ class SilhouetteLoss(nn.Module):
     def __init__(self, loss_func=config.SILHOUETTE_LOSS_FUNC):
         super().__init__()
         self.loss_func = nn.L1Loss() if loss_func == 'L1' else nn.MSELoss()     # silhouette.py:11
+        self.is_mse = loss_func != 'L1'
 
     def forward(self, predict_meshes, gt_silhouettes: torch.Tensor,
                 dists: torch.Tensor, elevs: torch.Tensor, azims: torch.Tensor) -> torch.Tensor:
@@ -59,6 +60,11 @@ class SilhouetteLoss(nn.Module):
         if isinstance(predict_meshes, (list, tuple)):
             predict_meshes = PrimitivePack.stack(list(predict_meshes))
         H, W = gt_silhouettes.shape[-2:]
-        _, alpha, _ = VertexRenderer.render(predict_meshes, dists, elevs, azims, image_size=(H, W))
-        predict_silhouettes = alpha.permute(0, 3, 1, 2)                          # silhouette.py:18
-        return self.loss_func(predict_silhouettes, gt_silhouettes)
+        B = len(predict_meshes)
+        dev = predict_meshes.params.device
+        cam = torch.stack([dists.to(dev).float().reshape(-1).expand(B), elevs.to(dev).float().reshape(-1).expand(B),
+                           azims.to(dev).float().reshape(-1).expand(B)], 1)
+        # render + loss fused (silhouette.py:16-22 renders, concatenates and applies L1Loss/MSELoss)
+        losses = RasterLossFunction.apply(predict_meshes.params, predict_meshes.kinds, cam, gt_silhouettes, None, H, W,
+                                          VertexRenderer.sigma, VertexRenderer.gamma, VertexRenderer.z_far, self.is_mse)
+        return losses[0]

@@ -4,6 +4,8 @@ Pattern follows the reference's own native op, emdFunction (modules/loss/emd/
 emd_module.py:29-70): forward allocates the outputs, calls native code, saves what
 backward needs; backward returns one gradient per tensor input and None for the rest.
 Unlike it, a non-zero return code raises."""
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -110,8 +112,11 @@ class ChamferFunction(Function):
         i2 = torch.empty((B, M), dtype=torch.int32, device=dev)
         loss_b = torch.empty((B,), dtype=torch.float32, device=dev)
         s = _lib.stream()
-        _lib.call('vpn_chamfer_nn', _lib.ptr(p1), _lib.ptr(p2), B, N, M, _lib.ptr(d1), _lib.ptr(i1), s)
-        _lib.call('vpn_chamfer_nn', _lib.ptr(p2), _lib.ptr(p1), B, M, N, _lib.ptr(d2), _lib.ptr(i2), s)
+        ws = None
+        if os.environ.get('VPN_CHAMFER_MODE', '').startswith('p'):      # opt-in pruned scan needs its sort workspace
+            ws = torch.empty((_lib.lib().vpn_chamfer_workspace(B, N, M) // 4,), dtype=torch.float32, device=dev)
+        _lib.call('vpn_chamfer_fwd_ws', _lib.ptr(p1), _lib.ptr(p2), B, N, M, _lib.ptr(d1), _lib.ptr(i1), _lib.ptr(d2),
+                  _lib.ptr(i2), _lib.ptr(ws), 0, s)
         _lib.call('vpn_chamfer_loss', _lib.ptr(d1), _lib.ptr(d2), B, N, M, float(w1), float(w2), _lib.ptr(loss_b), s)
         ctx.save_for_backward(p1, p2, d1, i1, d2, i2)
         ctx.w = (float(w1), float(w2))
@@ -131,9 +136,13 @@ class ChamferFunction(Function):
         return g1, g2, None, None
 
 
-def chamfer_nn(p1, p2):
+CHAMFER_MODES = {'auto': 0, 'brute': 1, 'pruned': 2}
+
+
+def chamfer_nn(p1, p2, mode='auto'):
     """Nearest-neighbour distances and indices in both directions (no autograd):
-    (dist1 [B,N], idx1 [B,N] int32, dist2 [B,M], idx2 [B,M] int32)."""
+    (dist1 [B,N], idx1 [B,N] int32, dist2 [B,M], idx2 [B,M] int32).  mode: 'auto' | 'brute' | 'pruned'
+    (same results bit for bit; 'pruned' Morton-sorts the clouds and skips far target chunks)."""
     p1, p2 = _f32c(p1.detach()), _f32c(p2.detach())
     B, N, _ = p1.shape
     M = p2.shape[1]
@@ -142,8 +151,9 @@ def chamfer_nn(p1, p2):
     d2 = torch.empty((B, M), dtype=torch.float32, device=dev)
     i1 = torch.empty((B, N), dtype=torch.int32, device=dev)
     i2 = torch.empty((B, M), dtype=torch.int32, device=dev)
-    _lib.call('vpn_chamfer_fwd', _lib.ptr(p1), _lib.ptr(p2), B, N, M, _lib.ptr(d1), _lib.ptr(i1),
-                                         _lib.ptr(d2), _lib.ptr(i2), _lib.stream())
+    ws = torch.empty((_lib.lib().vpn_chamfer_workspace(B, N, M) // 4,), dtype=torch.float32, device=dev)
+    _lib.call('vpn_chamfer_fwd_ws', _lib.ptr(p1), _lib.ptr(p2), B, N, M, _lib.ptr(d1), _lib.ptr(i1), _lib.ptr(d2),
+              _lib.ptr(i2), _lib.ptr(ws), CHAMFER_MODES[mode], _lib.stream())
     return d1, i1, d2, i2
 
 
@@ -180,3 +190,48 @@ class RasterFunction(Function):
                   z_far, _lib.ptr(aux), _lib.ptr(rec), _lib.ptr(ga), _lib.ptr(gd), _lib.ptr(ws),
                   _lib.ptr(grad_params), _lib.stream())
         return grad_params, None, None, None, None, None, None, None
+
+
+class RasterLossFunction(Function):
+    """SilhouetteLoss.forward (silhouette.py:13-23) fused into the raster: render + L1/MSE mean against
+    the GT silhouette (+ optional L1 depth loss) without materialising the images.
+    Returns a [2] tensor: (silhouette loss, depth loss)."""
+
+    @staticmethod
+    def forward(ctx, params, kinds, cam, gt_sil, gt_depth, H, W, sigma, gamma, z_far, sil_mse):
+        params, cam = _f32c(params), _f32c(cam)
+        B, K, S = params.shape
+        assert S == PARAM_STRIDE and kinds.numel() == K and cam.shape == (B, 3)
+        if gt_sil is not None:
+            gt_sil = _f32c(gt_sil).reshape(B, H, W)
+        if gt_depth is not None:
+            gt_depth = _f32c(gt_depth).reshape(B, H, W)
+        dev = params.device
+        L = _lib.lib()
+        aux = torch.empty((B, 3, H, W), dtype=torch.float32, device=dev)
+        rec = torch.empty((L.vpn_raster_records_size(B, K) // 4,), dtype=torch.float32, device=dev)
+        lws = torch.empty((L.vpn_raster_loss_workspace(B, H, W) // 4,), dtype=torch.float32, device=dev)
+        losses = torch.empty((2,), dtype=torch.float32, device=dev)
+        _lib.call('vpn_raster_loss_fwd', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(cam), B, K, H, W, float(sigma),
+                  float(gamma), float(z_far), _lib.ptr(gt_sil), _lib.ptr(gt_depth), int(bool(sil_mse)), _lib.ptr(aux),
+                  _lib.ptr(rec), _lib.ptr(lws), _lib.ptr(losses), _lib.stream())
+        empty = torch.empty(0, device=dev)
+        ctx.save_for_backward(params, kinds, cam, aux, rec, gt_sil if gt_sil is not None else empty,
+                              gt_depth if gt_depth is not None else empty)
+        ctx.meta = (B, K, H, W, float(sigma), float(gamma), float(z_far), int(bool(sil_mse)),
+                    gt_sil is not None, gt_depth is not None)
+        return losses
+
+    @staticmethod
+    def backward(ctx, grad_losses):
+        params, kinds, cam, aux, rec, gt_sil, gt_depth = ctx.saved_tensors
+        B, K, H, W, sigma, gamma, z_far, sil_mse, has_sil, has_depth = ctx.meta
+        g = _f32c(grad_losses)
+        ws = torch.empty((_lib.lib().vpn_raster_bwd_workspace(B, K, H, W) // 4,), dtype=torch.float32,
+                         device=params.device)
+        grad_params = torch.empty_like(params)
+        _lib.call('vpn_raster_loss_bwd', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(cam), B, K, H, W, sigma, gamma,
+                  z_far, _lib.ptr(aux), _lib.ptr(rec), _lib.ptr(gt_sil) if has_sil else None,
+                  _lib.ptr(gt_depth) if has_depth else None, sil_mse, _lib.ptr(g), _lib.ptr(ws),
+                  _lib.ptr(grad_params), _lib.stream())
+        return (grad_params,) + (None,) * 10
