@@ -97,7 +97,7 @@ def main():
         cd = cd_fn(pts, gt_points)
         # SilhouetteLoss (L1, silhouette.py:11) + L1 depth loss, fused into the raster pass
         img = vpn_amd.RasterLossFunction.apply(params, kinds, cam, gt_sil, gt_depth, H, W, sigma, gamma, z_far, False)
-        loss = cd + img[0] + img[1]
+        loss = cd + img.sum()
         loss.backward()
         if reducer is not None:
             return reducer.reduce(params.grad, loss)
@@ -118,7 +118,7 @@ def main():
             pts = vpn_amd.Sampling.sample_primitives(params, kinds, n, seed=1234 + i, sample_base=rank * B)
             cd = cd_fn(pts, gt_points)
             img = vpn_amd.RasterLossFunction.apply(params, kinds, cam, gt_sil, gt_depth, H, W, sigma, gamma, z_far, False)
-            loss = cd + img[0] + img[1]
+            loss = cd + img.sum()
             loss.backward()
             return loss
         side = torch.cuda.Stream()

@@ -396,7 +396,9 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(const float4* __restrict
             const int imin = __float_as_int(bb.z), imax = __float_as_int(bb.w);
 #pragma unroll
             for (int s = 0; s < R_PPL; ++s) {
+#ifdef VPN_RASTER_ROWSKIP
                 if (imin > r0 + 4 * s + 3 || imax < r0 + 4 * s) continue;   // wave-uniform: row group not touched
+#endif
                 PixPrim q;
                 eval_prim(q0, q1, q2, q3, px, py[s], inv_sigma, inv_gamma, zref, q);
                 P[s] *= q.c;
@@ -563,7 +565,9 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(const float4* __restrict
             for (int i = 0; i < 16; ++i) v[i] = 0.0f;
 #pragma unroll
             for (int s = 0; s < R_PPL; ++s) {
+#ifdef VPN_RASTER_ROWSKIP
                 if (imin > r0 + 4 * s + 3 || imax < r0 + 4 * s) continue;
+#endif
                 PixPrim q;
                 eval_prim(q0, q1, q2, q3, px, py[s], inv_sigma, inv_gamma, zref, q);
                 // composite backward
