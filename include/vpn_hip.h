@@ -95,9 +95,13 @@ int vpn_chamfer_fwd(const float* p1, const float* p2, int B, int N, int M,
 int vpn_chamfer_nn(const float* queries, const float* targets, int B, int Nq, int Nt,
                    float* dist, int32_t* idx, void* stream);
 /* Both directions with a caller-provided workspace of vpn_chamfer_workspace(B,N,M) bytes: each
- * cloud is Morton-sorted once per call and both scans prune target chunks whose bounding box is
- * farther than the current best (exact: same outputs as vpn_chamfer_fwd, bit for bit).
- * mode: 0 automatic, 1 brute force (workspace unused, may be NULL), 2 pruned. */
+ * scan strategy is selectable and every strategy returns the same bits as vpn_chamfer_fwd:
+ *   mode 1  brute force (workspace unused, may be NULL);
+ *   mode 2  box-pruned: clouds Morton-sorted per call, target chunks farther than the current best skipped;
+ *   mode 3  MFMA-filtered: the fp32 matrix pipe evaluates |b|^2 - 2a.b for 32x32 pairs, the candidates are
+ *           re-evaluated with the exact separately-rounded d2 (a rigorous error band decides when a full
+ *           exact rescan of a query is needed);
+ *   mode 0  automatic (mode 3 for large clouds when a workspace is given, else mode 1). */
 size_t vpn_chamfer_workspace(int B, int N, int M);
 int vpn_chamfer_fwd_ws(const float* p1, const float* p2, int B, int N, int M,
                        float* dist1, int32_t* idx1, float* dist2, int32_t* idx2,

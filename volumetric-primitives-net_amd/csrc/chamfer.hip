@@ -614,6 +614,387 @@ __global__ __launch_bounds__(64) void chamfer_nn_pruned_kernel(
     }
 }
 
+// =====================================================================================
+// MFMA-filtered exact nearest neighbour.
+//
+// The brute-force scan is bound by fp32 VALU issue (8 separately rounded flops per pair are needed for
+// bit-exact d2).  Here the matrix pipe does the bulk: with A = (bx, by, bz, |b|^2) per target and
+// B = (-2ax, -2ay, -2az, 1) per query, two v_mfma_f32_32x32x2_f32 give t_ij = |b_i|^2 - 2 a_j.b_i for
+// 32 targets x 32 queries (= d2 - |a_j|^2 up to a rigorous rounding bound E), on a pipe that runs
+// beside the VALU, which only keeps a v_min3 tree per 32x32 block: (smallest t, its block, second
+// smallest block minimum).  The exact contract is restored in the epilogue:
+//   * the 32 targets of the winning block are re-evaluated with the exact separately-rounded d2 and the
+//     sqrt tie rule;
+//   * if any other block comes within band = 2E + 4e-6 d2 of the winner, the filter cannot decide and
+//     the wave re-scans all targets exactly for that query (same cooperative scan as the tie path).
+// Outputs are bit-identical to chamfer_nn_kernel.
+// =====================================================================================
+typedef float f16v __attribute__((ext_vector_type(16)));
+constexpr int CM_BLOCK = 256;            // 4 waves x 32 queries
+constexpr int CM_TILE = 512;             // targets per LDS feature tile (8 KB per buffer)
+constexpr float CM_EPS = 8.0f * 5.9604644775390625e-08f;   // 8 * 2^-24: bound on the relative rounding of t_ij
+
+// feature planes F[b][4][Np] = (x, y, z, |p|^2) (padded with a never-winning sentinel), nmax[b] = max |p|^2.
+// One workgroup per sample (no atomics, no memset): lanes stride over the points.
+__global__ __launch_bounds__(1024) void chamfer_feat_kernel(const float* __restrict__ pts, int N, int Np,
+                                                            float* __restrict__ F, unsigned int* __restrict__ nmax) {
+    __shared__ float red[16];
+    const int b = blockIdx.x;
+    const float* pb = pts + (size_t)b * N * 3;
+    float* f = F + (size_t)b * 4 * Np;
+    float nv = 0.f;
+    for (int j = threadIdx.x; j < Np; j += 1024) {
+        float x = 0.f, y = 0.f, z = 0.f, n = 3.0e38f;
+        if (j < N) {
+            x = pb[j * 3]; y = pb[j * 3 + 1]; z = pb[j * 3 + 2];
+            n = x * x + y * y + z * z;
+            nv = fmaxf(nv, n);
+        }
+        f[j] = x; f[Np + j] = y; f[2 * Np + j] = z; f[3 * Np + j] = n;
+    }
+    nv = wave_max_u(nv);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = nv;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = red[0];
+        for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w]);
+        nmax[b] = __float_as_uint(m);
+    }
+}
+
+// whole wave, one query: exact (min sqrt distance, lowest index attaining it) over all Nt targets.
+// 256 targets per step (4 coalesced loads in flight per lane); second pass applies the sqrt tie rule.
+__device__ inline void exact_scan_query(float qx, float qy, float qz, const float* __restrict__ tb, int Nt,
+                                        float& dist, int& idx) {
+    const int lane = threadIdx.x & 63;
+    float m = __builtin_inff();
+    for (int base = 0; base < Nt; base += 256) {
+        float x[4], y[4], z[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = min(base + u * 64 + lane, Nt - 1);
+            x[u] = tb[j * 3]; y[u] = tb[j * 3 + 1]; z[u] = tb[j * 3 + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) m = fminf(m, dist2_exact(qx, qy, qz, x[u], y[u], z[u]));
+    }
+    const float s = sqrtf(wave_min_u(m));
+    int loc = 0x7fffffff;
+    for (int base = 0; base < Nt; base += 256) {
+        float x[4], y[4], z[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = min(base + u * 64 + lane, Nt - 1);
+            x[u] = tb[j * 3]; y[u] = tb[j * 3 + 1]; z[u] = tb[j * 3 + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = base + u * 64 + lane;
+            if (j < Nt && sqrtf(dist2_exact(qx, qy, qz, x[u], y[u], z[u])) == s) loc = min(loc, j);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) loc = min(loc, __shfl_xor(loc, o, 64));
+    dist = s; idx = loc;
+}
+
+// Queries the filter could not decide (idx == -1: three or more 32-target blocks within the error band,
+// a handful per launch) are resolved exactly here.  One workgroup per 256 queries; workgroups without a
+// marked query leave at once, the others scan all targets with all 256 lanes per marked query.
+constexpr int CF_THREADS = 256;
+
+__global__ __launch_bounds__(CF_THREADS) void chamfer_fixup_kernel(const float* __restrict__ qpts,
+                                                                   const float* __restrict__ tpts, int Nq, int Nt,
+                                                                   float* __restrict__ out_dist,
+                                                                   int32_t* __restrict__ out_idx) {
+    __shared__ int marked[CF_THREADS];
+    __shared__ int nmarked;
+    __shared__ float redf[4];
+    __shared__ int redi[4];
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* qb = qpts + (size_t)b * Nq * 3;
+    const float* tb = tpts + (size_t)b * Nt * 3;
+    int32_t* oi = out_idx + (size_t)b * Nq;
+    float* od = out_dist + (size_t)b * Nq;
+    if (threadIdx.x == 0) nmarked = 0;
+    __syncthreads();
+    const int qi = blockIdx.x * CF_THREADS + threadIdx.x;
+    if (qi < Nq && oi[qi] < 0) marked[atomicAdd(&nmarked, 1)] = qi;
+    __syncthreads();
+    const int nm = nmarked;
+    for (int k = 0; k < nm; ++k) {
+        const int q = marked[k];
+        const float qx = qb[q * 3], qy = qb[q * 3 + 1], qz = qb[q * 3 + 2];
+        float m = __builtin_inff();
+        for (int base = 0; base < Nt; base += 4 * CF_THREADS) {
+            float x[4], y[4], z[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = min(base + u * CF_THREADS + (int)threadIdx.x, Nt - 1);
+                x[u] = tb[j * 3]; y[u] = tb[j * 3 + 1]; z[u] = tb[j * 3 + 2];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) m = fminf(m, dist2_exact(qx, qy, qz, x[u], y[u], z[u]));
+        }
+        m = wave_min_u(m);
+        if (lane == 0) redf[wave] = m;
+        __syncthreads();
+        m = fminf(fminf(redf[0], redf[1]), fminf(redf[2], redf[3]));
+        const float s = sqrtf(m), lim = m * (1.0f + 1.0e-6f);
+        int loc = 0x7fffffff;
+        for (int base = 0; base < Nt; base += 4 * CF_THREADS) {
+            float x[4], y[4], z[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = min(base + u * CF_THREADS + (int)threadIdx.x, Nt - 1);
+                x[u] = tb[j * 3]; y[u] = tb[j * 3 + 1]; z[u] = tb[j * 3 + 2];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = base + u * CF_THREADS + (int)threadIdx.x;
+                const float d2 = dist2_exact(qx, qy, qz, x[u], y[u], z[u]);
+                if (j < Nt && d2 <= lim && sqrtf(d2) == s) loc = min(loc, j);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) loc = min(loc, __shfl_xor(loc, o, 64));
+        if (lane == 0) redi[wave] = loc;
+        __syncthreads();
+        if (threadIdx.x == 0) { od[q] = s; oi[q] = min(min(redi[0], redi[1]), min(redi[2], redi[3])); }
+        __syncthreads();
+    }
+}
+
+__device__ inline float min16(const f16v& v) {
+    float m = __builtin_fminf(__builtin_fminf(v[0], v[1]), v[2]);
+    m = __builtin_fminf(__builtin_fminf(m, v[3]), v[4]);
+    m = __builtin_fminf(__builtin_fminf(m, v[5]), v[6]);
+    m = __builtin_fminf(__builtin_fminf(m, v[7]), v[8]);
+    m = __builtin_fminf(__builtin_fminf(m, v[9]), v[10]);
+    m = __builtin_fminf(__builtin_fminf(m, v[11]), v[12]);
+    m = __builtin_fminf(__builtin_fminf(m, v[13]), v[14]);
+    return __builtin_fminf(m, v[15]);
+}
+
+__global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_kernel(const float* __restrict__ qpts,
+                                                                   const float* __restrict__ tpts,
+                                                                   const float* __restrict__ F,
+                                                                   const unsigned int* __restrict__ nmax, int Nq,
+                                                                   int Nt, int Ntp, float* __restrict__ out_dist,
+                                                                   int32_t* __restrict__ out_idx) {
+    const int b = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, jq = lane & 31, half = lane >> 5;
+    const float* qb = qpts + (size_t)b * Nq * 3;
+    const float* tb = tpts + (size_t)b * Nt * 3;
+    const int qi = (blockIdx.x * 4 + wave) * 32 + jq;
+    const int qc = min(qi, Nq - 1);
+    const float ax = qb[qc * 3], ay = qb[qc * 3 + 1], az = qb[qc * 3 + 2];
+    // B operand (K x N): lane supplies B[k = lane/32][n = lane%32]
+    const float bq0 = half ? -2.0f * ay : -2.0f * ax;
+    const float bq1 = half ? 1.0f : -2.0f * az;
+    // A operand (M x K): lane supplies A[i = lane%32][k = lane/32] from the feature planes (through LDS)
+
+    // smallest / second / third smallest block minimum of this lane's half, with the blocks of the first two
+    float best = __builtin_inff(), second = __builtin_inff(), third = __builtin_inff();
+    int blk = 0, blk2 = 0;
+    // The 4 waves of the workgroup scan the same targets: feature tiles of CM_TILE targets go through LDS
+    // (double buffered: the next tile's loads are in flight while this one feeds the matrix pipe).
+    __shared__ __attribute__((aligned(16))) float tileF[2][4][CM_TILE];
+    const float* Fb = F + (size_t)b * 4 * Ntp;
+    // each lane moves 2 float4 per tile (4 planes x CM_TILE floats = 512 float4, 256 lanes)
+    auto fetch = [&](int t0, float4 v[2]) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = threadIdx.x + u * CM_BLOCK;
+            const int plane = i / (CM_TILE / 4), off = (i - plane * (CM_TILE / 4)) * 4;
+            v[u] = make_float4(0.f, 0.f, 0.f, 3.0e38f);
+            if (t0 + off < Ntp) v[u] = *reinterpret_cast<const float4*>(Fb + (size_t)plane * Ntp + t0 + off);
+        }
+    };
+    auto stash = [&](int buf, const float4 v[2]) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = threadIdx.x + u * CM_BLOCK;
+            const int plane = i / (CM_TILE / 4), off = (i - plane * (CM_TILE / 4)) * 4;
+            *reinterpret_cast<float4*>(&tileF[buf][plane][off]) = v[u];
+        }
+    };
+    float4 pre[2];
+    fetch(0, pre);
+    stash(0, pre);
+    __syncthreads();
+    int buf = 0;
+    for (int t0 = 0; t0 < Ntp; t0 += CM_TILE, buf ^= 1) {
+        const bool more = t0 + CM_TILE < Ntp;
+        if (more) fetch(t0 + CM_TILE, pre);         // in flight during the MFMA loop, stored to LDS after it
+        const int nblk = min(CM_TILE, Ntp - t0) >> 5;
+        const float* T0 = &tileF[buf][half][jq];
+        const float* T1 = &tileF[buf][2 + half][jq];
+// branch-free selects (the compiler otherwise turns the index updates into exec-mask branches)
+#define CM_SEL(dst, cond_mask, a, b) asm volatile("v_cndmask_b32 %0, %1, %2, %3" : "=v"(dst) : "v"(b), "v"(a), "s"(cond_mask))
+#define CM_UPDATE(m, tb0)                                                                  \
+    {                                                                                          \
+        const int t_ = (tb0);                                                                  \
+        unsigned long long k1_, k2_;                                                           \
+        asm volatile("v_cmp_lt_f32 %0, %1, %2" : "=s"(k1_) : "v"(m), "v"(best));               \
+        asm volatile("v_cmp_lt_f32 %0, %1, %2" : "=s"(k2_) : "v"(m), "v"(second));             \
+        third = __builtin_amdgcn_fmed3f(second, third, (m));                                   \
+        second = __builtin_amdgcn_fmed3f(best, second, (m));                                   \
+        int sel_;                                                                              \
+        CM_SEL(sel_, k2_, t_, blk2);      /* c2 ? t : blk2 */                                  \
+        CM_SEL(blk2, k1_, blk, sel_);     /* c1 ? blk : sel */                                 \
+        CM_SEL(blk, k1_, t_, blk);        /* c1 ? t : blk */                                   \
+        best = __builtin_fminf(best, (m));                                                     \
+    }
+        const f16v zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        // operands of the next pair of blocks are read from LDS while the current MFMAs run
+        float o0 = T0[0], o1 = T1[0], o2 = T0[32], o3 = T1[32];
+        for (int u = 0; u < nblk; u += 2) {         // nblk is even (tiles are multiples of 64 targets)
+            const float c0 = o0, c1 = o1, c2 = o2, c3 = o3;
+            if (u + 2 < nblk) { o0 = T0[u * 32 + 64]; o1 = T1[u * 32 + 64]; o2 = T0[u * 32 + 96]; o3 = T1[u * 32 + 96]; }
+#if defined(VPN_ABL_NO_MFMA)
+            f16v accA = zero, accB = zero;
+            accA[0] = c0 * bq0 + c1 * bq1; accB[3] = c2 * bq0 + c3 * bq1;
+            asm volatile("" : "+v"(accA), "+v"(accB));
+#else
+            f16v accA = __builtin_amdgcn_mfma_f32_32x32x2f32(c0, bq0, zero, 0, 0, 0);   // two independent accumulators:
+            f16v accB = __builtin_amdgcn_mfma_f32_32x32x2f32(c2, bq0, zero, 0, 0, 0);   // the min-tree of one block
+            accA = __builtin_amdgcn_mfma_f32_32x32x2f32(c1, bq1, accA, 0, 0, 0);         // overlaps the MFMAs of the other
+            accB = __builtin_amdgcn_mfma_f32_32x32x2f32(c3, bq1, accB, 0, 0, 0);
+#endif
+#if defined(VPN_ABL_NO_VALU)
+            asm volatile("" :: "v"(accA), "v"(accB));
+            const float mA = accA[0], mB = accB[0];
+            best = fminf(best, fminf(mA, mB)); blk = t0 + u * 32;
+#else
+            const float mA = min16(accA);           // this lane: query jq, 16 of the block's 32 targets
+            CM_UPDATE(mA, t0 + u * 32)
+            const float mB = min16(accB);
+            CM_UPDATE(mB, t0 + u * 32 + 32)
+#endif
+        }
+        if (more) stash(buf ^ 1, pre);
+        __syncthreads();                            // everybody done with `buf`, next tile landed
+    }
+    // merge the two half-waves that share a query (they saw disjoint halves of every block): the two best
+    // DISTINCT blocks K, K2 and a lower bound T for the minimum of every other block
+    int K, K2;
+    float Bv, V2, T;
+    {
+        const float ob = __shfl_xor(best, 32, 64), os = __shfl_xor(second, 32, 64), ot = __shfl_xor(third, 32, 64);
+        const int ok = __shfl_xor(blk, 32, 64), ok2 = __shfl_xor(blk2, 32, 64);
+        const float cv[4] = {best, second, ob, os};
+        const int ck[4] = {blk, blk2, ok, ok2};
+        Bv = fminf(best, ob);
+        K = (ob < best || (ob == best && ok < blk)) ? ok : blk;
+        V2 = __builtin_inff(); K2 = K;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (ck[c] != K && (cv[c] < V2 || (cv[c] == V2 && ck[c] < K2))) { V2 = cv[c]; K2 = ck[c]; }
+        T = fminf(third, ot);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (ck[c] != K && ck[c] != K2) T = fminf(T, cv[c]);
+    }
+    // exact finish: the 32 targets of block K (16 per lane of the pair), and of K2 when it is within the band
+    // this lane's 16 targets are contiguous in the (padded) feature planes: 4 float4 per coordinate
+    auto exact16 = [&](int base, float out[16]) -> float {
+        float mloc = __builtin_inff();
+        const float4* px4 = reinterpret_cast<const float4*>(Fb + base);
+        const float4* py4 = reinterpret_cast<const float4*>(Fb + (size_t)Ntp + base);
+        const float4* pz4 = reinterpret_cast<const float4*>(Fb + 2 * (size_t)Ntp + base);
+        float4 X[4], Y[4], Z[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { X[v] = px4[v]; Y[v] = py4[v]; Z[v] = pz4[v]; }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const float xs[4] = {X[v].x, X[v].y, X[v].z, X[v].w}, ys[4] = {Y[v].x, Y[v].y, Y[v].z, Y[v].w};
+            const float zs[4] = {Z[v].x, Z[v].y, Z[v].z, Z[v].w};
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const int e = v * 4 + w;
+                out[e] = (base + e < Nt) ? dist2_exact(ax, ay, az, xs[w], ys[w], zs[w]) : __builtin_inff();
+                mloc = fminf(mloc, out[e]);
+            }
+        }
+        return mloc;
+    };
+    float d2[16];
+    float m2 = exact16(K + half * 16, d2);
+    m2 = fminf(m2, __shfl_xor(m2, 32, 64));
+    // t = d2 - |a|^2 within E; exact d2 within 4e-7 relative: outside `band` nothing can win or tie
+    const float na = ax * ax + ay * ay + az * az, nb = __uint_as_float(nmax[b]);
+    const float E = CM_EPS * (2.0f * sqrtf(na * nb) + nb + na);
+    const float band = 2.0f * E + 4.0e-6f * m2;
+    const bool need2 = !(V2 > Bv + band);
+    const bool ambiguous = !(T > Bv + band);
+    float e2[16];
+    const bool any2 = __ballot(need2) != 0ull;       // wave-level: about 6 % of the waves
+    if (any2) {
+        const float mk2 = exact16(K2 + half * 16, e2);
+        if (need2) m2 = fminf(m2, mk2);
+        else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) e2[e] = __builtin_inff();
+        }
+        m2 = fminf(m2, __shfl_xor(m2, 32, 64));
+    }
+    float s = sqrtf(m2);
+    // lowest index attaining the minimum; a different d2 can only share the sqrt if it lies within a few ulp
+    // of it, which is rare: only then are the sqrt values compared
+    const float lim = m2 * (1.0f + 1.0e-6f);
+    int idx = 0x7fffffff;
+    bool near_tie = false;
+#pragma unroll
+    for (int e = 15; e >= 0; --e) {
+        if (d2[e] == m2) idx = K + half * 16 + e;
+        near_tie |= (d2[e] != m2) && (d2[e] <= lim);
+    }
+    if (any2) {
+#pragma unroll
+        for (int e = 15; e >= 0; --e) {
+            if (e2[e] == m2) idx = min(idx, K2 + half * 16 + e);
+            near_tie |= (e2[e] != m2) && (e2[e] <= lim);
+        }
+    }
+    if (__ballot(near_tie)) {
+#pragma unroll
+        for (int e = 15; e >= 0; --e) {
+            if (d2[e] <= lim && sqrtf(d2[e]) == s) idx = min(idx, K + half * 16 + e);
+            if (any2 && e2[e] <= lim && sqrtf(e2[e]) == s) idx = min(idx, K2 + half * 16 + e);
+        }
+    }
+    idx = min(idx, __shfl_xor(idx, 32, 64));
+    if (half == 0 && qi < Nq) {
+        out_dist[(size_t)b * Nq + qi] = s;
+        out_idx[(size_t)b * Nq + qi] = ambiguous ? -1 : idx;      // -1: resolved by chamfer_fixup_kernel
+#ifdef VPN_CHAMFER_DEBUG
+        if (ambiguous) atomicAdd(&g_dbg[6], 1ull);
+#endif
+    }
+}
+
+static inline int pad32(int n) { return (n + 63) & ~63; }   // feature planes padded to 64 targets (blocks are processed in pairs)
+static inline size_t mfma_ws_floats(int B, int N) { return (size_t)B * 4 * pad32(N) + (size_t)B; }
+
+// one direction: features of the targets -> filtered scan of the queries
+static int mfma_nn(const float* q, const float* t, int B, int Nq, int Nt, float* F, float* d, int32_t* idx,
+                   hipStream_t s) {
+    const int Ntp = pad32(Nt);
+    unsigned int* nmax = reinterpret_cast<unsigned int*>(F + (size_t)B * 4 * Ntp);
+    hipLaunchKernelGGL(chamfer_feat_kernel, dim3(B), dim3(1024), 0, s, t, Nt, Ntp, F, nmax);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(chamfer_nn_mfma_kernel, dim3((Nq + 127) / 128, B), dim3(CM_BLOCK), 0, s, q, t, F, nmax, Nq, Nt,
+                       Ntp, d, idx);
+    e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(chamfer_fixup_kernel, dim3((Nq + CF_THREADS - 1) / CF_THREADS, B), dim3(CF_THREADS), 0, s, q, t,
+                       Nq, Nt, d, idx);
+    e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
 struct CloudWs { float* sorted; int32_t* perm; float* boxes; int C; };
 
 static inline int chunks_of(int N) { return (N + CP_CHUNK - 1) / CP_CHUNK; }
@@ -636,12 +1017,12 @@ static int pruned_nn(const CloudWs& q, const CloudWs& t, int B, int Nq, int Nt, 
     return e == hipSuccess ? 0 : (int)e;
 }
 
-// 0: automatic, 1: brute force, 2: pruned   (VPN_CHAMFER_MODE=brute|pruned, tuning / tests)
+// 0: automatic, 1: brute force, 2: pruned, 3: mfma-filtered   (VPN_CHAMFER_MODE=brute|pruned|mfma, tuning / tests)
 static int chamfer_mode() {
     static int mode = -1;
     if (mode < 0) {
         const char* e = getenv("VPN_CHAMFER_MODE");
-        mode = !e ? 0 : (e[0] == 'b' ? 1 : (e[0] == 'p' ? 2 : 0));
+        mode = !e ? 0 : (e[0] == 'b' ? 1 : (e[0] == 'p' ? 2 : (e[0] == 'm' ? 3 : 0)));
     }
     return mode;
 }
@@ -717,24 +1098,34 @@ extern "C" int vpn_chamfer_bwd(const float* p1, const float* p2, const float* di
 
 extern "C" size_t vpn_chamfer_workspace(int B, int N, int M) {
     if (B <= 0 || N <= 0 || M <= 0) return 0;
-    return (cloud_ws_floats(B, N) + cloud_ws_floats(B, M)) * sizeof(float);
+    const size_t pruned = cloud_ws_floats(B, N) + cloud_ws_floats(B, M);
+    const size_t mfma = mfma_ws_floats(B, N) + mfma_ws_floats(B, M);
+    return (pruned > mfma ? pruned : mfma) * sizeof(float);
 }
 
 // Both directions with a caller-provided workspace: clouds are Morton-sorted once and both scans are
-// pruned.  mode: 0 automatic (= brute force unless VPN_CHAMFER_MODE=pruned), 1 brute force, 2 pruned.
+// pruned.  mode: 0 automatic, 1 brute force, 2 box-pruned, 3 MFMA-filtered (all bit-identical).
 extern "C" int vpn_chamfer_fwd_ws(const float* p1, const float* p2, int B, int N, int M, float* dist1, int32_t* idx1,
                                   float* dist2, int32_t* idx2, void* workspace, int mode, void* stream) {
     if (!p1 || !p2 || !dist1 || !idx1 || !dist2 || !idx2) return VPN_E_BADARG;
     if (B <= 0 || N <= 0 || M <= 0) return VPN_E_BADARG;
     if (B > 65535) return VPN_E_TOOBIG;
     if (mode == 0) mode = chamfer_mode();
-    if (mode == 0) mode = 1;   // measured on MI355X: pruning only skips 42 % of the chunk visits on
-                               // the C3 workload and runs below the brute-force scan's efficiency -> opt-in only
+    // automatic: the MFMA-filtered scan for large clouds (measured 1.3x the brute-force scan at C3), brute force
+    // for small ones or without a workspace; the box-pruned scan stays opt-in
+    if (mode == 0) mode = (workspace && (long)N * M >= 512L * 512L) ? 3 : 1;
     hipStream_t s = (hipStream_t)stream;
     if (mode == 1 || !workspace) {
         int rc = nn_dispatch(p1, p2, B, N, M, dist1, idx1, s);
         if (rc) return rc;
         return nn_dispatch(p2, p1, B, M, N, dist2, idx2, s);
+    }
+    if (mode == 3) {
+        float* F2 = (float*)workspace;                           // features of p2 (targets of direction 1)
+        float* F1 = F2 + mfma_ws_floats(B, M);                   // features of p1 (targets of direction 2)
+        int rc = mfma_nn(p1, p2, B, N, M, F2, dist1, idx1, s);
+        if (rc) return rc;
+        return mfma_nn(p2, p1, B, M, N, F1, dist2, idx2, s);
     }
     float* cur = (float*)workspace;
     CloudWs w1 = carve(cur, B, N), w2 = carve(cur, B, M);

@@ -393,7 +393,7 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(const float4* __restrict
             m &= m - 1;
             const float4 q0 = lds[k * R_LREC], q1 = lds[k * R_LREC + 1], q2 = lds[k * R_LREC + 2],
                          q3 = lds[k * R_LREC + 3], bb = lds[k * R_LREC + 4];
-            const int imin = __float_as_int(bb.z), imax = __float_as_int(bb.w);
+            [[maybe_unused]] const int imin = __float_as_int(bb.z), imax = __float_as_int(bb.w);
 #pragma unroll
             for (int s = 0; s < R_PPL; ++s) {
 #ifdef VPN_RASTER_ROWSKIP
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(const float4* __restrict
             m &= m - 1;
             const float4 q0 = lds[k * R_LREC], q1 = lds[k * R_LREC + 1], q2 = lds[k * R_LREC + 2],
                          q3 = lds[k * R_LREC + 3], bb = lds[k * R_LREC + 4];
-            const int imin = __float_as_int(bb.z), imax = __float_as_int(bb.w);
+            [[maybe_unused]] const int imin = __float_as_int(bb.z), imax = __float_as_int(bb.w);
             float v[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] = 0.0f;

@@ -112,9 +112,7 @@ class ChamferFunction(Function):
         i2 = torch.empty((B, M), dtype=torch.int32, device=dev)
         loss_b = torch.empty((B,), dtype=torch.float32, device=dev)
         s = _lib.stream()
-        ws = None
-        if os.environ.get('VPN_CHAMFER_MODE', '').startswith('p'):      # opt-in pruned scan needs its sort workspace
-            ws = torch.empty((_lib.lib().vpn_chamfer_workspace(B, N, M) // 4,), dtype=torch.float32, device=dev)
+        ws = torch.empty((_lib.lib().vpn_chamfer_workspace(B, N, M) // 4,), dtype=torch.float32, device=dev)
         _lib.call('vpn_chamfer_fwd_ws', _lib.ptr(p1), _lib.ptr(p2), B, N, M, _lib.ptr(d1), _lib.ptr(i1), _lib.ptr(d2),
                   _lib.ptr(i2), _lib.ptr(ws), 0, s)
         _lib.call('vpn_chamfer_loss', _lib.ptr(d1), _lib.ptr(d2), B, N, M, float(w1), float(w2), _lib.ptr(loss_b), s)
@@ -136,7 +134,7 @@ class ChamferFunction(Function):
         return g1, g2, None, None
 
 
-CHAMFER_MODES = {'auto': 0, 'brute': 1, 'pruned': 2}
+CHAMFER_MODES = {'auto': 0, 'brute': 1, 'pruned': 2, 'mfma': 3}
 
 
 def chamfer_nn(p1, p2, mode='auto'):
