@@ -155,39 +155,46 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = B * world * args.steps / dt
 
-    # ---- per-entry-point device time (HIP events on the launch stream), same steps again
+    # ---- device time per C-ABI entry point and per KERNEL (HIP events on the launch stream, recorded by the
+    # binding / by the library around every launch), same steps again, eagerly
     ksteps = max(5, min(args.steps, 20))
-    with _lib.KernelTimer() as kt:
+    with _lib.KernelTimer() as kt, _lib.KernelProfile() as kp:
         for i in range(ksteps):
             step(i)
-    ktimes = kt.summary()          # name -> (calls, mean ms); vpn_chamfer_nn mixes both directions
-    # split the two chamfer directions (first call of a step = p1->p2, second = p2->p1)
-    phases = {k: round(v[1] * 1e3, 2) for k, v in ktimes.items()}      # microseconds
+        entry = kt.summary()            # entry point -> (calls, mean ms)
+    kern = kp.summary()                 # kernel      -> (calls, mean ms)
+    entry_us = {k: round(v[1] * 1e3, 2) for k, v in entry.items()}
+    kernel_us = {k: {'calls_per_step': round(v[0] / ksteps, 2), 'avg_us': round(v[1] * 1e3, 2)} for k, v in kern.items()}
 
-    # algorithmic bytes per launch (SURVEY.md 8d per-image figures x B; stated in DESIGN.md)
+    # algorithmic bytes / flops per launch (SURVEY.md 8d per-image figures x B)
     N = K * n
-    alg = {
-        'vpn_chamfer_fwd_ws': B * (12 * (N + M) + 8 * (N + M)),    # both directions: clouds in, minima + arg-minima out
-        'vpn_raster_fwd': B * (40 * K + 8 * H * W),
-        'vpn_raster_bwd': B * (8 * H * W + 40 * K + 40 * K),
-        'vpn_raster_loss_fwd': B * (40 * K + 8 * H * W),          # reads the two GT images instead of writing two
-        'vpn_raster_loss_bwd': B * (8 * H * W + 40 * K + 40 * K),
-        'vpn_sample_fwd': B * (40 * K + 12 * N),
-        'vpn_sample_bwd': B * (12 * N + 40 * K + 40 * K),
-        'vpn_chamfer_bwd': B * (12 * (N + M) + 8 * (N + M) + 12 * N),
+    nn_bytes = B * 16 * (N + M)                       # mean of the two directions: both clouds in, dist + idx out
+    alg_bytes = {
+        'chamfer_nn_mfma_kernel': nn_bytes, 'chamfer_nn_kernel<R>': nn_bytes, 'chamfer_nn_pruned_kernel<1>': nn_bytes,
+        'raster_fwd_kernel<0>': B * (40 * K + 8 * H * W), 'raster_fwd_kernel<1>': B * (40 * K + 8 * H * W),
+        'raster_bwd_kernel<0>': B * (8 * H * W + 80 * K), 'raster_bwd_kernel<1>': B * (8 * H * W + 80 * K),
+        'sample_fwd_kernel': B * (40 * K + 12 * N), 'sample_bwd_kernel': B * (12 * N + 80 * K),
+        'chamfer_bwd_lds_kernel': B * (12 * (N + M) + 8 * (N + M) + 12 * N),
     }
-    flops = {   # fp32 vector ops actually issued per launch (for the VALU view)
-
-    }
-    dom = max((k for k in phases if k in alg), key=lambda k: phases[k])
-    dom_s = phases[dom] * 1e-6
-    achieved = alg[dom] / dom_s / 1e9
-    roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': None,
-                'algorithmic_bytes_per_launch': alg[dom], 'avg_launch_us': phases[dom]}
-    if dom in flops:
-        roofline['valu_tflops'] = round(flops[dom] / dom_s / 1e12, 2)
-        roofline['valu_frac_of_fp32_peak'] = round(flops[dom] / dom_s / 1e12 / VALU_PEAK_TFLOPS, 4)
+    pair_flops = 8.0 * B * N * M                      # 8 flop per point pair (3 sub, 3 mul, 2 add  ==  K=4 MAC on the matrix pipe)
+    dom = max((k for k in kern if k in alg_bytes), key=lambda k: kern[k][0] * kern[k][1])
+    dom_s = kern[dom][1] * 1e-3
+    hbm_gbs = alg_bytes[dom] / dom_s / 1e9
+    if dom == 'chamfer_nn_mfma_kernel':               # the filter runs on the fp32 matrix pipe
+        tf = pair_flops / dom_s / 1e12
+        roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': round(tf, 2), 'peak': VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': round(tf / VALU_PEAK_TFLOPS, 4), 'traffic': None,
+                    'algorithmic_flops_per_launch': pair_flops, 'avg_launch_us': round(dom_s * 1e6, 2),
+                    'peak_note': 'dense fp32-input MFMA peak (v_mfma_f32_32x32x2_f32), MI355X_MICROARCH.md',
+                    'hbm_view': {'algorithmic_bytes_per_launch': alg_bytes[dom], 'achieved_GBps': round(hbm_gbs, 2),
+                                 'frac_of_8TBps': round(hbm_gbs / HBM_PEAK_GBS, 5)}}
+    else:
+        roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': round(hbm_gbs, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': round(hbm_gbs / HBM_PEAK_GBS, 5), 'traffic': None,
+                    'algorithmic_bytes_per_launch': alg_bytes[dom], 'avg_launch_us': round(dom_s * 1e6, 2)}
+        if dom.startswith('chamfer_nn'):
+            roofline['valu_tflops'] = round(pair_flops / dom_s / 1e12, 2)
+            roofline['valu_frac_of_fp32_peak'] = round(pair_flops / dom_s / 1e12 / VALU_PEAK_TFLOPS, 4)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -205,7 +212,7 @@ def main():
                                    '(N=%d) vs M=%d GT points, Chamfer+L1 fwd+bwd' % (B, K, H, W, n, N, M),
                        'global_batch': B * world, 'parallelism': 'dp%d' % world,
                        'collective': 'rccl all-reduce %d B/step' % ((B * world * K * 10 + 1) * 4) if world > 1 else 'none'},
-            'roofline': roofline, 'kernel_us': phases,
+            'roofline': roofline, 'kernel_us': kernel_us, 'entry_us': entry_us,
         }
         if cpu is not None:
             out['cpu_baseline'] = cpu
@@ -253,7 +260,7 @@ def cpu_baseline(params, gt_points, gt_sil, gt_depth, K, n, H, W, sigma, gamma, 
     loss_g = cd + img[0] + img[1]
     loss_g.backward()
     gerr = float((pg.grad.cpu() - grad_c).abs().max() / grad_c.abs().max())
-    lerr = abs(float(loss_g) - loss_c) / abs(loss_c)
+    lerr = abs(float(loss_g.detach()) - loss_c) / abs(loss_c)
     return {'value': round(S / dt, 3), 'unit': 'images/s', 'cores': cores, 'kind': 'port',
             'sample': '%d images of the same workload (1-image warm-up + 1 timed pass of %.1f s), torch CPU fp32, '
                       'dense B*N*M Chamfer as chamfer_distance.py:14-23' % (S, dt),

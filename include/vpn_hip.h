@@ -50,6 +50,13 @@ int vpn_abi_version(void);
 /* static description of a code returned by any entry point below */
 const char* vpn_error_string(int code);
 
+/* Optional per-kernel timing for benchmarks: while enabled, every kernel the library launches is
+ * bracketed by a pair of HIP events on its stream (do not enable under graph capture).
+ * vpn_profile_enable(on) clears the records; vpn_profile_read synchronises and returns, per kernel
+ * name (newline separated in `names`), the mean duration in ms and the number of launches. */
+int vpn_profile_enable(int on);
+int vpn_profile_read(char* names, int names_len, float* mean_ms, int* calls, int max_entries);
+
 /* ------------------------------------------------------------------ sampler
  * Replaces Sampling.sphere_sampling / cuboid_sampling (modules/sampling/
  * sampling.py:11-37, sphere.py:22-43, cuboid.py:8-101), transform_points

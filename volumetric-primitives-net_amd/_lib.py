@@ -17,6 +17,8 @@ _i, _f, _u64, _sz = ctypes.c_int, ctypes.c_float, ctypes.c_uint64, ctypes.c_size
 SIGNATURES = {
     'vpn_abi_version': (ctypes.c_int, []),
     'vpn_error_string': (ctypes.c_char_p, [_i]),
+    'vpn_profile_enable': (_i, [_i]),
+    'vpn_profile_read': (_i, [ctypes.c_char_p, _i, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int), _i]),
     'vpn_sample_fwd': (_i, [_c_f, _c_f, _c_f, _u64, _u64, _i, _i, _i, _c_f, _c_f]),
     'vpn_sample_bwd': (_i, [_c_f, _c_f, _c_f, _u64, _u64, _i, _i, _i, _c_f, _c_f, _c_f]),
     'vpn_transform_fwd': (_i, [_c_f, _c_f, _c_f, _i, _i, _c_f, _c_f]),
@@ -84,6 +86,32 @@ class KernelTimer:
 
 
 _timer = None
+
+
+class KernelProfile:
+    """Per-KERNEL device times measured by the library itself (HIP events around every launch on the
+    launch stream): `with KernelProfile() as kp: ...; kp.summary()` -> {kernel: (calls, mean ms)}."""
+
+    def __enter__(self):
+        lib().vpn_profile_enable(1)
+        return self
+
+    def __exit__(self, *exc):
+        self._summary = self._read()
+        lib().vpn_profile_enable(0)
+
+    def _read(self):
+        names = ctypes.create_string_buffer(8192)
+        ms = (ctypes.c_float * 64)()
+        calls = (ctypes.c_int * 64)()
+        n = lib().vpn_profile_read(names, 8192, ms, calls, 64)
+        if n < 0:
+            check(n)
+        keys = names.value.decode().split('\n')[:n]
+        return {k: (calls[i], ms[i]) for i, k in enumerate(keys)}
+
+    def summary(self):
+        return getattr(self, '_summary', None) or self._read()
 
 
 def call(name, *args):

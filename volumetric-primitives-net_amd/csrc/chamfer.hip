@@ -328,7 +328,7 @@ static int launch_bwd_lds(const float* pa, const float* pb, const float* dA, con
         if (e != hipSuccess) return (int)e;
         raised = 1;
     }
-    hipLaunchKernelGGL(chamfer_bwd_lds_kernel, dim3(B), dim3(CB_THREADS), lds, s, pa, pb, dA, iA, dB, iB, gl, Na, Nb, wA,
+    VPN_LAUNCH(chamfer_bwd_lds_kernel, dim3(B), dim3(CB_THREADS), lds, s, pa, pb, dA, iA, dB, iB, gl, Na, Nb, wA,
                        wB, ga);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
@@ -337,7 +337,7 @@ static int launch_bwd_lds(const float* pa, const float* pb, const float* dA, con
 template <int R>
 static int launch_nn(const float* q, const float* t, int B, int Nq, int Nt, float* d, int32_t* idx, hipStream_t s) {
     int gx = (Nq + 64 * R - 1) / (64 * R);
-    hipLaunchKernelGGL(chamfer_nn_kernel<R>, dim3(gx, B), dim3(CH_BLOCK), 0, s, q, t, Nq, Nt, d, idx);
+    VPN_LAUNCH(chamfer_nn_kernel<R>, dim3(gx, B), dim3(CH_BLOCK), 0, s, q, t, Nq, Nt, d, idx);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
@@ -982,14 +982,14 @@ static int mfma_nn(const float* q, const float* t, int B, int Nq, int Nt, float*
                    hipStream_t s) {
     const int Ntp = pad32(Nt);
     unsigned int* nmax = reinterpret_cast<unsigned int*>(F + (size_t)B * 4 * Ntp);
-    hipLaunchKernelGGL(chamfer_feat_kernel, dim3(B), dim3(1024), 0, s, t, Nt, Ntp, F, nmax);
+    VPN_LAUNCH(chamfer_feat_kernel, dim3(B), dim3(1024), 0, s, t, Nt, Ntp, F, nmax);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(chamfer_nn_mfma_kernel, dim3((Nq + 127) / 128, B), dim3(CM_BLOCK), 0, s, q, t, F, nmax, Nq, Nt,
+    VPN_LAUNCH(chamfer_nn_mfma_kernel, dim3((Nq + 127) / 128, B), dim3(CM_BLOCK), 0, s, q, t, F, nmax, Nq, Nt,
                        Ntp, d, idx);
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(chamfer_fixup_kernel, dim3((Nq + CF_THREADS - 1) / CF_THREADS, B), dim3(CF_THREADS), 0, s, q, t,
+    VPN_LAUNCH(chamfer_fixup_kernel, dim3((Nq + CF_THREADS - 1) / CF_THREADS, B), dim3(CF_THREADS), 0, s, q, t,
                        Nq, Nt, d, idx);
     e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
@@ -1011,7 +1011,7 @@ static CloudWs carve(float*& cur, int B, int N) {
 
 static int pruned_nn(const CloudWs& q, const CloudWs& t, int B, int Nq, int Nt, float* d, int32_t* idx, hipStream_t s) {
     dim3 grid((Nq + 63) / 64, B);
-    hipLaunchKernelGGL(chamfer_nn_pruned_kernel<1>, grid, dim3(64), 0, s, q.sorted, q.perm, t.sorted, t.perm, t.boxes,
+    VPN_LAUNCH(chamfer_nn_pruned_kernel<1>, grid, dim3(64), 0, s, q.sorted, q.perm, t.sorted, t.perm, t.boxes,
                        Nq, Nt, t.C, d, idx);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
@@ -1059,7 +1059,7 @@ extern "C" int vpn_chamfer_loss(const float* dist1, const float* dist2, int B, i
                                 float* loss_b, void* stream) {
     if (!dist1 || !dist2 || !loss_b) return VPN_E_BADARG;
     if (B <= 0 || N <= 0 || M <= 0) return VPN_E_BADARG;
-    hipLaunchKernelGGL(chamfer_loss_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, dist1, dist2, N, M, w1, w2,
+    VPN_LAUNCH(chamfer_loss_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, dist1, dist2, N, M, w1, w2,
                        loss_b);
     VPN_LAUNCH_CHECK();
     return 0;
@@ -1087,10 +1087,10 @@ extern "C" int vpn_chamfer_bwd(const float* p1, const float* p2, const float* di
     }
     int mx = N > M ? N : M;
     dim3 grid((mx + 255) / 256, B);
-    hipLaunchKernelGGL(chamfer_bwd_direct_kernel, grid, dim3(256), 0, (hipStream_t)stream, p1, p2, dist1, idx1,
+    VPN_LAUNCH(chamfer_bwd_direct_kernel, grid, dim3(256), 0, (hipStream_t)stream, p1, p2, dist1, idx1,
                        dist2, idx2, grad_loss_b, N, M, w1, w2, grad_p1, grad_p2);
     VPN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(chamfer_bwd_scatter_kernel, grid, dim3(256), 0, (hipStream_t)stream, p1, p2, dist1, idx1,
+    VPN_LAUNCH(chamfer_bwd_scatter_kernel, grid, dim3(256), 0, (hipStream_t)stream, p1, p2, dist1, idx1,
                        dist2, idx2, grad_loss_b, N, M, w1, w2, grad_p1, grad_p2);
     VPN_LAUNCH_CHECK();
     return 0;
@@ -1129,9 +1129,9 @@ extern "C" int vpn_chamfer_fwd_ws(const float* p1, const float* p2, int B, int N
     }
     float* cur = (float*)workspace;
     CloudWs w1 = carve(cur, B, N), w2 = carve(cur, B, M);
-    hipLaunchKernelGGL(cloud_sort_kernel, dim3(B), dim3(1024), 0, s, p1, N, w1.sorted, w1.perm, w1.boxes, w1.C);
+    VPN_LAUNCH(cloud_sort_kernel, dim3(B), dim3(1024), 0, s, p1, N, w1.sorted, w1.perm, w1.boxes, w1.C);
     VPN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(cloud_sort_kernel, dim3(B), dim3(1024), 0, s, p2, M, w2.sorted, w2.perm, w2.boxes, w2.C);
+    VPN_LAUNCH(cloud_sort_kernel, dim3(B), dim3(1024), 0, s, p2, M, w2.sorted, w2.perm, w2.boxes, w2.C);
     VPN_LAUNCH_CHECK();
     int rc = pruned_nn(w1, w2, B, N, M, dist1, idx1, s);
     if (rc) return rc;

@@ -693,12 +693,12 @@ extern "C" int vpn_raster_fwd(const float* params, const int32_t* kinds, const f
     if (!alpha || !depth || !aux || !records) return VPN_E_BADARG;
     if (((uintptr_t)records & 15) != 0) return VPN_E_BADARG;
     const int BK = B * K;
-    hipLaunchKernelGGL(raster_prep_kernel, dim3((BK + 255) / 256), dim3(256), 0, (hipStream_t)stream, params, kinds,
+    VPN_LAUNCH(raster_prep_kernel, dim3((BK + 255) / 256), dim3(256), 0, (hipStream_t)stream, params, kinds,
                        cam, BK, K, H, W, sigma, (float4*)records);
     VPN_LAUNCH_CHECK();
     size_t lds = fwd_lds(K);
     if (lds > 65536 && (rc = raise_lds_limit())) return rc;
-    hipLaunchKernelGGL(raster_fwd_kernel<0>, raster_grid(B, H, W), dim3(64), lds, (hipStream_t)stream,
+    VPN_LAUNCH(raster_fwd_kernel<0>, raster_grid(B, H, W), dim3(64), lds, (hipStream_t)stream,
                        (const float4*)records, cam, K, H, W, sigma, gamma, z_far, alpha, depth, aux, LossArgs{});
     VPN_LAUNCH_CHECK();
     return 0;
@@ -719,17 +719,17 @@ extern "C" int vpn_raster_loss_fwd(const float* params, const int32_t* kinds, co
     if (!aux || !records || !loss_ws || !losses) return VPN_E_BADARG;
     if (((uintptr_t)records & 15) != 0) return VPN_E_BADARG;
     const int BK = B * K;
-    hipLaunchKernelGGL(raster_prep_kernel, dim3((BK + 255) / 256), dim3(256), 0, (hipStream_t)stream, params, kinds,
+    VPN_LAUNCH(raster_prep_kernel, dim3((BK + 255) / 256), dim3(256), 0, (hipStream_t)stream, params, kinds,
                        cam, BK, K, H, W, sigma, (float4*)records);
     VPN_LAUNCH_CHECK();
     size_t lds = fwd_lds(K);
     if (lds > 65536 && (rc = raise_lds_limit())) return rc;
     dim3 g = raster_grid(B, H, W);
     LossArgs la{gt_sil, gt_depth, sil_mse, 1.0f / ((float)B * (float)H * (float)W), (float*)loss_ws, nullptr};
-    hipLaunchKernelGGL(raster_fwd_kernel<1>, g, dim3(64), lds, (hipStream_t)stream, (const float4*)records, cam, K, H,
+    VPN_LAUNCH(raster_fwd_kernel<1>, g, dim3(64), lds, (hipStream_t)stream, (const float4*)records, cam, K, H,
                        W, sigma, gamma, z_far, (float*)nullptr, (float*)nullptr, aux, la);
     VPN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(raster_loss_reduce_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float2*)loss_ws,
+    VPN_LAUNCH(raster_loss_reduce_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float2*)loss_ws,
                        (int)(B * g.x * g.y), la.inv_count, losses);
     VPN_LAUNCH_CHECK();
     return 0;
@@ -752,11 +752,11 @@ extern "C" int vpn_raster_bwd(const float* params, const int32_t* kinds, const f
     dim3 g = raster_grid(B, H, W);
     size_t lds = bwd_lds(K);
     if (lds > 65536 && (rc = raise_lds_limit())) return rc;
-    hipLaunchKernelGGL(raster_bwd_kernel<0>, g, dim3(64), lds, (hipStream_t)stream, (const float4*)records, cam, K, H,
+    VPN_LAUNCH(raster_bwd_kernel<0>, g, dim3(64), lds, (hipStream_t)stream, (const float4*)records, cam, K, H,
                        W, sigma, gamma, z_far, aux, grad_alpha, grad_depth, (float*)workspace, LossArgs{});
     VPN_LAUNCH_CHECK();
     const int BK = B * K;
-    hipLaunchKernelGGL(raster_bwd_finish_kernel, dim3((BK + 3) / 4), dim3(256), 0, (hipStream_t)stream, params, cam,
+    VPN_LAUNCH(raster_bwd_finish_kernel, dim3((BK + 3) / 4), dim3(256), 0, (hipStream_t)stream, params, cam,
                        BK, K, (int)(g.x * g.y), (const float*)workspace, grad_params);
     VPN_LAUNCH_CHECK();
     return 0;
@@ -774,11 +774,11 @@ extern "C" int vpn_raster_loss_bwd(const float* params, const int32_t* kinds, co
     size_t lds = bwd_lds(K);
     if (lds > 65536 && (rc = raise_lds_limit())) return rc;
     LossArgs la{gt_sil, gt_depth, sil_mse, 1.0f / ((float)B * (float)H * (float)W), nullptr, grad_losses};
-    hipLaunchKernelGGL(raster_bwd_kernel<1>, g, dim3(64), lds, (hipStream_t)stream, (const float4*)records, cam, K, H,
+    VPN_LAUNCH(raster_bwd_kernel<1>, g, dim3(64), lds, (hipStream_t)stream, (const float4*)records, cam, K, H,
                        W, sigma, gamma, z_far, aux, (const float*)nullptr, (const float*)nullptr, (float*)workspace, la);
     VPN_LAUNCH_CHECK();
     const int BK = B * K;
-    hipLaunchKernelGGL(raster_bwd_finish_kernel, dim3((BK + 3) / 4), dim3(256), 0, (hipStream_t)stream, params, cam,
+    VPN_LAUNCH(raster_bwd_finish_kernel, dim3((BK + 3) / 4), dim3(256), 0, (hipStream_t)stream, params, cam,
                        BK, K, (int)(g.x * g.y), (const float*)workspace, grad_params);
     VPN_LAUNCH_CHECK();
     return 0;

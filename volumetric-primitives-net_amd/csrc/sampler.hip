@@ -253,7 +253,7 @@ extern "C" int vpn_sample_fwd(const float* params, const int32_t* kinds, const f
     if (!params || !kinds || !points) return VPN_E_BADARG;
     if (B <= 0 || K <= 0 || n <= 0) return VPN_E_BADARG;
     if (B > 65535) return VPN_E_TOOBIG;
-    hipLaunchKernelGGL(sample_fwd_kernel, dim3(K, B), dim3(SAMP_BLOCK), 0, (hipStream_t)stream, params, kinds, u,
+    VPN_LAUNCH(sample_fwd_kernel, dim3(K, B), dim3(SAMP_BLOCK), 0, (hipStream_t)stream, params, kinds, u,
                        seed, sample_base, K, n, points);
     VPN_LAUNCH_CHECK();
     return 0;
@@ -265,7 +265,7 @@ extern "C" int vpn_sample_bwd(const float* params, const int32_t* kinds, const f
     if (!params || !kinds || !grad_points || !grad_params) return VPN_E_BADARG;
     if (B <= 0 || K <= 0 || n <= 0) return VPN_E_BADARG;
     if (B > 65535) return VPN_E_TOOBIG;
-    hipLaunchKernelGGL(sample_bwd_kernel, dim3(K, B), dim3(SAMP_BLOCK), 0, (hipStream_t)stream, params, kinds, u,
+    VPN_LAUNCH(sample_bwd_kernel, dim3(K, B), dim3(SAMP_BLOCK), 0, (hipStream_t)stream, params, kinds, u,
                        seed, sample_base, K, n, grad_points, grad_params);
     VPN_LAUNCH_CHECK();
     return 0;
@@ -278,7 +278,7 @@ extern "C" int vpn_transform_fwd(const float* points, const float* q, const floa
     if (B > 65535) return VPN_E_TOOBIG;
     int gx = (N + TR_BLOCK - 1) / TR_BLOCK;
     if (gx > 1024) gx = 1024;
-    hipLaunchKernelGGL(transform_fwd_kernel, dim3(gx, B), dim3(TR_BLOCK), 0, (hipStream_t)stream, points, q, t, N,
+    VPN_LAUNCH(transform_fwd_kernel, dim3(gx, B), dim3(TR_BLOCK), 0, (hipStream_t)stream, points, q, t, N,
                        out);
     VPN_LAUNCH_CHECK();
     return 0;
@@ -288,7 +288,7 @@ extern "C" int vpn_transform_bwd(const float* points, const float* q, const floa
                                  float* grad_points, float* grad_q, float* grad_t, void* stream) {
     if (!points || !q || !grad_out) return VPN_E_BADARG;
     if (B <= 0 || N <= 0) return VPN_E_BADARG;
-    hipLaunchKernelGGL(transform_bwd_kernel, dim3(B), dim3(TR_BLOCK), 0, (hipStream_t)stream, points, q, grad_out,
+    VPN_LAUNCH(transform_bwd_kernel, dim3(B), dim3(TR_BLOCK), 0, (hipStream_t)stream, points, q, grad_out,
                        N, grad_points, grad_q, grad_t);
     VPN_LAUNCH_CHECK();
     return 0;

@@ -15,6 +15,21 @@
 
 namespace vpn {
 
+// Optional per-kernel timing (bench.py): when enabled every launch is bracketed by HIP events on its stream.
+void prof_begin(const char* name, hipStream_t s);
+void prof_end(hipStream_t s);
+
+}  // namespace vpn
+
+#define VPN_LAUNCH(kern, grid, block, lds, strm, ...)                                  \
+    do {                                                                               \
+        vpn::prof_begin(#kern, strm);                                                  \
+        hipLaunchKernelGGL(kern, grid, block, lds, strm, __VA_ARGS__);                 \
+        vpn::prof_end(strm);                                                           \
+    } while (0)
+
+namespace vpn {
+
 struct Mat3 { float m[3][3]; };
 
 struct Pose {          // everything derived from q (B,4) that fwd and bwd need
