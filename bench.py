@@ -196,6 +196,15 @@ def main():
             roofline['valu_tflops'] = round(pair_flops / dom_s / 1e12, 2)
             roofline['valu_frac_of_fp32_peak'] = round(pair_flops / dom_s / 1e12 / VALU_PEAK_TFLOPS, 4)
 
+    # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 cannot run inside bench.py)
+    try:
+        tr = json.load(open(os.path.join(ROOT, 'profiles', 'r01d_traffic.json')))['kernels'].get(dom)
+        if tr and (B, K, n, M, H) == (64, 32, 256, 2048, 256):
+            roofline['traffic'] = tr['traffic_bytes']
+            roofline['traffic_source'] = 'profiles/r01d_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same workload)'
+    except (OSError, ValueError, KeyError):
+        pass
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(params_all[:args.cpu_sample].detach().cpu(), gt_all[:args.cpu_sample].cpu(),
