@@ -91,14 +91,17 @@ def main():
     cd_fn = vpn_amd.ChamferDistanceLoss()
     sigma, gamma, z_far = vpn_amd.config.RASTER_SIGMA, vpn_amd.config.RASTER_GAMMA, vpn_amd.config.RASTER_Z_FAR
 
-    def step(i):
+    def compute(i):
+        # total = ChamferDistanceLoss(sample(params), gt) + SilhouetteLoss(L1) + L1 depth loss  (train.py:243-262),
+        # one autograd node: sampler -> Chamfer scans -> raster with fused image losses, and the matching backward
         params.grad = None
-        pts = vpn_amd.Sampling.sample_primitives(params, kinds, n, seed=1234 + i, sample_base=rank * B)
-        cd = cd_fn(pts, gt_points)
-        # SilhouetteLoss (L1, silhouette.py:11) + L1 depth loss, fused into the raster pass
-        img = vpn_amd.RasterLossFunction.apply(params, kinds, cam, gt_sil, gt_depth, H, W, sigma, gamma, z_far, False)
-        loss = cd + img.sum()
-        loss.backward()
+        out = vpn_amd.HotPathLossFunction.apply(params, kinds, cam, gt_points, gt_sil, gt_depth, n, 1234 + i,
+                                                rank * B, H, W, sigma, gamma, z_far, 1.0, 1.0, 1.0)
+        out[2].backward()
+        return out[2]
+
+    def step(i):
+        loss = compute(i)
         if reducer is not None:
             return reducer.reduce(params.grad, loss)
         return params.grad, loss
@@ -113,14 +116,6 @@ def main():
     use_graph = not args.no_graph
     run_step = step
     if use_graph:
-        def compute(i):
-            params.grad = None
-            pts = vpn_amd.Sampling.sample_primitives(params, kinds, n, seed=1234 + i, sample_base=rank * B)
-            cd = cd_fn(pts, gt_points)
-            img = vpn_amd.RasterLossFunction.apply(params, kinds, cam, gt_sil, gt_depth, H, W, sigma, gamma, z_far, False)
-            loss = cd + img.sum()
-            loss.backward()
-            return loss
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -262,11 +257,9 @@ def cpu_baseline(params, gt_points, gt_sil, gt_depth, K, n, H, W, sigma, gamma, 
     dt = time.perf_counter() - t0
     # same samples on the GPU (explicit uniforms = the Philox draws the kernel makes itself)
     pg = gpu_params[:S].detach().clone().requires_grad_(True)
-    pts = vpn_amd.Sampling.sample_primitives(pg, kinds, n, seed=1234, sample_base=0)
-    cd = vpn_amd.ChamferDistanceLoss()(pts, gpu_gt_points[:S])
-    img = vpn_amd.RasterLossFunction.apply(pg, kinds, cam[:S].contiguous(), gpu_gt_sil[:S].contiguous(),
-                                           gpu_gt_depth[:S].contiguous(), H, W, sigma, gamma, z_far, False)
-    loss_g = cd + img[0] + img[1]
+    loss_g = vpn_amd.HotPathLossFunction.apply(pg, kinds, cam[:S].contiguous(), gpu_gt_points[:S].contiguous(),
+                                               gpu_gt_sil[:S].contiguous(), gpu_gt_depth[:S].contiguous(), n, 1234, 0,
+                                               H, W, sigma, gamma, z_far, 1.0, 1.0, 1.0)[2]
     loss_g.backward()
     gerr = float((pg.grad.cpu() - grad_c).abs().max() / grad_c.abs().max())
     lerr = abs(float(loss_g.detach()) - loss_c) / abs(loss_c)

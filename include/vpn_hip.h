@@ -156,21 +156,27 @@ int vpn_raster_bwd(const float* params, const int32_t* kinds, const float* cam,
  * against the GT silhouette) in one pass, optionally with an L1 depth loss: the losses are
  * evaluated where the pixel is produced, so alpha/depth and their gradients never travel through HBM.
  *   gt_sil, gt_depth [B,H,W] (either may be NULL -> that loss is 0); sil_mse: 0 = L1, 1 = MSE;
- *   losses [2] = (mean silhouette loss, mean |depth - gt_depth|);
+ *   losses [3] = (mean silhouette loss, mean |depth - gt_depth|, total); the total is written only when
+ *   extra_loss_b [nb] is given: total = w_extra * mean(extra_loss_b) + w_sil * losses[0] + w_dep * losses[1]
+ *   (the weighted sum of train.py:243-262 with the per-sample Chamfer losses as `extra`);
  *   loss_ws: vpn_raster_loss_workspace(B,H,W) bytes of scratch; aux/records as for vpn_raster_fwd.
  */
 size_t vpn_raster_loss_workspace(int B, int H, int W);
 int vpn_raster_loss_fwd(const float* params, const int32_t* kinds, const float* cam,
                         int B, int K, int H, int W, float sigma, float gamma, float z_far,
                         const float* gt_sil, const float* gt_depth, int sil_mse,
-                        float* aux, void* records, void* loss_ws, float* losses, void* stream);
+                        float* aux, void* records, void* loss_ws, float* losses,
+                        const float* extra_loss_b, int nb, float w_extra, float w_sil, float w_dep,
+                        void* stream);
 /* grad_losses [2] (device): upstream gradients of the two scalar losses; workspace as for
- * vpn_raster_bwd; grad_params [B,K,10] is written. */
+ * vpn_raster_bwd; grad_params [B,K,10] is written, or added to when accumulate != 0 (so the gradient of
+ * the sampler + Chamfer branch and of the raster branch meet without an extra pass). */
 int vpn_raster_loss_bwd(const float* params, const int32_t* kinds, const float* cam,
                         int B, int K, int H, int W, float sigma, float gamma, float z_far,
                         const float* aux, const void* records,
                         const float* gt_sil, const float* gt_depth, int sil_mse,
-                        const float* grad_losses, void* workspace, float* grad_params, void* stream);
+                        const float* grad_losses, void* workspace, float* grad_params, int accumulate,
+                        void* stream);
 
 #ifdef __cplusplus
 }

@@ -461,6 +461,42 @@ def test_raster_fused_losses(vpn):
     assert rel_err(pg.grad.cpu(), pc.grad) <= RTOL
 
 
+def test_hot_path_loss_single_node(vpn):
+    """HotPathLossFunction (sampler -> Chamfer -> raster + image losses -> total, one autograd node) against
+    the oracle and against the composition of the individual modules."""
+    gen = torch.Generator().manual_seed(33)
+    B, K, n, M, H, W = 3, 5, 40, 300, 48, 40
+    params = rand_params(gen, B, K)
+    kinds = [1, 0, 0, 1, 0]
+    gt_pts = torch.rand(B, M, 3, generator=gen) - 0.5
+    gt_sil = (torch.rand(B, 1, H, W, generator=gen) > 0.5).float()
+    gt_dep = 2.0 - torch.rand(B, H, W, generator=gen)
+    cam = torch.tensor([[1.0, 0.0, 0.0]]).expand(B, 3).contiguous()
+    w = (0.7, 1.3, 0.4)
+    seed = 77
+    u = O.philox_uniforms(seed, 0, B, K, n)
+    pc = params.clone().requires_grad_(True)
+    pts = O.sample_primitives(pc, kinds, u)
+    a, d = O.raster(pc, kinds, cam, H, W, 0.05, 0.1, 2.0)
+    ref = w[0] * O.chamfer_loss(pts, gt_pts) + w[1] * O.silhouette_loss(a, gt_sil) + w[2] * (d - gt_dep).abs().mean()
+    ref.backward()
+    kt = vpn.kinds_tensor(kinds, torch.device(DEV))
+    pg = g(params).requires_grad_(True)
+    out = vpn.HotPathLossFunction.apply(pg, kt, g(cam), g(gt_pts), g(gt_sil), g(gt_dep), n, seed, 0, H, W, 0.05, 0.1,
+                                        2.0, *w)
+    out[2].backward()
+    assert rel_err(out[2].detach().cpu(), ref.detach()) <= RTOL
+    assert rel_err(pg.grad.cpu(), pc.grad) <= RTOL
+    # same thing assembled from the module surface
+    pm = g(params).requires_grad_(True)
+    pts_g = vpn.Sampling.sample_primitives(pm, kinds, n, seed=seed)
+    img = vpn.RasterLossFunction.apply(pm, kt, g(cam), g(gt_sil), g(gt_dep), H, W, 0.05, 0.1, 2.0, False)
+    tot = w[0] * vpn.ChamferDistanceLoss()(pts_g, g(gt_pts)) + w[1] * img[0] + w[2] * img[1]
+    tot.backward()
+    assert rel_err(out[2].detach().cpu(), tot.detach().cpu()) <= 1e-5
+    assert rel_err(pg.grad.cpu(), pm.grad.cpu()) <= 1e-5
+
+
 def test_raster_full_size_properties(vpn):
     """Config 3 raster (B=64, K=32, 256x256): too big for the dense oracle, so: oracle on two
     images, plus linearity of the backward in the incoming gradient and determinism."""

@@ -4,7 +4,7 @@ Import as `vpn_amd` (repo-root alias module); the directory name is fixed by the
 layout.  Everything here runs on hand-written HIP kernels in libvpn_hip.so through the C
 ABI of include/vpn_hip.h; there is no CPU fallback."""
 from . import config
-from .ops import (SPHERE, CUBOID, SampleFunction, TransformFunction, ChamferFunction, RasterFunction, RasterLossFunction,
+from .ops import (SPHERE, CUBOID, SampleFunction, TransformFunction, ChamferFunction, RasterFunction, RasterLossFunction, HotPathLossFunction,
                   chamfer_nn, kinds_tensor)
 from .primitives import PrimitivePack, pack_primitives, kinds_from_counts
 from .modules import (Sampling, ChamferDistanceLoss, SilhouetteLoss, VPDiverseLoss, VertexRenderer,

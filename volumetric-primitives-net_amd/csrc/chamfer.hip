@@ -631,7 +631,10 @@ __global__ __launch_bounds__(64) void chamfer_nn_pruned_kernel(
 // =====================================================================================
 typedef float f16v __attribute__((ext_vector_type(16)));
 constexpr int CM_BLOCK = 256;            // 4 waves x 32 queries
-constexpr int CM_TILE = 512;             // targets per LDS feature tile (8 KB per buffer)
+#ifndef VPN_CM_TILE
+#define VPN_CM_TILE 512
+#endif
+constexpr int CM_TILE = VPN_CM_TILE;     // targets per LDS feature tile (16 B per target per buffer)
 constexpr float CM_EPS = 8.0f * 5.9604644775390625e-08f;   // 8 * 2^-24: bound on the relative rounding of t_ij
 
 // feature planes F[b][4][Np] = (x, y, z, |p|^2) (padded with a never-winning sentinel), nmax[b] = max |p|^2.
@@ -765,15 +768,16 @@ __global__ __launch_bounds__(CF_THREADS) void chamfer_fixup_kernel(const float* 
     }
 }
 
+// balanced v_min3 tree (depth 3): a serial chain of 8 dependent v_min3 made the filter latency-bound
 __device__ inline float min16(const f16v& v) {
-    float m = __builtin_fminf(__builtin_fminf(v[0], v[1]), v[2]);
-    m = __builtin_fminf(__builtin_fminf(m, v[3]), v[4]);
-    m = __builtin_fminf(__builtin_fminf(m, v[5]), v[6]);
-    m = __builtin_fminf(__builtin_fminf(m, v[7]), v[8]);
-    m = __builtin_fminf(__builtin_fminf(m, v[9]), v[10]);
-    m = __builtin_fminf(__builtin_fminf(m, v[11]), v[12]);
-    m = __builtin_fminf(__builtin_fminf(m, v[13]), v[14]);
-    return __builtin_fminf(m, v[15]);
+    const float a = __builtin_fminf(__builtin_fminf(v[0], v[1]), v[2]);
+    const float b = __builtin_fminf(__builtin_fminf(v[3], v[4]), v[5]);
+    const float c = __builtin_fminf(__builtin_fminf(v[6], v[7]), v[8]);
+    const float d = __builtin_fminf(__builtin_fminf(v[9], v[10]), v[11]);
+    const float e = __builtin_fminf(__builtin_fminf(v[12], v[13]), v[14]);
+    const float f = __builtin_fminf(__builtin_fminf(a, b), c);
+    const float g = __builtin_fminf(__builtin_fminf(d, e), v[15]);
+    return __builtin_fminf(f, g);
 }
 
 __global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_kernel(const float* __restrict__ qpts,
@@ -802,24 +806,25 @@ __global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_kernel(const float* 
     __shared__ __attribute__((aligned(16))) float tileF[2][4][CM_TILE];
     const float* Fb = F + (size_t)b * 4 * Ntp;
     // each lane moves 2 float4 per tile (4 planes x CM_TILE floats = 512 float4, 256 lanes)
-    auto fetch = [&](int t0, float4 v[2]) {
+    constexpr int CM_F4 = CM_TILE / CM_BLOCK;       // float4 per lane per tile
+    auto fetch = [&](int t0, float4 v[CM_F4]) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < CM_F4; ++u) {
             const int i = threadIdx.x + u * CM_BLOCK;
             const int plane = i / (CM_TILE / 4), off = (i - plane * (CM_TILE / 4)) * 4;
             v[u] = make_float4(0.f, 0.f, 0.f, 3.0e38f);
             if (t0 + off < Ntp) v[u] = *reinterpret_cast<const float4*>(Fb + (size_t)plane * Ntp + t0 + off);
         }
     };
-    auto stash = [&](int buf, const float4 v[2]) {
+    auto stash = [&](int buf, const float4 v[CM_F4]) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < CM_F4; ++u) {
             const int i = threadIdx.x + u * CM_BLOCK;
             const int plane = i / (CM_TILE / 4), off = (i - plane * (CM_TILE / 4)) * 4;
             *reinterpret_cast<float4*>(&tileF[buf][plane][off]) = v[u];
         }
     };
-    float4 pre[2];
+    float4 pre[CM_F4];
     fetch(0, pre);
     stash(0, pre);
     __syncthreads();

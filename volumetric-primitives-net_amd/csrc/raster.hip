@@ -443,8 +443,11 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(const float4* __restrict
 
 // fixed-order sum of the per-tile loss partials -> the two mean losses (one workgroup of 1024 lanes,
 // float2 loads, 4 independent accumulators per lane so the loads pipeline)
+// optional: losses[2] = w_extra * mean(extra_loss_b[0..nb)) + w_sil * losses[0] + w_dep * losses[1]
 __global__ __launch_bounds__(1024) void raster_loss_reduce_kernel(const float2* __restrict__ tile_loss, int n,
-                                                                  float inv_count, float* __restrict__ losses) {
+                                                                  float inv_count, float* __restrict__ losses,
+                                                                  const float* __restrict__ extra_loss_b, int nb,
+                                                                  float w_extra, float w_sil, float w_dep) {
     __shared__ float red[2][16];
     float a[4] = {0.f, 0.f, 0.f, 0.f}, c[4] = {0.f, 0.f, 0.f, 0.f};
     int i = threadIdx.x;
@@ -461,6 +464,11 @@ __global__ __launch_bounds__(1024) void raster_loss_reduce_kernel(const float2* 
         for (int w = 0; w < 16; ++w) { ta += red[0][w]; tc += red[1][w]; }
         losses[0] = ta * inv_count;
         losses[1] = tc * inv_count;
+        if (extra_loss_b) {
+            float e = 0.f;
+            for (int i = 0; i < nb; ++i) e += extra_loss_b[i];
+            losses[2] = w_extra * (e / (float)nb) + w_sil * losses[0] + w_dep * losses[1];
+        }
     }
 }
 
@@ -598,7 +606,7 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(const float4* __restrict
 __global__ __launch_bounds__(256) void raster_bwd_finish_kernel(const float* __restrict__ params,
                                                                 const float* __restrict__ cam, int BK, int K,
                                                                 int ntile, const float* __restrict__ partial,
-                                                                float* __restrict__ gparams) {
+                                                                float* __restrict__ gparams, int accumulate) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int bk = blockIdx.x * 4 + wave;
     if (bk >= BK) return;
@@ -644,9 +652,9 @@ __global__ __launch_bounds__(256) void raster_bwd_finish_kernel(const float* __r
     }
     pose_backward(P, prm[3], prm[4], prm[5], gR, gq);
     float* o = gparams + (size_t)bk * VPN_PARAM_STRIDE;
-    o[0] = gv[0]; o[1] = gv[1]; o[2] = gv[2];
-    o[3] = gq[0]; o[4] = gq[1]; o[5] = gq[2]; o[6] = gq[3];
-    o[7] = gt[0]; o[8] = gt[1]; o[9] = gt[2];
+    const float r[10] = {gv[0], gv[1], gv[2], gq[0], gq[1], gq[2], gq[3], gt[0], gt[1], gt[2]};
+#pragma unroll
+    for (int i = 0; i < 10; ++i) o[i] = accumulate ? o[i] + r[i] : r[i];   // accumulate: add to the sampler's gradient
 }
 
 static inline dim3 raster_grid(int B, int H, int W) { return dim3((W + R_TW - 1) / R_TW, (H + R_TH - 1) / R_TH, B); }
@@ -713,7 +721,8 @@ extern "C" size_t vpn_raster_loss_workspace(int B, int H, int W) {
 extern "C" int vpn_raster_loss_fwd(const float* params, const int32_t* kinds, const float* cam, int B, int K, int H,
                                    int W, float sigma, float gamma, float z_far, const float* gt_sil,
                                    const float* gt_depth, int sil_mse, float* aux, void* records, void* loss_ws,
-                                   float* losses, void* stream) {
+                                   float* losses, const float* extra_loss_b, int nb, float w_extra, float w_sil,
+                                   float w_dep, void* stream) {
     int rc = raster_check(params, kinds, cam, B, K, H, W, sigma, gamma);
     if (rc) return rc;
     if (!aux || !records || !loss_ws || !losses) return VPN_E_BADARG;
@@ -730,7 +739,7 @@ extern "C" int vpn_raster_loss_fwd(const float* params, const int32_t* kinds, co
                        W, sigma, gamma, z_far, (float*)nullptr, (float*)nullptr, aux, la);
     VPN_LAUNCH_CHECK();
     VPN_LAUNCH(raster_loss_reduce_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float2*)loss_ws,
-                       (int)(B * g.x * g.y), la.inv_count, losses);
+                       (int)(B * g.x * g.y), la.inv_count, losses, extra_loss_b, nb, w_extra, w_sil, w_dep);
     VPN_LAUNCH_CHECK();
     return 0;
 }
@@ -757,7 +766,7 @@ extern "C" int vpn_raster_bwd(const float* params, const int32_t* kinds, const f
     VPN_LAUNCH_CHECK();
     const int BK = B * K;
     VPN_LAUNCH(raster_bwd_finish_kernel, dim3((BK + 3) / 4), dim3(256), 0, (hipStream_t)stream, params, cam,
-                       BK, K, (int)(g.x * g.y), (const float*)workspace, grad_params);
+                       BK, K, (int)(g.x * g.y), (const float*)workspace, grad_params, 0);
     VPN_LAUNCH_CHECK();
     return 0;
 }
@@ -765,7 +774,7 @@ extern "C" int vpn_raster_bwd(const float* params, const int32_t* kinds, const f
 extern "C" int vpn_raster_loss_bwd(const float* params, const int32_t* kinds, const float* cam, int B, int K, int H,
                                    int W, float sigma, float gamma, float z_far, const float* aux, const void* records,
                                    const float* gt_sil, const float* gt_depth, int sil_mse, const float* grad_losses,
-                                   void* workspace, float* grad_params, void* stream) {
+                                   void* workspace, float* grad_params, int accumulate, void* stream) {
     int rc = raster_check(params, kinds, cam, B, K, H, W, sigma, gamma);
     if (rc) return rc;
     if (!aux || !records || !grad_losses || !workspace || !grad_params) return VPN_E_BADARG;
@@ -779,7 +788,7 @@ extern "C" int vpn_raster_loss_bwd(const float* params, const int32_t* kinds, co
     VPN_LAUNCH_CHECK();
     const int BK = B * K;
     VPN_LAUNCH(raster_bwd_finish_kernel, dim3((BK + 3) / 4), dim3(256), 0, (hipStream_t)stream, params, cam,
-                       BK, K, (int)(g.x * g.y), (const float*)workspace, grad_params);
+                       BK, K, (int)(g.x * g.y), (const float*)workspace, grad_params, accumulate);
     VPN_LAUNCH_CHECK();
     return 0;
 }

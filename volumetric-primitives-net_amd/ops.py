@@ -4,6 +4,7 @@ Pattern follows the reference's own native op, emdFunction (modules/loss/emd/
 emd_module.py:29-70): forward allocates the outputs, calls native code, saves what
 backward needs; backward returns one gradient per tensor input and None for the rest.
 Unlike it, a non-zero return code raises."""
+import ctypes
 import os
 
 import torch
@@ -209,10 +210,11 @@ class RasterLossFunction(Function):
         aux = torch.empty((B, 3, H, W), dtype=torch.float32, device=dev)
         rec = torch.empty((L.vpn_raster_records_size(B, K) // 4,), dtype=torch.float32, device=dev)
         lws = torch.empty((L.vpn_raster_loss_workspace(B, H, W) // 4,), dtype=torch.float32, device=dev)
-        losses = torch.empty((2,), dtype=torch.float32, device=dev)
+        losses = torch.empty((3,), dtype=torch.float32, device=dev)
         _lib.call('vpn_raster_loss_fwd', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(cam), B, K, H, W, float(sigma),
                   float(gamma), float(z_far), _lib.ptr(gt_sil), _lib.ptr(gt_depth), int(bool(sil_mse)), _lib.ptr(aux),
-                  _lib.ptr(rec), _lib.ptr(lws), _lib.ptr(losses), _lib.stream())
+                  _lib.ptr(rec), _lib.ptr(lws), _lib.ptr(losses), None, 0, 0.0, 0.0, 0.0, _lib.stream())
+        losses = losses[:2]
         empty = torch.empty(0, device=dev)
         ctx.save_for_backward(params, kinds, cam, aux, rec, gt_sil if gt_sil is not None else empty,
                               gt_depth if gt_depth is not None else empty)
@@ -231,5 +233,89 @@ class RasterLossFunction(Function):
         _lib.call('vpn_raster_loss_bwd', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(cam), B, K, H, W, sigma, gamma,
                   z_far, _lib.ptr(aux), _lib.ptr(rec), _lib.ptr(gt_sil) if has_sil else None,
                   _lib.ptr(gt_depth) if has_depth else None, sil_mse, _lib.ptr(g), _lib.ptr(ws),
-                  _lib.ptr(grad_params), _lib.stream())
+                  _lib.ptr(grad_params), 0, _lib.stream())
         return (grad_params,) + (None,) * 10
+
+
+_PATTERNS = {}
+
+
+def _grad_pattern(B, w_cd, w_sil, w_depth, dev):
+    """d total / d(loss_b[0..B), sil, depth): constant per configuration, cached on the device (created
+    outside any graph capture by the first eager call)."""
+    key = (B, float(w_cd), float(w_sil), float(w_depth), str(dev))
+    if key not in _PATTERNS:
+        _PATTERNS[key] = torch.tensor([w_cd / B] * B + [w_sil, w_depth], dtype=torch.float32, device=dev)
+    return _PATTERNS[key]
+
+
+class HotPathLossFunction(Function):
+    """One training-step loss of the reference's hot path in a single autograd node (train.py:243-262):
+        total = w_cd * ChamferDistanceLoss(sample(params), gt_points) + w_sil * SilhouetteLoss + w_depth * L1(depth)
+    Forward: sampler -> Chamfer scans -> per-sample loss -> raster with fused image losses (which also
+    assembles the total).  Backward: Chamfer backward -> sampler backward (writes d/dparams) -> raster
+    backward (adds to it).  No intermediate ever goes through an ATen kernel.  Returns [3] =
+    (silhouette loss, depth loss, total); differentiate the total."""
+
+    @staticmethod
+    def forward(ctx, params, kinds, cam, gt_points, gt_sil, gt_depth, n, seed, sample_base, H, W, sigma, gamma,
+                z_far, w_cd, w_sil, w_depth):
+        params, cam, gt_points = _f32c(params), _f32c(cam), _f32c(gt_points)
+        B, K, _ = params.shape
+        M = gt_points.shape[1]
+        N = K * n
+        dev = params.device
+        L = _lib.lib()
+        s = _lib.stream()
+        gt_sil = _f32c(gt_sil).reshape(B, H, W) if gt_sil is not None else None
+        gt_depth = _f32c(gt_depth).reshape(B, H, W) if gt_depth is not None else None
+        points = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
+        _lib.call('vpn_sample_fwd', _lib.ptr(params), _lib.ptr(kinds), None, int(seed), int(sample_base), B, K, n,
+                  _lib.ptr(points), s)
+        d1 = torch.empty((B, N), dtype=torch.float32, device=dev)
+        d2 = torch.empty((B, M), dtype=torch.float32, device=dev)
+        i1 = torch.empty((B, N), dtype=torch.int32, device=dev)
+        i2 = torch.empty((B, M), dtype=torch.int32, device=dev)
+        cws = torch.empty((L.vpn_chamfer_workspace(B, N, M) // 4,), dtype=torch.float32, device=dev)
+        _lib.call('vpn_chamfer_fwd_ws', _lib.ptr(points), _lib.ptr(gt_points), B, N, M, _lib.ptr(d1), _lib.ptr(i1),
+                  _lib.ptr(d2), _lib.ptr(i2), _lib.ptr(cws), 0, s)
+        loss_b = torch.empty((B,), dtype=torch.float32, device=dev)
+        _lib.call('vpn_chamfer_loss', _lib.ptr(d1), _lib.ptr(d2), B, N, M, 1.0, 1.0, _lib.ptr(loss_b), s)
+        aux = torch.empty((B, 3, H, W), dtype=torch.float32, device=dev)
+        rec = torch.empty((L.vpn_raster_records_size(B, K) // 4,), dtype=torch.float32, device=dev)
+        lws = torch.empty((L.vpn_raster_loss_workspace(B, H, W) // 4,), dtype=torch.float32, device=dev)
+        losses = torch.empty((3,), dtype=torch.float32, device=dev)
+        _lib.call('vpn_raster_loss_fwd', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(cam), B, K, H, W, float(sigma),
+                  float(gamma), float(z_far), _lib.ptr(gt_sil), _lib.ptr(gt_depth), 0, _lib.ptr(aux), _lib.ptr(rec),
+                  _lib.ptr(lws), _lib.ptr(losses), _lib.ptr(loss_b), B, float(w_cd), float(w_sil), float(w_depth), s)
+        pattern = _grad_pattern(B, w_cd, w_sil, w_depth, dev)
+        empty = torch.empty(0, device=dev)
+        ctx.save_for_backward(params, kinds, cam, gt_points, points, d1, i1, d2, i2, aux, rec,
+                              gt_sil if gt_sil is not None else empty, gt_depth if gt_depth is not None else empty,
+                              pattern)
+        ctx.meta = (B, K, n, M, H, W, int(seed), int(sample_base), float(sigma), float(gamma), float(z_far),
+                    gt_sil is not None, gt_depth is not None)
+        return losses
+
+    @staticmethod
+    def backward(ctx, grad_losses):
+        (params, kinds, cam, gt_points, points, d1, i1, d2, i2, aux, rec, gt_sil, gt_depth, pattern) = ctx.saved_tensors
+        B, K, n, M, H, W, seed, base, sigma, gamma, z_far, has_sil, has_depth = ctx.meta
+        N = K * n
+        s = _lib.stream()
+        # only the total (index 2) is meant to be differentiated
+        gvec = (pattern * grad_losses[2]).contiguous()          # one small kernel: [B] for Chamfer, [2] for the raster
+        grad_points = torch.empty_like(points)
+        _lib.call('vpn_chamfer_bwd', _lib.ptr(points), _lib.ptr(gt_points), _lib.ptr(d1), _lib.ptr(i1), _lib.ptr(d2),
+                  _lib.ptr(i2), _lib.ptr(gvec), B, N, M, 1.0, 1.0, _lib.ptr(grad_points), None, s)
+        grad_params = torch.empty_like(params)
+        _lib.call('vpn_sample_bwd', _lib.ptr(params), _lib.ptr(kinds), None, seed, base, B, K, n, _lib.ptr(grad_points),
+                  _lib.ptr(grad_params), s)
+        ws = torch.empty((_lib.lib().vpn_raster_bwd_workspace(B, K, H, W) // 4,), dtype=torch.float32,
+                         device=params.device)
+        g2 = ctypes.c_void_p(gvec.data_ptr() + 4 * B)           # the last two entries: (sil, depth) gradients
+        _lib.call('vpn_raster_loss_bwd', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(cam), B, K, H, W, sigma, gamma,
+                  z_far, _lib.ptr(aux), _lib.ptr(rec), _lib.ptr(gt_sil) if has_sil else None,
+                  _lib.ptr(gt_depth) if has_depth else None, 0, g2, _lib.ptr(ws), _lib.ptr(grad_params), 1, s)
+        return (grad_params,) + (None,) * 16
+
