@@ -168,6 +168,9 @@ int vpn_raster_loss_fwd(const float* params, const int32_t* kinds, const float* 
                         float* aux, void* records, void* loss_ws, float* losses,
                         const float* extra_loss_b, int nb, float w_extra, float w_sil, float w_dep,
                         void* stream);
+/* losses[2] = w_extra * mean(loss_b[0..nb)) + w_sil * losses[0] + w_dep * losses[1]: the total when the raster
+ * and the Chamfer branches ran concurrently on two streams and meet here. */
+int vpn_total_loss(const float* loss_b, int nb, float w_extra, float w_sil, float w_dep, float* losses, void* stream);
 /* grad_losses [2] (device): upstream gradients of the two scalar losses; workspace as for
  * vpn_raster_bwd; grad_params [B,K,10] is written, or added to when accumulate != 0 (so the gradient of
  * the sampler + Chamfer branch and of the raster branch meet without an extra pass). */

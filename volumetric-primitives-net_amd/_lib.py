@@ -36,6 +36,7 @@ SIGNATURES = {
     'vpn_raster_loss_workspace': (_sz, [_i, _i, _i]),
     'vpn_raster_loss_fwd': (_i, [_c_f, _c_f, _c_f, _i, _i, _i, _i, _f, _f, _f, _c_f, _c_f, _i, _c_f, _c_f, _c_f, _c_f,
                                  _c_f, _i, _f, _f, _f, _c_f]),
+    'vpn_total_loss': (_i, [_c_f, _i, _f, _f, _f, _c_f, _c_f]),
     'vpn_raster_loss_bwd': (_i, [_c_f, _c_f, _c_f, _i, _i, _i, _i, _f, _f, _f, _c_f, _c_f, _c_f, _c_f, _i, _c_f, _c_f, _c_f,
                                  _i, _c_f]),
 }

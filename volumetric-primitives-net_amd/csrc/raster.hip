@@ -792,3 +792,21 @@ extern "C" int vpn_raster_loss_bwd(const float* params, const int32_t* kinds, co
     VPN_LAUNCH_CHECK();
     return 0;
 }
+
+// losses[2] = w_extra * mean(loss_b) + w_sil * losses[0] + w_dep * losses[1]  (weighted sum of train.py:243-262)
+__global__ void total_loss_kernel(const float* __restrict__ loss_b, int nb, float w_extra, float w_sil, float w_dep,
+                                  float* __restrict__ losses) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float e = 0.f;
+        for (int i = 0; i < nb; ++i) e += loss_b[i];
+        losses[2] = w_extra * (e / (float)nb) + w_sil * losses[0] + w_dep * losses[1];
+    }
+}
+
+extern "C" int vpn_total_loss(const float* loss_b, int nb, float w_extra, float w_sil, float w_dep, float* losses,
+                              void* stream) {
+    if (!loss_b || !losses || nb <= 0) return VPN_E_BADARG;
+    VPN_LAUNCH(total_loss_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, loss_b, nb, w_extra, w_sil, w_dep, losses);
+    VPN_LAUNCH_CHECK();
+    return 0;
+}

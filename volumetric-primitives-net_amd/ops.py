@@ -238,6 +238,17 @@ class RasterLossFunction(Function):
 
 
 _PATTERNS = {}
+_SIDE = {}
+# optionally run the raster branch of HotPathLossFunction on a second HIP stream (VPN_CONCURRENT=1)
+CONCURRENT_BRANCHES = os.environ.get('VPN_CONCURRENT', '0') == '1'   # measured: no gain at C3 (each kernel already fills the GPU)
+
+
+def _side_stream(dev):
+    key = str(dev)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=dev)
+    return _SIDE[key]
+
 
 
 def _grad_pattern(B, w_cd, w_sil, w_depth, dev):
@@ -269,6 +280,21 @@ class HotPathLossFunction(Function):
         s = _lib.stream()
         gt_sil = _f32c(gt_sil).reshape(B, H, W) if gt_sil is not None else None
         gt_depth = _f32c(gt_depth).reshape(B, H, W) if gt_depth is not None else None
+        # The raster branch (VALU-bound) is independent of the sampler + Chamfer branch (matrix-pipe filter) until
+        # the total: it runs on a side stream so the two overlap (fork / join is captured into HIP graphs as such).
+        aux = torch.empty((B, 3, H, W), dtype=torch.float32, device=dev)
+        rec = torch.empty((L.vpn_raster_records_size(B, K) // 4,), dtype=torch.float32, device=dev)
+        lws = torch.empty((L.vpn_raster_loss_workspace(B, H, W) // 4,), dtype=torch.float32, device=dev)
+        losses = torch.empty((3,), dtype=torch.float32, device=dev)
+        main = torch.cuda.current_stream()
+        side = _side_stream(dev) if CONCURRENT_BRANCHES else None
+        if side is not None:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                _lib.call('vpn_raster_loss_fwd', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(cam), B, K, H, W,
+                          float(sigma), float(gamma), float(z_far), _lib.ptr(gt_sil), _lib.ptr(gt_depth), 0,
+                          _lib.ptr(aux), _lib.ptr(rec), _lib.ptr(lws), _lib.ptr(losses), None, 0, 0.0, 0.0, 0.0,
+                          _lib.stream())
         points = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
         _lib.call('vpn_sample_fwd', _lib.ptr(params), _lib.ptr(kinds), None, int(seed), int(sample_base), B, K, n,
                   _lib.ptr(points), s)
@@ -281,13 +307,15 @@ class HotPathLossFunction(Function):
                   _lib.ptr(d2), _lib.ptr(i2), _lib.ptr(cws), 0, s)
         loss_b = torch.empty((B,), dtype=torch.float32, device=dev)
         _lib.call('vpn_chamfer_loss', _lib.ptr(d1), _lib.ptr(d2), B, N, M, 1.0, 1.0, _lib.ptr(loss_b), s)
-        aux = torch.empty((B, 3, H, W), dtype=torch.float32, device=dev)
-        rec = torch.empty((L.vpn_raster_records_size(B, K) // 4,), dtype=torch.float32, device=dev)
-        lws = torch.empty((L.vpn_raster_loss_workspace(B, H, W) // 4,), dtype=torch.float32, device=dev)
-        losses = torch.empty((3,), dtype=torch.float32, device=dev)
-        _lib.call('vpn_raster_loss_fwd', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(cam), B, K, H, W, float(sigma),
-                  float(gamma), float(z_far), _lib.ptr(gt_sil), _lib.ptr(gt_depth), 0, _lib.ptr(aux), _lib.ptr(rec),
-                  _lib.ptr(lws), _lib.ptr(losses), _lib.ptr(loss_b), B, float(w_cd), float(w_sil), float(w_depth), s)
+        if side is not None:
+            main.wait_stream(side)
+            _lib.call('vpn_total_loss', _lib.ptr(loss_b), B, float(w_cd), float(w_sil), float(w_depth),
+                      _lib.ptr(losses), s)
+        else:
+            _lib.call('vpn_raster_loss_fwd', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(cam), B, K, H, W,
+                      float(sigma), float(gamma), float(z_far), _lib.ptr(gt_sil), _lib.ptr(gt_depth), 0, _lib.ptr(aux),
+                      _lib.ptr(rec), _lib.ptr(lws), _lib.ptr(losses), _lib.ptr(loss_b), B, float(w_cd), float(w_sil),
+                      float(w_depth), s)
         pattern = _grad_pattern(B, w_cd, w_sil, w_depth, dev)
         empty = torch.empty(0, device=dev)
         ctx.save_for_backward(params, kinds, cam, gt_points, points, d1, i1, d2, i2, aux, rec,
@@ -305,17 +333,32 @@ class HotPathLossFunction(Function):
         s = _lib.stream()
         # only the total (index 2) is meant to be differentiated
         gvec = (pattern * grad_losses[2]).contiguous()          # one small kernel: [B] for Chamfer, [2] for the raster
+        g2 = ctypes.c_void_p(gvec.data_ptr() + 4 * B)           # the last two entries: (sil, depth) gradients
+        ws = torch.empty((_lib.lib().vpn_raster_bwd_workspace(B, K, H, W) // 4,), dtype=torch.float32,
+                         device=params.device)
+        main = torch.cuda.current_stream()
+        side = _side_stream(params.device) if CONCURRENT_BRANCHES else None
+        grad_raster = None
+        if side is not None:
+            grad_raster = torch.empty_like(params)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                _lib.call('vpn_raster_loss_bwd', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(cam), B, K, H, W, sigma,
+                          gamma, z_far, _lib.ptr(aux), _lib.ptr(rec), _lib.ptr(gt_sil) if has_sil else None,
+                          _lib.ptr(gt_depth) if has_depth else None, 0, g2, _lib.ptr(ws), _lib.ptr(grad_raster), 0,
+                          _lib.stream())
         grad_points = torch.empty_like(points)
         _lib.call('vpn_chamfer_bwd', _lib.ptr(points), _lib.ptr(gt_points), _lib.ptr(d1), _lib.ptr(i1), _lib.ptr(d2),
                   _lib.ptr(i2), _lib.ptr(gvec), B, N, M, 1.0, 1.0, _lib.ptr(grad_points), None, s)
         grad_params = torch.empty_like(params)
         _lib.call('vpn_sample_bwd', _lib.ptr(params), _lib.ptr(kinds), None, seed, base, B, K, n, _lib.ptr(grad_points),
                   _lib.ptr(grad_params), s)
-        ws = torch.empty((_lib.lib().vpn_raster_bwd_workspace(B, K, H, W) // 4,), dtype=torch.float32,
-                         device=params.device)
-        g2 = ctypes.c_void_p(gvec.data_ptr() + 4 * B)           # the last two entries: (sil, depth) gradients
-        _lib.call('vpn_raster_loss_bwd', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(cam), B, K, H, W, sigma, gamma,
-                  z_far, _lib.ptr(aux), _lib.ptr(rec), _lib.ptr(gt_sil) if has_sil else None,
-                  _lib.ptr(gt_depth) if has_depth else None, 0, g2, _lib.ptr(ws), _lib.ptr(grad_params), 1, s)
+        if side is not None:
+            main.wait_stream(side)
+            grad_params += grad_raster
+        else:
+            _lib.call('vpn_raster_loss_bwd', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(cam), B, K, H, W, sigma,
+                      gamma, z_far, _lib.ptr(aux), _lib.ptr(rec), _lib.ptr(gt_sil) if has_sil else None,
+                      _lib.ptr(gt_depth) if has_depth else None, 0, g2, _lib.ptr(ws), _lib.ptr(grad_params), 1, s)
         return (grad_params,) + (None,) * 16
 
