@@ -165,7 +165,8 @@ def main():
     N = K * n
     nn_bytes = B * 16 * (N + M)                       # mean of the two directions: both clouds in, dist + idx out
     alg_bytes = {
-        'chamfer_nn_mfma_kernel': nn_bytes, 'chamfer_nn_kernel<R>': nn_bytes, 'chamfer_nn_pruned_kernel<1>': nn_bytes,
+        'chamfer_nn_mfma_kernel<1>': nn_bytes, 'chamfer_nn_mfma_kernel<0>': nn_bytes, 'chamfer_nn_kernel<R>': nn_bytes,
+        'chamfer_nn_pruned_kernel<1>': nn_bytes,
         'raster_fwd_kernel<0>': B * (40 * K + 8 * H * W), 'raster_fwd_kernel<1>': B * (40 * K + 8 * H * W),
         'raster_bwd_kernel<0>': B * (8 * H * W + 80 * K), 'raster_bwd_kernel<1>': B * (8 * H * W + 80 * K),
         'sample_fwd_kernel': B * (40 * K + 12 * N), 'sample_bwd_kernel': B * (12 * N + 80 * K),
@@ -175,14 +176,21 @@ def main():
     dom = max((k for k in kern if k in alg_bytes), key=lambda k: kern[k][0] * kern[k][1])
     dom_s = kern[dom][1] * 1e-3
     hbm_gbs = alg_bytes[dom] / dom_s / 1e9
-    if dom == 'chamfer_nn_mfma_kernel':               # the filter runs on the fp32 matrix pipe
+    if dom.startswith('chamfer_nn_mfma_kernel'):      # the exact scan with the matrix-pipe filter
         tf = pair_flops / dom_s / 1e12
+        bf16 = dom.endswith('<1>')
         roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': round(tf, 2), 'peak': VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': round(tf / VALU_PEAK_TFLOPS, 4), 'traffic': None,
                     'algorithmic_flops_per_launch': pair_flops, 'avg_launch_us': round(dom_s * 1e6, 2),
-                    'peak_note': 'dense fp32-input MFMA peak (v_mfma_f32_32x32x2_f32), MI355X_MICROARCH.md',
+                    'peak_note': 'algorithmic work = 8 fp32 flop per point pair, priced against the fp32 rate of MI355X '
+                                 '(157.3 TFLOP/s, vector = fp32-input MFMA; MI355X_MICROARCH.md)',
                     'hbm_view': {'algorithmic_bytes_per_launch': alg_bytes[dom], 'achieved_GBps': round(hbm_gbs, 2),
                                  'frac_of_8TBps': round(hbm_gbs / HBM_PEAK_GBS, 5)}}
+        if bf16:    # executed on the bf16 matrix pipe: 2 x v_mfma_f32_32x32x16_bf16 per 32x32 pairs = 64 flop per pair
+            ex = 64.0 * B * N * M / dom_s / 1e12
+            roofline['matrix_pipe'] = {'instruction': 'v_mfma_f32_32x32x16_bf16 (fp32 coordinates split exactly into 3 bf16 pieces)',
+                                       'executed_TFLOPs': round(ex, 1), 'dense_bf16_peak_TFLOPs': 2500.0,
+                                       'frac': round(ex / 2500.0, 4)}
     else:
         roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': round(hbm_gbs, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': round(hbm_gbs / HBM_PEAK_GBS, 5), 'traffic': None,

@@ -635,26 +635,74 @@ constexpr int CM_BLOCK = 256;            // 4 waves x 32 queries
 #define VPN_CM_TILE 512
 #endif
 constexpr int CM_TILE = VPN_CM_TILE;     // targets per LDS feature tile (16 B per target per buffer)
-constexpr float CM_EPS = 8.0f * 5.9604644775390625e-08f;   // 8 * 2^-24: bound on the relative rounding of t_ij
+constexpr float CM_EPS = 8.0f * 5.9604644775390625e-08f;   // 8 * 2^-24: bound on the relative rounding of t_ij (fp32 MFMA chain)
+// bf16 variant: 21 exact products accumulated in fp32 (<= 24 * 2^-24), dropped cross terms b2a3+b3a2+b3a3
+// (<= 4.2 * 2^-24 |a||b|), rounding of |b|^2 (3 * 2^-24): 32 * 2^-24 covers all of it
+constexpr float CM_EPS_BF16 = 32.0f * 5.9604644775390625e-08f;
+constexpr int CM_TILE16 = 256;           // targets per LDS tile of bf16 rows
+constexpr int CM_ROWB = 80;              // LDS row stride (64 B of data): ds_read_b128 of 16 consecutive rows hits 64 distinct banks
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef unsigned short us8 __attribute__((ext_vector_type(8)));
+
+// exact 3-way split of an fp32 into bf16 pieces (truncation): x == p0 + p1 + p2
+__device__ inline void split3_bf16(float x, unsigned short p[3]) {
+    const unsigned u0 = __float_as_uint(x);
+    p[0] = (unsigned short)(u0 >> 16);
+    const float r1 = x - __uint_as_float(u0 & 0xFFFF0000u);
+    const unsigned u1 = __float_as_uint(r1);
+    p[1] = (unsigned short)(u1 >> 16);
+    const float r2 = r1 - __uint_as_float(u1 & 0xFFFF0000u);
+    p[2] = (unsigned short)(__float_as_uint(r2) >> 16);
+}
 
 // feature planes F[b][4][Np] = (x, y, z, |p|^2) (padded with a never-winning sentinel), nmax[b] = max |p|^2.
 // One workgroup per sample (no atomics, no memset): lanes stride over the points.
+// H[b][Np][32] bf16 rows for the bf16 filter: per coordinate the target pieces (b1 b1 b2 b1 b3 b2) that pair
+// with the query pieces (a1 a2 a1 a3 a1 a2), then the three pieces of |p|^2 (paired with 1.0), then zeros.
 __global__ __launch_bounds__(1024) void chamfer_feat_kernel(const float* __restrict__ pts, int N, int Np,
-                                                            float* __restrict__ F, unsigned int* __restrict__ nmax) {
+                                                            float* __restrict__ F, unsigned int* __restrict__ nmax,
+                                                            unsigned short* __restrict__ H) {
     __shared__ float red[16];
     const int b = blockIdx.x;
     const float* pb = pts + (size_t)b * N * 3;
     float* f = F + (size_t)b * 4 * Np;
     float nv = 0.f;
-    for (int j = threadIdx.x; j < Np; j += 1024) {
+    // gridDim.y workgroups share a sample: each converts its slice; the max norm is cheap enough that
+    // workgroup 0 simply scans the whole cloud for it (no atomics, no zero-initialised output)
+    if (blockIdx.y == 0)
+        for (int j = threadIdx.x; j < N; j += 1024) {
+            const float x = pb[j * 3], y = pb[j * 3 + 1], z = pb[j * 3 + 2];
+            nv = fmaxf(nv, x * x + y * y + z * z);
+        }
+    const int per = ((Np + (int)gridDim.y - 1) / (int)gridDim.y + 63) & ~63;
+    const int j0 = blockIdx.y * per, j1 = min(Np, j0 + per);
+    for (int j = j0 + threadIdx.x; j < j1; j += 1024) {
         float x = 0.f, y = 0.f, z = 0.f, n = 3.0e38f;
         if (j < N) {
             x = pb[j * 3]; y = pb[j * 3 + 1]; z = pb[j * 3 + 2];
             n = x * x + y * y + z * z;
-            nv = fmaxf(nv, n);
         }
         f[j] = x; f[Np + j] = y; f[2 * Np + j] = z; f[3 * Np + j] = n;
+        if (H) {
+            unsigned short px[3], py[3], pz[3], pn[3], row[32];
+            split3_bf16(x, px); split3_bf16(y, py); split3_bf16(z, pz); split3_bf16(n, pn);
+            const int BI[6] = {0, 0, 1, 0, 2, 1};
+#pragma unroll
+            for (int t = 0; t < 6; ++t) { row[t] = px[BI[t]]; row[6 + t] = py[BI[t]]; row[12 + t] = pz[BI[t]]; }
+            row[18] = pn[0]; row[19] = pn[1]; row[20] = pn[2];
+#pragma unroll
+            for (int t = 21; t < 32; ++t) row[t] = 0;
+            uint4* dst = reinterpret_cast<uint4*>(H + ((size_t)b * Np + j) * 32);
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                uint4 v;
+                v.x = row[qd * 8 + 0] | ((unsigned)row[qd * 8 + 1] << 16); v.y = row[qd * 8 + 2] | ((unsigned)row[qd * 8 + 3] << 16);
+                v.z = row[qd * 8 + 4] | ((unsigned)row[qd * 8 + 5] << 16); v.w = row[qd * 8 + 6] | ((unsigned)row[qd * 8 + 7] << 16);
+                dst[qd] = v;
+            }
+        }
     }
+    if (blockIdx.y != 0) return;
     nv = wave_max_u(nv);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = nv;
     __syncthreads();
@@ -780,9 +828,11 @@ __device__ inline float min16(const f16v& v) {
     return __builtin_fminf(f, g);
 }
 
+template <int PREC>   // 0: fp32-input MFMA (shares the fp32 vector datapath), 1: bf16 3-piece split on the matrix pipe
 __global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_kernel(const float* __restrict__ qpts,
                                                                    const float* __restrict__ tpts,
                                                                    const float* __restrict__ F,
+                                                                   const unsigned short* __restrict__ H,
                                                                    const unsigned int* __restrict__ nmax, int Nq,
                                                                    int Nt, int Ntp, float* __restrict__ out_dist,
                                                                    int32_t* __restrict__ out_idx) {
@@ -801,10 +851,94 @@ __global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_kernel(const float* 
     // smallest / second / third smallest block minimum of this lane's half, with the blocks of the first two
     float best = __builtin_inff(), second = __builtin_inff(), third = __builtin_inff();
     int blk = 0, blk2 = 0;
+// branch-free selects (the compiler otherwise turns the index updates into exec-mask branches)
+#define CM_SEL(dst, cond_mask, a, b) asm volatile("v_cndmask_b32 %0, %1, %2, %3" : "=v"(dst) : "v"(b), "v"(a), "s"(cond_mask))
+#define CM_UPDATE(m, tb0)                                                                  \
+    {                                                                                          \
+        const int t_ = (tb0);                                                                  \
+        unsigned long long k1_, k2_;                                                           \
+        asm volatile("v_cmp_lt_f32 %0, %1, %2" : "=s"(k1_) : "v"(m), "v"(best));               \
+        asm volatile("v_cmp_lt_f32 %0, %1, %2" : "=s"(k2_) : "v"(m), "v"(second));             \
+        third = __builtin_amdgcn_fmed3f(second, third, (m));                                   \
+        second = __builtin_amdgcn_fmed3f(best, second, (m));                                   \
+        int sel_;                                                                              \
+        CM_SEL(sel_, k2_, t_, blk2);      /* c2 ? t : blk2 */                                  \
+        CM_SEL(blk2, k1_, blk, sel_);     /* c1 ? blk : sel */                                 \
+        CM_SEL(blk, k1_, t_, blk);        /* c1 ? t : blk */                                   \
+        best = __builtin_fminf(best, (m));                                                     \
+    }
+    const float* Fb = F + (size_t)b * 4 * Ntp;
+    const f16v zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if constexpr (PREC == 1) {
+        // ---- bf16 filter: 2 x v_mfma_f32_32x32x16_bf16 per 32x32 block, on the matrix pipe beside the VALU
+        __shared__ __attribute__((aligned(16))) unsigned char tileH[2][CM_TILE16 * CM_ROWB];
+        const unsigned char* Hb = reinterpret_cast<const unsigned char*>(H) + (size_t)b * Ntp * 64;
+        bf8 bqA, bqB;                                // this lane's query: K slots [8 half, 8 half + 8) of the two MFMAs
+        {
+            unsigned short qx[3], qy[3], qz[3], qs[32];
+            split3_bf16(-2.0f * ax, qx); split3_bf16(-2.0f * ay, qy); split3_bf16(-2.0f * az, qz);
+            const int AI[6] = {0, 1, 0, 2, 0, 1};
+#pragma unroll
+            for (int t = 0; t < 6; ++t) { qs[t] = qx[AI[t]]; qs[6 + t] = qy[AI[t]]; qs[12 + t] = qz[AI[t]]; }
+            qs[18] = 0x3F80; qs[19] = 0x3F80; qs[20] = 0x3F80;           // bf16 1.0 for the three |b|^2 pieces
+#pragma unroll
+            for (int t = 21; t < 32; ++t) qs[t] = 0;
+            us8 ua, ub;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { ua[e] = half ? qs[8 + e] : qs[e]; ub[e] = half ? qs[24 + e] : qs[16 + e]; }
+            bqA = __builtin_bit_cast(bf8, ua); bqB = __builtin_bit_cast(bf8, ub);
+        }
+        constexpr int F4 = CM_TILE16 * 4 / CM_BLOCK;                    // float4 per lane per tile (rows are 4 float4)
+        auto fetch = [&](int t0, float4 v[F4]) {
+#pragma unroll
+            for (int u = 0; u < F4; ++u) {
+                const int i = threadIdx.x + u * CM_BLOCK, row = i >> 2, qd = i & 3;
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (t0 + row < Ntp) v[u] = *reinterpret_cast<const float4*>(Hb + (size_t)(t0 + row) * 64 + qd * 16);
+            }
+        };
+        auto stash = [&](int buf, const float4 v[F4]) {
+#pragma unroll
+            for (int u = 0; u < F4; ++u) {
+                const int i = threadIdx.x + u * CM_BLOCK, row = i >> 2, qd = i & 3;
+                *reinterpret_cast<float4*>(&tileH[buf][row * CM_ROWB + qd * 16]) = v[u];
+            }
+        };
+        float4 pre[F4];
+        fetch(0, pre);
+        stash(0, pre);
+        __syncthreads();
+        int buf = 0;
+        for (int t0 = 0; t0 < Ntp; t0 += CM_TILE16, buf ^= 1) {
+            const bool more = t0 + CM_TILE16 < Ntp;
+            if (more) fetch(t0 + CM_TILE16, pre);      // in flight during the MFMA loop, stored to LDS after it
+            const int nblk = min(CM_TILE16, Ntp - t0) >> 5;
+            const unsigned char* T = &tileH[buf][jq * CM_ROWB + half * 16];
+            float4 o0 = *reinterpret_cast<const float4*>(T), o1 = *reinterpret_cast<const float4*>(T + 32);
+            float4 o2 = *reinterpret_cast<const float4*>(T + 32 * CM_ROWB), o3 = *reinterpret_cast<const float4*>(T + 32 * CM_ROWB + 32);
+            for (int u = 0; u < nblk; u += 2) {        // nblk is even (Ntp is a multiple of 64)
+                const float4 c0 = o0, c1 = o1, c2 = o2, c3 = o3;
+                if (u + 2 < nblk) {
+                    const unsigned char* Tn = T + (u + 2) * 32 * CM_ROWB;
+                    o0 = *reinterpret_cast<const float4*>(Tn); o1 = *reinterpret_cast<const float4*>(Tn + 32);
+                    o2 = *reinterpret_cast<const float4*>(Tn + 32 * CM_ROWB); o3 = *reinterpret_cast<const float4*>(Tn + 32 * CM_ROWB + 32);
+                }
+                f16v accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, c0), bqA, zero, 0, 0, 0);
+                f16v accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, c2), bqA, zero, 0, 0, 0);
+                accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, c1), bqB, accA, 0, 0, 0);
+                accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, c3), bqB, accB, 0, 0, 0);
+                const float mA = min16(accA);
+                CM_UPDATE(mA, t0 + u * 32)
+                const float mB = min16(accB);
+                CM_UPDATE(mB, t0 + u * 32 + 32)
+            }
+            if (more) stash(buf ^ 1, pre);
+            __syncthreads();
+        }
+    } else {
     // The 4 waves of the workgroup scan the same targets: feature tiles of CM_TILE targets go through LDS
     // (double buffered: the next tile's loads are in flight while this one feeds the matrix pipe).
     __shared__ __attribute__((aligned(16))) float tileF[2][4][CM_TILE];
-    const float* Fb = F + (size_t)b * 4 * Ntp;
     // each lane moves 2 float4 per tile (4 planes x CM_TILE floats = 512 float4, 256 lanes)
     constexpr int CM_F4 = CM_TILE / CM_BLOCK;       // float4 per lane per tile
     auto fetch = [&](int t0, float4 v[CM_F4]) {
@@ -835,23 +969,6 @@ __global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_kernel(const float* 
         const int nblk = min(CM_TILE, Ntp - t0) >> 5;
         const float* T0 = &tileF[buf][half][jq];
         const float* T1 = &tileF[buf][2 + half][jq];
-// branch-free selects (the compiler otherwise turns the index updates into exec-mask branches)
-#define CM_SEL(dst, cond_mask, a, b) asm volatile("v_cndmask_b32 %0, %1, %2, %3" : "=v"(dst) : "v"(b), "v"(a), "s"(cond_mask))
-#define CM_UPDATE(m, tb0)                                                                  \
-    {                                                                                          \
-        const int t_ = (tb0);                                                                  \
-        unsigned long long k1_, k2_;                                                           \
-        asm volatile("v_cmp_lt_f32 %0, %1, %2" : "=s"(k1_) : "v"(m), "v"(best));               \
-        asm volatile("v_cmp_lt_f32 %0, %1, %2" : "=s"(k2_) : "v"(m), "v"(second));             \
-        third = __builtin_amdgcn_fmed3f(second, third, (m));                                   \
-        second = __builtin_amdgcn_fmed3f(best, second, (m));                                   \
-        int sel_;                                                                              \
-        CM_SEL(sel_, k2_, t_, blk2);      /* c2 ? t : blk2 */                                  \
-        CM_SEL(blk2, k1_, blk, sel_);     /* c1 ? blk : sel */                                 \
-        CM_SEL(blk, k1_, t_, blk);        /* c1 ? t : blk */                                   \
-        best = __builtin_fminf(best, (m));                                                     \
-    }
-        const f16v zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         // operands of the next pair of blocks are read from LDS while the current MFMAs run
         float o0 = T0[0], o1 = T1[0], o2 = T0[32], o3 = T1[32];
         for (int u = 0; u < nblk; u += 2) {         // nblk is even (tiles are multiples of 64 targets)
@@ -880,6 +997,7 @@ __global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_kernel(const float* 
         }
         if (more) stash(buf ^ 1, pre);
         __syncthreads();                            // everybody done with `buf`, next tile landed
+    }
     }
     // merge the two half-waves that share a query (they saw disjoint halves of every block): the two best
     // DISTINCT blocks K, K2 and a lower bound T for the minimum of every other block
@@ -929,7 +1047,7 @@ __global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_kernel(const float* 
     m2 = fminf(m2, __shfl_xor(m2, 32, 64));
     // t = d2 - |a|^2 within E; exact d2 within 4e-7 relative: outside `band` nothing can win or tie
     const float na = ax * ax + ay * ay + az * az, nb = __uint_as_float(nmax[b]);
-    const float E = CM_EPS * (2.0f * sqrtf(na * nb) + nb + na);
+    const float E = (PREC == 1 ? CM_EPS_BF16 : CM_EPS) * (2.0f * sqrtf(na * nb) + nb + na);
     const float band = 2.0f * E + 4.0e-6f * m2;
     const bool need2 = !(V2 > Bv + band);
     const bool ambiguous = !(T > Bv + band);
@@ -980,18 +1098,26 @@ __global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_kernel(const float* 
 }
 
 static inline int pad32(int n) { return (n + 63) & ~63; }   // feature planes padded to 64 targets (blocks are processed in pairs)
-static inline size_t mfma_ws_floats(int B, int N) { return (size_t)B * 4 * pad32(N) + (size_t)B; }
+static inline size_t mfma_ws_floats(int B, int N) { return (size_t)B * (4 + 16) * pad32(N) + (size_t)B; }   // fp32 planes + bf16 rows + nmax
 
 // one direction: features of the targets -> filtered scan of the queries
 static int mfma_nn(const float* q, const float* t, int B, int Nq, int Nt, float* F, float* d, int32_t* idx,
                    hipStream_t s) {
     const int Ntp = pad32(Nt);
-    unsigned int* nmax = reinterpret_cast<unsigned int*>(F + (size_t)B * 4 * Ntp);
-    VPN_LAUNCH(chamfer_feat_kernel, dim3(B), dim3(1024), 0, s, t, Nt, Ntp, F, nmax);
+    unsigned short* Hrows = reinterpret_cast<unsigned short*>(F + (size_t)B * 4 * Ntp);     // [B][Ntp][32] bf16
+    unsigned int* nmax = reinterpret_cast<unsigned int*>(F + (size_t)B * 20 * Ntp);
+    static int fp32_filter = -1;
+    if (fp32_filter < 0) { const char* ev = getenv("VPN_CHAMFER_FP32_MFMA"); fp32_filter = (ev && ev[0] == '1') ? 1 : 0; }
+    VPN_LAUNCH(chamfer_feat_kernel, dim3(B, Ntp >= 4096 ? 4 : (Ntp >= 1024 ? 2 : 1)), dim3(1024), 0, s, t, Nt, Ntp, F, nmax,
+               fp32_filter ? nullptr : Hrows);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    VPN_LAUNCH(chamfer_nn_mfma_kernel, dim3((Nq + 127) / 128, B), dim3(CM_BLOCK), 0, s, q, t, F, nmax, Nq, Nt,
-                       Ntp, d, idx);
+    if (fp32_filter)
+        VPN_LAUNCH(chamfer_nn_mfma_kernel<0>, dim3((Nq + 127) / 128, B), dim3(CM_BLOCK), 0, s, q, t, F, Hrows, nmax, Nq,
+                   Nt, Ntp, d, idx);
+    else
+        VPN_LAUNCH(chamfer_nn_mfma_kernel<1>, dim3((Nq + 127) / 128, B), dim3(CM_BLOCK), 0, s, q, t, F, Hrows, nmax, Nq,
+                   Nt, Ntp, d, idx);
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     VPN_LAUNCH(chamfer_fixup_kernel, dim3((Nq + CF_THREADS - 1) / CF_THREADS, B), dim3(CF_THREADS), 0, s, q, t,
