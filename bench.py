@@ -48,6 +48,8 @@ def main():
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='launch every step eagerly instead of replaying a HIP graph')
+    ap.add_argument('--dist-selftest', action='store_true',
+                    help='run the multi-rank code path (RCCL group, gradient all-reduce) even with one rank')
     ap.add_argument('--cpu-sample', type=int, default=32, help='images in the CPU baseline sample')
     args = ap.parse_args()
 
@@ -62,8 +64,10 @@ def main():
         args.gpus = world
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    multi = world > 1 or args.dist_selftest
+    if multi:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     import vpn_amd
@@ -87,7 +91,7 @@ def main():
                                               vpn_amd.config.RASTER_Z_FAR)
     gt_sil = (a2 > 0.5).float()
     gt_depth = d2.clone()
-    reducer = GradAllReduce(B * world, K, dev, rank, world) if world > 1 else None
+    reducer = GradAllReduce(B * world, K, dev, rank, world) if multi else None
     cd_fn = vpn_amd.ChamferDistanceLoss()
     sigma, gamma, z_far = vpn_amd.config.RASTER_SIGMA, vpn_amd.config.RASTER_GAMMA, vpn_amd.config.RASTER_Z_FAR
 
@@ -107,7 +111,7 @@ def main():
         return params.grad, loss
 
     def sync():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -143,7 +147,7 @@ def main():
         run_step(args.warmup + i)
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         tmax = torch.tensor([dt], device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
@@ -223,13 +227,13 @@ def main():
             'config': {'workload': 'C3: B=%d/GPU, K=%d sphere primitives, %dx%d silhouette+depth, n=%d pts/prim '
                                    '(N=%d) vs M=%d GT points, Chamfer+L1 fwd+bwd' % (B, K, H, W, n, N, M),
                        'global_batch': B * world, 'parallelism': 'dp%d' % world,
-                       'collective': 'rccl all-reduce %d B/step' % ((B * world * K * 10 + 1) * 4) if world > 1 else 'none'},
+                       'collective': 'rccl all-reduce %d B/step' % ((B * world * K * 10 + 1) * 4) if multi else 'none'},
             'roofline': roofline, 'kernel_us': kernel_us, 'entry_us': entry_us,
         }
         if cpu is not None:
             out['cpu_baseline'] = cpu
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

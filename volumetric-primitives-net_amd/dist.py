@@ -33,6 +33,6 @@ class GradAllReduce:
         self.buf.zero_()
         self.grad[self.lo:self.hi].copy_(local_grad)
         self.buf[-1] = local_loss.detach() / self.world
-        if self.world > 1:
+        if self.world > 1 or dist.is_initialized():
             dist.all_reduce(self.buf, op=dist.ReduceOp.SUM)
         return self.grad, self.buf[-1]
