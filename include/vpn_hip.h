@@ -38,7 +38,6 @@ extern "C" {
 /* negative return codes */
 #define VPN_E_BADARG  (-1)   /* null pointer / non-positive size              */
 #define VPN_E_TOOBIG  (-2)   /* size above a documented limit                 */
-#define VPN_E_KIND    (-3)   /* unknown primitive kind (e.g. cone: sampling.py:39-45 is `pass`) */
 
 /* packed primitive parameters: [B, K, 10] = (v0 v1 v2 | q0 q1 q2 q3 | t0 t1 t2)
  * — the reference passes K separate (B,3),(B,4),(B,3) tensors (train.py:117).  */
@@ -105,9 +104,10 @@ int vpn_chamfer_nn(const float* queries, const float* targets, int B, int Nq, in
  * scan strategy is selectable and every strategy returns the same bits as vpn_chamfer_fwd:
  *   mode 1  brute force (workspace unused, may be NULL);
  *   mode 2  box-pruned: clouds Morton-sorted per call, target chunks farther than the current best skipped;
- *   mode 3  MFMA-filtered: the fp32 matrix pipe evaluates |b|^2 - 2a.b for 32x32 pairs, the candidates are
- *           re-evaluated with the exact separately-rounded d2 (a rigorous error band decides when a full
- *           exact rescan of a query is needed);
+ *   mode 3  matrix-pipe filter: bf16 MFMA (fp32 coordinates split exactly into three bf16 pieces) evaluates
+ *           |b|^2 - 2a.b for 32x32 pairs, the candidates are re-evaluated with the exact separately-rounded
+ *           d2 (a rigorous error band decides when a second block or a full exact rescan is needed);
+ *   mode 4  the same filter with fp32-input MFMA;
  *   mode 0  automatic (mode 3 for large clouds when a workspace is given, else mode 1). */
 size_t vpn_chamfer_workspace(int B, int N, int M);
 int vpn_chamfer_fwd_ws(const float* p1, const float* p2, int B, int N, int M,

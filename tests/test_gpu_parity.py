@@ -158,7 +158,7 @@ def _chamfer_exact(vpn, p1, p2, torch_sqrt_too=True):
     CPU sqrt (MKL VML, <= 1 ulp, see vpn_oracle.chamfer_nn_ieee) indices must still agree and
     distances agree to 1 ulp."""
     m1, j1, m2, j2 = O.chamfer_nn_ieee(p1, p2)
-    for mode in ('brute', 'pruned', 'mfma'):   # every scan strategy must give the same bits
+    for mode in ('brute', 'pruned', 'mfma', 'mfma32'):   # every scan strategy must give the same bits
         d1, i1, d2, i2 = vpn.chamfer_nn(g(p1), g(p2), mode=mode)
         assert torch.equal(i1.cpu().long(), j1), 'argmin direction 1 differs (%s)' % mode
         assert torch.equal(i2.cpu().long(), j2), 'argmin direction 2 differs (%s)' % mode
@@ -172,7 +172,7 @@ def _chamfer_exact(vpn, p1, p2, torch_sqrt_too=True):
 @pytest.mark.parametrize('name', ['g4_chamfer_b4_n128_m96', 'g4_chamfer_b2_n257_m2048', 'g4_chamfer_ties'])
 def test_chamfer_golden(vpn, name):
     gd = load_golden(name)
-    for mode in ('brute', 'pruned', 'mfma'):
+    for mode in ('brute', 'pruned', 'mfma', 'mfma32'):
         d1, i1, d2, i2 = vpn.chamfer_nn(g(gd['p1']), g(gd['p2']), mode=mode)
         assert torch.equal(i1.cpu(), gd['idx1']) and torch.equal(i2.cpu(), gd['idx2'])
     assert torch.equal(i1.cpu(), gd['idx1']) and torch.equal(i2.cpu(), gd['idx2'])

@@ -15,13 +15,13 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libvpn_hip.so')
 SOURCES = ['vpn_api.hip', 'sampler.hip', 'chamfer.hip', 'raster.hip']
 COMMON = ['-O3', '--offload-arch=gfx950', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function']
-COMMON += os.environ.get('VPN_EXTRA_FLAGS', '').split()      # experiments only (e.g. -DVPN_CHAMFER_NO_RESCAN)
+COMMON += os.environ.get('VPN_EXTRA_FLAGS', '').split()      # experiments only (e.g. -DVPN_CHAMFER_DEBUG)
 PER_FILE = {
     # index-exact argmin: correctly rounded sqrt (hipcc default) and no contraction (also a pragma in the file)
     # -amdgpu-mfma-vgpr-form: MFMA results straight into VGPRs (no v_accvgpr_read copies before the min-tree)
     'chamfer.hip': ['-ffp-contract=off', '-mllvm', '-amdgpu-mfma-vgpr-form'],
     # the raster is compared with a 1e-4 tolerance: 1-ulp v_rcp/v_sqrt instead of the IEEE sequences
-    'raster.hip': [] if os.environ.get('VPN_RASTER_IEEE') else ['-fno-hip-fp32-correctly-rounded-divide-sqrt'],
+    'raster.hip': ['-fno-hip-fp32-correctly-rounded-divide-sqrt'],
 }
 
 

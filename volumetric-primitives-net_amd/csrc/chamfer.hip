@@ -18,6 +18,7 @@
 //   minimum the wave re-scans the earlier targets with the sqrt compare.
 #include "vpn_common.h"
 #include <stdlib.h>
+#include <string.h>
 
 #pragma clang fp contract(off)
 
@@ -157,7 +158,6 @@ __global__ __launch_bounds__(CH_BLOCK) void chamfer_nn_kernel(const float* __res
             const float d2 = dist2_exact(ax[r], ay[r], az[r], tb[j * 3], tb[j * 3 + 1], tb[j * 3 + 2]);
             if (g + e < Nt && sqrtf(d2) == s) idx = g + e;
         }
-#ifndef VPN_CHAMFER_NO_RESCAN
         // Rare (about one query in 1e5..1e6): a target of an EARLIER group has a larger d2 that
         // rounds to the same sqrt, so it wins the reference's tie rule.  gprev = min d2 over all
         // earlier groups; the whole wave re-scans them for that one query, 64 per step, and
@@ -182,7 +182,6 @@ __global__ __launch_bounds__(CH_BLOCK) void chamfer_nn_kernel(const float* __res
             if (lane == src) { atomicAdd(&g_dbg[0], 1ull); atomicAdd(&g_dbg[3], (unsigned long long)lim); }
 #endif
         }
-#endif
         if (qi < Nq) {
             out_dist[(size_t)b * Nq + qi] = s;
             out_idx[(size_t)b * Nq + qi] = idx;
@@ -631,10 +630,7 @@ __global__ __launch_bounds__(64) void chamfer_nn_pruned_kernel(
 // =====================================================================================
 typedef float f16v __attribute__((ext_vector_type(16)));
 constexpr int CM_BLOCK = 256;            // 4 waves x 32 queries
-#ifndef VPN_CM_TILE
-#define VPN_CM_TILE 512
-#endif
-constexpr int CM_TILE = VPN_CM_TILE;     // targets per LDS feature tile (16 B per target per buffer)
+constexpr int CM_TILE = 512;             // targets per LDS feature tile of the fp32 filter (16 B per target per buffer)
 constexpr float CM_EPS = 8.0f * 5.9604644775390625e-08f;   // 8 * 2^-24: bound on the relative rounding of t_ij (fp32 MFMA chain)
 // bf16 variant: 21 exact products accumulated in fp32 (<= 24 * 2^-24), dropped cross terms b2a3+b3a2+b3a3
 // (<= 4.2 * 2^-24 |a||b|), rounding of |b|^2 (3 * 2^-24): 32 * 2^-24 covers all of it
@@ -711,42 +707,6 @@ __global__ __launch_bounds__(1024) void chamfer_feat_kernel(const float* __restr
         for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w]);
         nmax[b] = __float_as_uint(m);
     }
-}
-
-// whole wave, one query: exact (min sqrt distance, lowest index attaining it) over all Nt targets.
-// 256 targets per step (4 coalesced loads in flight per lane); second pass applies the sqrt tie rule.
-__device__ inline void exact_scan_query(float qx, float qy, float qz, const float* __restrict__ tb, int Nt,
-                                        float& dist, int& idx) {
-    const int lane = threadIdx.x & 63;
-    float m = __builtin_inff();
-    for (int base = 0; base < Nt; base += 256) {
-        float x[4], y[4], z[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = min(base + u * 64 + lane, Nt - 1);
-            x[u] = tb[j * 3]; y[u] = tb[j * 3 + 1]; z[u] = tb[j * 3 + 2];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) m = fminf(m, dist2_exact(qx, qy, qz, x[u], y[u], z[u]));
-    }
-    const float s = sqrtf(wave_min_u(m));
-    int loc = 0x7fffffff;
-    for (int base = 0; base < Nt; base += 256) {
-        float x[4], y[4], z[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = min(base + u * 64 + lane, Nt - 1);
-            x[u] = tb[j * 3]; y[u] = tb[j * 3 + 1]; z[u] = tb[j * 3 + 2];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = base + u * 64 + lane;
-            if (j < Nt && sqrtf(dist2_exact(qx, qy, qz, x[u], y[u], z[u])) == s) loc = min(loc, j);
-        }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) loc = min(loc, __shfl_xor(loc, o, 64));
-    dist = s; idx = loc;
 }
 
 // Queries the filter could not decide (idx == -1: three or more 32-target blocks within the error band,
@@ -839,7 +799,6 @@ __global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_kernel(const float* 
     const int b = blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, jq = lane & 31, half = lane >> 5;
     const float* qb = qpts + (size_t)b * Nq * 3;
-    const float* tb = tpts + (size_t)b * Nt * 3;
     const int qi = (blockIdx.x * 4 + wave) * 32 + jq;
     const int qc = min(qi, Nq - 1);
     const float ax = qb[qc * 3], ay = qb[qc * 3 + 1], az = qb[qc * 3 + 2];
@@ -974,26 +933,14 @@ __global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_kernel(const float* 
         for (int u = 0; u < nblk; u += 2) {         // nblk is even (tiles are multiples of 64 targets)
             const float c0 = o0, c1 = o1, c2 = o2, c3 = o3;
             if (u + 2 < nblk) { o0 = T0[u * 32 + 64]; o1 = T1[u * 32 + 64]; o2 = T0[u * 32 + 96]; o3 = T1[u * 32 + 96]; }
-#if defined(VPN_ABL_NO_MFMA)
-            f16v accA = zero, accB = zero;
-            accA[0] = c0 * bq0 + c1 * bq1; accB[3] = c2 * bq0 + c3 * bq1;
-            asm volatile("" : "+v"(accA), "+v"(accB));
-#else
             f16v accA = __builtin_amdgcn_mfma_f32_32x32x2f32(c0, bq0, zero, 0, 0, 0);   // two independent accumulators:
             f16v accB = __builtin_amdgcn_mfma_f32_32x32x2f32(c2, bq0, zero, 0, 0, 0);   // the min-tree of one block
             accA = __builtin_amdgcn_mfma_f32_32x32x2f32(c1, bq1, accA, 0, 0, 0);         // overlaps the MFMAs of the other
             accB = __builtin_amdgcn_mfma_f32_32x32x2f32(c3, bq1, accB, 0, 0, 0);
-#endif
-#if defined(VPN_ABL_NO_VALU)
-            asm volatile("" :: "v"(accA), "v"(accB));
-            const float mA = accA[0], mB = accB[0];
-            best = fminf(best, fminf(mA, mB)); blk = t0 + u * 32;
-#else
             const float mA = min16(accA);           // this lane: query jq, 16 of the block's 32 targets
             CM_UPDATE(mA, t0 + u * 32)
             const float mB = min16(accB);
             CM_UPDATE(mB, t0 + u * 32 + 32)
-#endif
         }
         if (more) stash(buf ^ 1, pre);
         __syncthreads();                            // everybody done with `buf`, next tile landed
@@ -1102,12 +1049,10 @@ static inline size_t mfma_ws_floats(int B, int N) { return (size_t)B * (4 + 16) 
 
 // one direction: features of the targets -> filtered scan of the queries
 static int mfma_nn(const float* q, const float* t, int B, int Nq, int Nt, float* F, float* d, int32_t* idx,
-                   hipStream_t s) {
+                   bool fp32_filter, hipStream_t s) {
     const int Ntp = pad32(Nt);
     unsigned short* Hrows = reinterpret_cast<unsigned short*>(F + (size_t)B * 4 * Ntp);     // [B][Ntp][32] bf16
     unsigned int* nmax = reinterpret_cast<unsigned int*>(F + (size_t)B * 20 * Ntp);
-    static int fp32_filter = -1;
-    if (fp32_filter < 0) { const char* ev = getenv("VPN_CHAMFER_FP32_MFMA"); fp32_filter = (ev && ev[0] == '1') ? 1 : 0; }
     VPN_LAUNCH(chamfer_feat_kernel, dim3(B, Ntp >= 4096 ? 4 : (Ntp >= 1024 ? 2 : 1)), dim3(1024), 0, s, t, Nt, Ntp, F, nmax,
                fp32_filter ? nullptr : Hrows);
     hipError_t e = hipGetLastError();
@@ -1148,12 +1093,13 @@ static int pruned_nn(const CloudWs& q, const CloudWs& t, int B, int Nq, int Nt, 
     return e == hipSuccess ? 0 : (int)e;
 }
 
-// 0: automatic, 1: brute force, 2: pruned, 3: mfma-filtered   (VPN_CHAMFER_MODE=brute|pruned|mfma, tuning / tests)
+// 0: automatic, 1: brute force, 2: box-pruned, 3: bf16 matrix-pipe filter, 4: fp32-MFMA filter
+// (VPN_CHAMFER_MODE=brute|pruned|mfma|mfma32 overrides the automatic choice)
 static int chamfer_mode() {
     static int mode = -1;
     if (mode < 0) {
         const char* e = getenv("VPN_CHAMFER_MODE");
-        mode = !e ? 0 : (e[0] == 'b' ? 1 : (e[0] == 'p' ? 2 : (e[0] == 'm' ? 3 : 0)));
+        mode = !e ? 0 : (e[0] == 'b' ? 1 : (e[0] == 'p' ? 2 : (e[0] == 'm' ? (strstr(e, "32") ? 4 : 3) : 0)));
     }
     return mode;
 }
@@ -1235,7 +1181,8 @@ extern "C" size_t vpn_chamfer_workspace(int B, int N, int M) {
 }
 
 // Both directions with a caller-provided workspace: clouds are Morton-sorted once and both scans are
-// pruned.  mode: 0 automatic, 1 brute force, 2 box-pruned, 3 MFMA-filtered (all bit-identical).
+// pruned.  mode: 0 automatic, 1 brute force, 2 box-pruned, 3 bf16 matrix-pipe filter, 4 fp32-MFMA filter
+// (all bit-identical).
 extern "C" int vpn_chamfer_fwd_ws(const float* p1, const float* p2, int B, int N, int M, float* dist1, int32_t* idx1,
                                   float* dist2, int32_t* idx2, void* workspace, int mode, void* stream) {
     if (!p1 || !p2 || !dist1 || !idx1 || !dist2 || !idx2) return VPN_E_BADARG;
@@ -1251,12 +1198,12 @@ extern "C" int vpn_chamfer_fwd_ws(const float* p1, const float* p2, int B, int N
         if (rc) return rc;
         return nn_dispatch(p2, p1, B, M, N, dist2, idx2, s);
     }
-    if (mode == 3) {
+    if (mode == 3 || mode == 4) {
         float* F2 = (float*)workspace;                           // features of p2 (targets of direction 1)
         float* F1 = F2 + mfma_ws_floats(B, M);                   // features of p1 (targets of direction 2)
-        int rc = mfma_nn(p1, p2, B, N, M, F2, dist1, idx1, s);
+        int rc = mfma_nn(p1, p2, B, N, M, F2, dist1, idx1, mode == 4, s);
         if (rc) return rc;
-        return mfma_nn(p2, p1, B, M, N, F1, dist2, idx2, s);
+        return mfma_nn(p2, p1, B, M, N, F1, dist2, idx2, mode == 4, s);
     }
     float* cur = (float*)workspace;
     CloudWs w1 = carve(cur, B, N), w2 = carve(cur, B, M);

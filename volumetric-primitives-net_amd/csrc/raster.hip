@@ -9,32 +9,28 @@
 // specification is oracle/vpn_oracle.py::raster (parity unpinned w.r.t. kaolin).
 //
 // Work decomposition (CDNA4):
-//   * prep kernel: one lane per (image, primitive): pose from q, camera-space ray
-//     coefficients (o~, Mr, Mu, Mf) and a conservative pixel bounding box -> a 5 x float4
-//     record [B,K,5] in HBM (2.5 KB per image at K=32), reused by forward and backward;
-//   * raster kernels: ONE WAVEFRONT PER 16x16 PIXEL TILE (workgroup = 64 threads); the
-//     image's K records are staged into LDS with coalesced float4 loads; inside the
-//     per-primitive loop every LDS read is a wave-uniform broadcast.  Lane l owns column
-//     l&15 and rows (l>>4)+4s, s=0..3: four pixels per lane give ILP across the
-//     transcendental chains and let backward accumulate 4 pixels in registers before the
-//     cross-lane reduction;
-//   * culling: each lane tests one primitive's box against the tile and a 64-bit ballot
-//     drives the loop; the four 16x4 row groups are skipped individually (wave-uniform
-//     branch).  A primitive is skipped only where its coverage logit is below -X_CUT
-//     (coverage < 1.3e-14), so the result matches the dense specification to ~1e-6;
-//   * backward: the per-pixel gradients w.r.t. the 12 ray coefficients of a primitive are
-//     summed over the lane's pixels, reduced over the wave with a transposing butterfly (17
-//     shuffles for 12 values), parked in LDS and written once per tile as partials
-//     [B,tiles,K,12] with plain coalesced stores; a finishing kernel sums the partials in a
-//     fixed order and applies the chain rule to (v,q,t).  No atomics anywhere: the
-//     gradient is bitwise reproducible.
+//   * prep kernel: one lane per (image, primitive): pose from q, camera-space ray coefficients
+//     (o~, Mr, Mu, Mf), the exact culling conic of the primitive and its tight pixel box -> a
+//     7 x float4 record [B,K,7] in HBM (3.5 KB per image at K=32), reused by forward and backward;
+//   * raster kernels: ONE WAVEFRONT PER 16x16 PIXEL TILE (workgroup = 64 threads); the ray
+//     coefficients and pixel boxes of the image's K primitives are staged into LDS; inside the
+//     per-primitive loop every LDS read is a wave-uniform broadcast.  Lane l owns column l&15 and
+//     rows (l>>4)+4s, s=0..3: backward accumulates its 4 pixels in registers before the cross-lane
+//     reduction;
+//   * culling: each lane tests one primitive against the tile (pixel box, then exact
+//     conic-vs-rectangle) and a 64-bit ballot drives the loop.  A primitive is skipped only where
+//     its coverage logit is below -X_CUT (coverage < 1.3e-14): the result matches the dense
+//     specification to ~1e-6;
+//   * MODE 1 fuses SilhouetteLoss (L1/MSE) and an L1 depth loss: the images and their gradients
+//     never go through HBM;
+//   * backward: the per-pixel gradients w.r.t. the 12 ray coefficients of a primitive are summed
+//     over the lane's pixels, reduced over the wave with a transposing butterfly (17 shuffles for
+//     12 values), parked in LDS and written once per tile as partials [B,tiles,K,12] with plain
+//     coalesced stores; a finishing kernel sums the partials in a fixed order and applies the
+//     chain rule to (v,q,t).  No atomics anywhere: the gradient is bitwise reproducible.
 #include "vpn_common.h"
 
-#ifdef VPN_RASTER_PRECISE_EXP
-#define R_EXP(x) expf(x)
-#else
-#define R_EXP(x) __expf(x)
-#endif
+#define R_EXP(x) __expf(x)   // v_exp_f32 based; the raster is a 1e-4 contract
 
 namespace vpn {
 
@@ -44,10 +40,7 @@ constexpr float R_E_CLAMP = 8.0f;
 constexpr float R_EPS_H = 1e-3f;     // squareplus smoothing of relu(1 - m2) under the chord sqrt
 constexpr float R_DELTA_S0 = 1e-12f;
 constexpr float R_EPS_D = 1e-9f;
-#ifndef VPN_RASTER_X_CUT
-#define VPN_RASTER_X_CUT 32.0f
-#endif
-constexpr float R_X_CUT = VPN_RASTER_X_CUT;     // primitives whose coverage logit is below -X_CUT on a tile are skipped
+constexpr float R_X_CUT = 32.0f;     // primitives whose coverage logit is below -X_CUT on a tile are skipped
 constexpr int R_TW = 16, R_TH = 16;  // pixel tile per wave
 constexpr int R_PPL = 4;             // pixels per lane (row groups of 4 rows)
 constexpr int R_REC = 7;             // float4 per primitive record in HBM
@@ -392,13 +385,9 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(const float4* __restrict
             const int k = k0 + __builtin_ctzll(m);
             m &= m - 1;
             const float4 q0 = lds[k * R_LREC], q1 = lds[k * R_LREC + 1], q2 = lds[k * R_LREC + 2],
-                         q3 = lds[k * R_LREC + 3], bb = lds[k * R_LREC + 4];
-            [[maybe_unused]] const int imin = __float_as_int(bb.z), imax = __float_as_int(bb.w);
+                         q3 = lds[k * R_LREC + 3];
 #pragma unroll
             for (int s = 0; s < R_PPL; ++s) {
-#ifdef VPN_RASTER_ROWSKIP
-                if (imin > r0 + 4 * s + 3 || imax < r0 + 4 * s) continue;   // wave-uniform: row group not touched
-#endif
                 PixPrim q;
                 eval_prim(q0, q1, q2, q3, px, py[s], inv_sigma, inv_gamma, zref, q);
                 P[s] *= q.c;
@@ -566,16 +555,12 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(const float4* __restrict
             const int k = k0 + __builtin_ctzll(m);
             m &= m - 1;
             const float4 q0 = lds[k * R_LREC], q1 = lds[k * R_LREC + 1], q2 = lds[k * R_LREC + 2],
-                         q3 = lds[k * R_LREC + 3], bb = lds[k * R_LREC + 4];
-            [[maybe_unused]] const int imin = __float_as_int(bb.z), imax = __float_as_int(bb.w);
+                         q3 = lds[k * R_LREC + 3];
             float v[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] = 0.0f;
 #pragma unroll
             for (int s = 0; s < R_PPL; ++s) {
-#ifdef VPN_RASTER_ROWSKIP
-                if (imin > r0 + 4 * s + 3 || imax < r0 + 4 * s) continue;
-#endif
                 PixPrim q;
                 eval_prim(q0, q1, q2, q3, px, py[s], inv_sigma, inv_gamma, zref, q);
                 // composite backward

@@ -8,7 +8,6 @@ extern "C" const char* vpn_error_string(int code) {
         case 0: return "success";
         case VPN_E_BADARG: return "vpn: null pointer or non-positive size";
         case VPN_E_TOOBIG: return "vpn: size above a documented limit";
-        case VPN_E_KIND: return "vpn: unknown primitive kind";
         default: break;
     }
     if (code > 0) return hipGetErrorString((hipError_t)code);

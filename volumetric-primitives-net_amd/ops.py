@@ -135,13 +135,14 @@ class ChamferFunction(Function):
         return g1, g2, None, None
 
 
-CHAMFER_MODES = {'auto': 0, 'brute': 1, 'pruned': 2, 'mfma': 3}
+CHAMFER_MODES = {'auto': 0, 'brute': 1, 'pruned': 2, 'mfma': 3, 'mfma32': 4}
 
 
 def chamfer_nn(p1, p2, mode='auto'):
     """Nearest-neighbour distances and indices in both directions (no autograd):
     (dist1 [B,N], idx1 [B,N] int32, dist2 [B,M], idx2 [B,M] int32).  mode: 'auto' | 'brute' | 'pruned'
-    (same results bit for bit; 'pruned' Morton-sorts the clouds and skips far target chunks)."""
+    (same results bit for bit; 'pruned' Morton-sorts the clouds and skips far target chunks, 'mfma' / 'mfma32'
+    filter on the bf16 / fp32 matrix instructions and finish exactly)."""
     p1, p2 = _f32c(p1.detach()), _f32c(p2.detach())
     B, N, _ = p1.shape
     M = p2.shape[1]
