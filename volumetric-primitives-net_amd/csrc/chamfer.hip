@@ -794,12 +794,20 @@ __global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_kernel(const float* 
                                                                    const float* __restrict__ F,
                                                                    const unsigned short* __restrict__ H,
                                                                    const unsigned int* __restrict__ nmax, int Nq,
-                                                                   int Nt, int Ntp, float* __restrict__ out_dist,
+                                                                   int Nt, int Ntp, int gx, float* __restrict__ out_dist,
                                                                    int32_t* __restrict__ out_idx) {
-    const int b = blockIdx.y;
+    // 1-D grid of gx * B workgroups.  Workgroups are dealt round-robin over the 8 XCDs (L2 is per XCD), so the
+    // linear id is remapped such that all workgroups of a sample land on ONE XCD and stream its target rows
+    // out of that XCD's L2 (speed only: any placement is correct).
+    int vid = blockIdx.x;
+    {
+        const int G = gridDim.x, per = G >> 3;
+        if (vid < (per << 3)) vid = (vid & 7) * per + (vid >> 3);
+    }
+    const int b = vid / gx, bx = vid - b * gx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, jq = lane & 31, half = lane >> 5;
     const float* qb = qpts + (size_t)b * Nq * 3;
-    const int qi = (blockIdx.x * 4 + wave) * 32 + jq;
+    const int qi = (bx * 4 + wave) * 32 + jq;
     const int qc = min(qi, Nq - 1);
     const float ax = qb[qc * 3], ay = qb[qc * 3 + 1], az = qb[qc * 3 + 2];
     // B operand (K x N): lane supplies B[k = lane/32][n = lane%32]
@@ -834,17 +842,28 @@ __global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_kernel(const float* 
         const unsigned char* Hb = reinterpret_cast<const unsigned char*>(H) + (size_t)b * Ntp * 64;
         bf8 bqA, bqB;                                // this lane's query: K slots [8 half, 8 half + 8) of the two MFMAs
         {
-            unsigned short qx[3], qy[3], qz[3], qs[32];
+            unsigned short qx[3], qy[3], qz[3];
             split3_bf16(-2.0f * ax, qx); split3_bf16(-2.0f * ay, qy); split3_bf16(-2.0f * az, qz);
-            const int AI[6] = {0, 1, 0, 2, 0, 1};
-#pragma unroll
-            for (int t = 0; t < 6; ++t) { qs[t] = qx[AI[t]]; qs[6 + t] = qy[AI[t]]; qs[12 + t] = qz[AI[t]]; }
-            qs[18] = 0x3F80; qs[19] = 0x3F80; qs[20] = 0x3F80;           // bf16 1.0 for the three |b|^2 pieces
-#pragma unroll
-            for (int t = 21; t < 32; ++t) qs[t] = 0;
+            // K slot k of the query row: per coordinate the pieces (a1 a2 a1 a3 a1 a2), then 1.0 x 3, then zeros.
+            // Everything is indexed by compile-time constants so the row lives in registers (no scratch).
+            auto slot = [&](int k) -> unsigned short {
+                const int c = k / 6, t = k % 6;
+                const int pi = (t == 1 || t == 5) ? 1 : (t == 3 ? 2 : 0);
+                if (k < 18) {
+                    const unsigned short v0 = c == 0 ? qx[0] : (c == 1 ? qy[0] : qz[0]);
+                    const unsigned short v1 = c == 0 ? qx[1] : (c == 1 ? qy[1] : qz[1]);
+                    const unsigned short v2 = c == 0 ? qx[2] : (c == 1 ? qy[2] : qz[2]);
+                    return pi == 0 ? v0 : (pi == 1 ? v1 : v2);
+                }
+                return k < 21 ? (unsigned short)0x3F80 : (unsigned short)0;      // bf16 1.0 for the |b|^2 pieces
+            };
             us8 ua, ub;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { ua[e] = half ? qs[8 + e] : qs[e]; ub[e] = half ? qs[24 + e] : qs[16 + e]; }
+            for (int e = 0; e < 8; ++e) {
+                const unsigned short lo0 = slot(e), hi0 = slot(8 + e), lo1 = slot(16 + e), hi1 = slot(24 + e);
+                ua[e] = half ? hi0 : lo0;
+                ub[e] = half ? hi1 : lo1;
+            }
             bqA = __builtin_bit_cast(bf8, ua); bqB = __builtin_bit_cast(bf8, ub);
         }
         constexpr int F4 = CM_TILE16 * 4 / CM_BLOCK;                    // float4 per lane per tile (rows are 4 float4)
@@ -1057,12 +1076,13 @@ static int mfma_nn(const float* q, const float* t, int B, int Nq, int Nt, float*
                fp32_filter ? nullptr : Hrows);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
+    const int gx = (Nq + 127) / 128;
     if (fp32_filter)
-        VPN_LAUNCH(chamfer_nn_mfma_kernel<0>, dim3((Nq + 127) / 128, B), dim3(CM_BLOCK), 0, s, q, t, F, Hrows, nmax, Nq,
-                   Nt, Ntp, d, idx);
+        VPN_LAUNCH(chamfer_nn_mfma_kernel<0>, dim3(gx * B), dim3(CM_BLOCK), 0, s, q, t, F, Hrows, nmax, Nq, Nt, Ntp, gx, d,
+                   idx);
     else
-        VPN_LAUNCH(chamfer_nn_mfma_kernel<1>, dim3((Nq + 127) / 128, B), dim3(CM_BLOCK), 0, s, q, t, F, Hrows, nmax, Nq,
-                   Nt, Ntp, d, idx);
+        VPN_LAUNCH(chamfer_nn_mfma_kernel<1>, dim3(gx * B), dim3(CM_BLOCK), 0, s, q, t, F, Hrows, nmax, Nq, Nt, Ntp, gx, d,
+                   idx);
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     VPN_LAUNCH(chamfer_fixup_kernel, dim3((Nq + CF_THREADS - 1) / CF_THREADS, B), dim3(CF_THREADS), 0, s, q, t,
