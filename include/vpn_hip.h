@@ -181,6 +181,21 @@ int vpn_raster_loss_bwd(const float* params, const int32_t* kinds, const float* 
                         const float* grad_losses, void* workspace, float* grad_params, int accumulate,
                         void* stream);
 
+/* ---- Earth Mover's Distance, auction approximation (row f1)
+ * Replaces emd.forward / emd.backward of the reference's CUDA extension (modules/loss/emd/emd_cuda.cu:228-282,
+ * :302-316, bound in emd_module.py:56, :69).  xyz1, xyz2 [B,n,3] (the reference requires equal sizes,
+ * emd_module.py:36); dist [B,n] = squared distance of every xyz1 point to its assigned xyz2 point;
+ * assignment [B,n] int32.  The nine scratch tensors the reference's caller allocates (emd_module.py:44-54)
+ * become one workspace of vpn_emd_workspace(B, n) bytes.  iters >= 1, eps >= 0.  n need not be a multiple
+ * of 1024 and B is not limited to 512 (emd_module.py:38-39). */
+size_t vpn_emd_workspace(int B, int n);
+int vpn_emd_fwd(const float* xyz1, const float* xyz2, int B, int n, float eps, int iters,
+                float* dist, int32_t* assignment, void* workspace, void* stream);
+/* grad_xyz1 [B,n,3] = 2 grad_dist (xyz1 - xyz2[assignment]) is written; xyz2 receives no gradient
+ * (emd_module.py:66-70 returns zeros for it). */
+int vpn_emd_bwd(const float* xyz1, const float* xyz2, const float* grad_dist, const int32_t* assignment,
+                int B, int n, float* grad_xyz1, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

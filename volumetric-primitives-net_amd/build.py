@@ -13,13 +13,15 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libvpn_hip.so')
-SOURCES = ['vpn_api.hip', 'sampler.hip', 'chamfer.hip', 'raster.hip']
+SOURCES = ['vpn_api.hip', 'sampler.hip', 'chamfer.hip', 'raster.hip', 'emd.hip']
 COMMON = ['-O3', '--offload-arch=gfx950', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function']
 COMMON += os.environ.get('VPN_EXTRA_FLAGS', '').split()      # experiments only (e.g. -DVPN_CHAMFER_DEBUG)
 PER_FILE = {
     # index-exact argmin: correctly rounded sqrt (hipcc default) and no contraction (also a pragma in the file)
     # -amdgpu-mfma-vgpr-form: MFMA results straight into VGPRs (no v_accvgpr_read copies before the min-tree)
     'chamfer.hip': ['-ffp-contract=off', '-mllvm', '-amdgpu-mfma-vgpr-form'],
+    # bit-equal to the oracle's auction: same rounding rules as the Chamfer scan
+    'emd.hip': ['-ffp-contract=off'],
     # the raster is compared with a 1e-4 tolerance: 1-ulp v_rcp/v_sqrt instead of the IEEE sequences
     'raster.hip': ['-fno-hip-fp32-correctly-rounded-divide-sqrt'],
 }

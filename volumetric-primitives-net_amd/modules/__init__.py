@@ -1,7 +1,7 @@
 """Host-side mirror of the reference's `modules` package for the hot path only:
 same import names as train.py:11-15 (`from modules.sampling import Sampling`, ...)."""
 from .sampling import Sampling
-from .loss import ChamferDistanceLoss, SilhouetteLoss, VPDiverseLoss
+from .loss import ChamferDistanceLoss, EarthMoverDistanceLoss, SilhouetteLoss, VPDiverseLoss
 from .render import VertexRenderer
 from .transform import (transform_points, rotate_points, translate_points, view_to_obj_points,
                         obj_to_view_points, rotate_points_forward_x_axis)

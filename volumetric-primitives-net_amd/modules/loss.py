@@ -1,10 +1,10 @@
-"""modules/loss of the reference (chamfer_distance.py, vp_diverse.py, silhouette.py) on
-the HIP Chamfer and raster kernels.  Same class names and forward signatures."""
+"""modules/loss of the reference (chamfer_distance.py, vp_diverse.py, silhouette.py, emd/emd_module.py)
+on the HIP Chamfer, raster and auction kernels.  Same class names and forward signatures."""
 import torch
 import torch.nn as nn
 
 from .. import config
-from ..ops import ChamferFunction, RasterLossFunction
+from ..ops import ChamferFunction, EmdFunction, RasterLossFunction
 from ..primitives import PrimitivePack
 from .render import VertexRenderer
 
@@ -26,6 +26,16 @@ class ChamferDistanceLoss(nn.Module):
     def check_parameters(points: torch.Tensor):
         assert points.ndimension() == 3  # (B, N, 3)        chamfer_distance.py:32-35
         assert points.size(-1) == 3
+
+
+class EarthMoverDistanceLoss(nn.Module):
+    def __init__(self):
+        super().__init__()
+
+    def forward(self, input1: torch.Tensor, input2: torch.Tensor, eps, iters):
+        """emd_module.py:77-78: (dist [B,n], assignment [B,n] int32); train.py:193 calls it with
+        eps=0.005, iters=50 on point sets normalised to the unit cube."""
+        return EmdFunction.apply(input1, input2, eps, iters)
 
 
 class VPDiverseLoss(nn.Module):

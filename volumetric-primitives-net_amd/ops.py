@@ -157,6 +157,39 @@ def chamfer_nn(p1, p2, mode='auto'):
     return d1, i1, d2, i2
 
 
+class EmdFunction(Function):
+    """emdFunction (modules/loss/emd/emd_module.py:29-70) on vpn_emd_fwd / vpn_emd_bwd: auction
+    approximation of the Earth Mover's Distance.  Returns (dist [B,n] squared distance to the assigned
+    point, assignment [B,n] int32).  The reference's nine scratch tensors are one workspace here."""
+
+    @staticmethod
+    def forward(ctx, xyz1, xyz2, eps, iters):
+        B, n, _ = xyz1.size()
+        assert n == xyz2.size(1)                       # emd_module.py:36-37
+        assert B == xyz2.size(0)
+        xyz1, xyz2 = _f32c(xyz1), _f32c(xyz2)
+        dev = xyz1.device
+        dist = torch.empty((B, n), dtype=torch.float32, device=dev)
+        assignment = torch.empty((B, n), dtype=torch.int32, device=dev)
+        ws = torch.empty((max(1, _lib.lib().vpn_emd_workspace(B, n) // 4),), dtype=torch.float32, device=dev)
+        _lib.call('vpn_emd_fwd', _lib.ptr(xyz1), _lib.ptr(xyz2), B, n, float(eps), int(iters), _lib.ptr(dist),
+                  _lib.ptr(assignment), _lib.ptr(ws), _lib.stream())
+        ctx.save_for_backward(xyz1, xyz2, assignment)
+        ctx.mark_non_differentiable(assignment)
+        return dist, assignment
+
+    @staticmethod
+    def backward(ctx, graddist, gradidx):
+        xyz1, xyz2, assignment = ctx.saved_tensors
+        B, n, _ = xyz1.shape
+        g = _f32c(graddist)
+        g1 = torch.empty_like(xyz1)
+        _lib.call('vpn_emd_bwd', _lib.ptr(xyz1), _lib.ptr(xyz2), _lib.ptr(g), _lib.ptr(assignment), B, n,
+                  _lib.ptr(g1), _lib.stream())
+        g2 = torch.zeros_like(xyz2) if ctx.needs_input_grad[1] else None     # emd_module.py:67
+        return g1, g2, None, None
+
+
 class RasterFunction(Function):
     """Primitive soft raster behind VertexRenderer.render (vertex_renderer.py:14-26):
     params [B,K,10], cam [B,3] = (dist, elev_deg, azim_deg) -> alpha, depth [B,H,W]."""
