@@ -439,7 +439,7 @@ def emd_auction(xyz1, xyz2, eps, iters):
 
     Per iteration (:246-273): list the unassigned points; each bids for the target maximising
     3 - |x1-x2| - price (Bid :95-179, value :143, increment best-second+eps :175-176, atomicMax :177);
-    the bidder whose increment matches the target's maximum within 1e-6 holds it (GetMax :181-194);
+    the bidder with the target's maximum increment holds it (GetMax :181-194);
     holders take the target, evict the previous owner, raise the price (Assign :196-215); on the last
     iteration every bidder is assigned to its bid.  fp32 throughout, sums as ((dx2+dy2)+dz2), no FMA."""
     import numpy as np
@@ -455,7 +455,6 @@ def emd_auction(xyz1, xyz2, eps, iters):
         assign = np.full(n, -1, np.int64)            # emd_module.py:44-50
         assign_inv = np.full(n, -1, np.int64)
         price = np.zeros(n, np.float32)
-        maxinc = np.zeros(n, np.float32)
         for it in range(iters):
             last = it == iters - 1
             U = np.nonzero(assign == -1)[0]
@@ -477,23 +476,21 @@ def emd_auction(xyz1, xyz2, eps, iters):
                 sv = val.max(1) if n > 1 else np.full(u.size, -1e9, np.float32)
                 best[s:s + 256], second[s:s + 256], bid[s:s + 256] = bv, np.maximum(sv, np.float32(-1e9)), bi
             inc = (best - second) + eps              # :175-176
-            np.maximum.at(maxinc, bid, inc)          # :177
-            mx = maxinc[bid].astype(np.float64)
-            v = inc.astype(np.float64)
-            holds = (v - 1e-6 <= mx) & (mx <= v + 1e-6)            # :188
-            maxidx = np.full(n, np.iinfo(np.int64).max, np.int64)
-            np.minimum.at(maxidx, bid[holds], U[holds])
             if last:
                 assign[U] = bid                      # :203 with `last`
                 break
-            win = maxidx[bid] == U
+            # :177 atomicMax + GetMax :181-194: the largest increment holds the target.  The reference lets every
+            # bidder within 1e-6 of the maximum store its index and keeps whichever store lands last; the
+            # exact maximum, lowest bidder among equal ones, is one of those outcomes and is what is fixed here.
+            order = np.lexsort((U, -inc.astype(np.float64), bid))
+            first = np.unique(bid[order], return_index=True)[1]
+            win = order[first]
             wi, wt = U[win], bid[win]
             prev = assign_inv[wt]
             assign[prev[prev != -1]] = -1            # :206-207
             assign_inv[wt] = wi
             assign[wi] = wt
             price[wt] = price[wt] + inc[win]         # :211
-            maxinc[wt] = np.float32(-1e9)            # :212
         d = a - c[assign]
         dist[b] = ((d[:, 0] * d[:, 0]) + (d[:, 1] * d[:, 1])) + (d[:, 2] * d[:, 2])     # CalcDist :217-226
         assignment[b] = assign

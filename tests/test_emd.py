@@ -79,7 +79,7 @@ def test_cabi_validation_and_surface():
     import vpn_amd
     import vpn_amd._lib as lib
     L = lib.lib()
-    assert L.vpn_emd_workspace(3, 1000) == 3 * 1000 * 8 * 4
+    assert L.vpn_emd_workspace(3, 1000) == 3 * 1000 * 8 * 4 + 16      # state + one barrier counter per sample
     assert L.vpn_emd_workspace(0, 5) == 0
     assert L.vpn_emd_fwd(None, None, 1, 8, 0.005, 50, None, None, None, None) == -1
     assert L.vpn_emd_bwd(None, None, None, None, 1, 8, None, None) == -1
@@ -119,6 +119,8 @@ def _exact(emd, x1, x2, eps, iters):
     (2, 2048, 0.005, 50),          # train.py:193 at the reference's SAMPLE_NUM * VP_NUM scale
     (1, 1024, 0.002, 1), (1, 1024, 0.002, 2),
     (1, 4500, 0.005, 12),          # more targets than one LDS tile: the cross-tile merge
+    (20, 512, 0.005, 50),          # ragged batch (padding workgroups), 8 workgroups per sample
+    (70, 300, 0.005, 30),          # more samples than fit with a group: one workgroup per sample
 ])
 def test_emd_equals_oracle(emd, B, n, eps, iters):
     x1, x2 = _clouds(B, n, 100 + n)
@@ -128,7 +130,7 @@ def test_emd_equals_oracle(emd, B, n, eps, iters):
 @pytest.mark.gpu
 def test_emd_ties_and_duplicates(emd):
     """Lattice points (equal values everywhere) and duplicated targets: lowest index wins, second best
-    counts duplicates, equal increments resolve to the lowest bidder."""
+    counts duplicates, equal increments resolve to the lowest bidder (also across workgroups of a group)."""
     gen = torch.Generator().manual_seed(5)
     x1 = torch.randint(0, 4, (2, 256, 3), generator=gen).float() / 4
     x2 = torch.randint(0, 4, (2, 256, 3), generator=gen).float() / 4

@@ -24,7 +24,9 @@ namespace vpn {
 constexpr int EMD_THREADS = 1024;
 constexpr int EMD_WAVES = EMD_THREADS / 64;
 constexpr int EMD_TILE = 4096;           // targets per LDS tile: 4 planes x 16 KB
+constexpr int EMD_UNROLL = 4;            // targets per lane per step of the scan; tiles are padded to 64 * EMD_UNROLL
 constexpr int EMD_WS_PLANES = 8;         // 4-byte words of workspace per point
+constexpr int EMD_MAX_GROUP = 16;        // workgroups cooperating on one sample
 
 // one bidder's running result over a set of targets
 struct Bid3 { float best, better; int idx; };
@@ -38,48 +40,82 @@ __device__ inline void emd_merge(Bid3& a, float ob, float obt, int oi) {
     a.idx = take ? oi : a.idx;
 }
 
-template <typename T>
-__device__ inline T emd_peek(const T* p) {     // read a word other waves of the workgroup updated atomically
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// Correctly rounded sqrt for 0 <= s < 2^100 without the compiler's denormal rescaling: v_sqrt_f32 (1 ulp) and the
+// two-residual fix-up.  For s < 2^-96 (where the rescaling would matter) the result is only required to be below
+// 2^-24, because the caller subtracts it from 3.0f.
+__device__ inline float emd_sqrt(float s) {
+    const float r = __builtin_amdgcn_sqrtf(s);
+    const float lo = __int_as_float(__float_as_int(r) - 1), hi = __int_as_float(__float_as_int(r) + 1);
+    const float elo = __builtin_fmaf(-lo, r, s), ehi = __builtin_fmaf(-hi, r, s);
+    float q = (0.0f >= elo) ? lo : r;
+    q = (0.0f < ehi) ? hi : q;
+    return q;
 }
 
+// State shared by the workgroups of a sample (assign, assign_inv, price) is read and written past the per-CU L1
+// (agent-scope relaxed accesses: sc1 loads / write-through stores), so the barrier below needs no cache-wide
+// write-back or invalidate — those cost ~70 us per barrier here, the accesses cost nothing measurable.
 template <typename T>
-__device__ inline void emd_poke(T* p, T v) {   // plain value for a word the next phase updates atomically (at L2)
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ inline T emd_ld(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T>
+__device__ inline void emd_st(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Barrier over the G workgroups of one sample (all resident: the host keeps B*G within the CU count).  Every
+// wave first waits for its own stores and atomics to be acknowledged (vmcnt counts stores on gfx9).
+__device__ inline void emd_group_sync(unsigned* counter, unsigned& passed, int G) {
+    if (G == 1) { __syncthreads(); return; }
+    __asm__ volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    passed += G;
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < passed)
+            __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
 }
 
+// grid: (ceil(B/8) * 8 * G) workgroups; the G workgroups of a sample sit on one XCD (workgroups are dealt to the
+// 8 XCDs round-robin), so its state stays in that XCD's L2.
 __global__ __launch_bounds__(EMD_THREADS) void emd_auction_kernel(const float* __restrict__ xyz1,
-                                                                  const float* __restrict__ xyz2, int n, float eps,
-                                                                  int iters, float* __restrict__ dist,
-                                                                  int32_t* assignment, float* wsf) {
+                                                                  const float* __restrict__ xyz2, int B, int n,
+                                                                  int G, float eps, int iters,
+                                                                  float* __restrict__ dist, int32_t* assignment,
+                                                                  float* wsf, unsigned* counters) {
     __shared__ __attribute__((aligned(16))) float tx[EMD_TILE], ty[EMD_TILE], tz[EMD_TILE], tp[EMD_TILE];
     __shared__ int wcount[EMD_WAVES];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int b = (q / G) * 8 + xcd, g = q % G;
+    if (b >= B) return;                                         // padding workgroups of a ragged batch
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int gtid = g * EMD_THREADS + tid, gthreads = G * EMD_THREADS;
     const float* p1 = xyz1 + (size_t)b * n * 3;
     const float* p2 = xyz2 + (size_t)b * n * 3;
     int32_t* assign = assignment + (size_t)b * n;
     float* base = wsf + (size_t)b * EMD_WS_PLANES * n;
-    float* price = base;                                        // per target
-    float* maxinc = base + n;                                   // per target: highest increment bid this round
-    int* maxidx = reinterpret_cast<int*>(base + 2 * n);         // per target: the bidder holding it
+    unsigned long long* top = reinterpret_cast<unsigned long long*>(base);   // per target: (increment, ~bidder) max
+    float* price = base + 2 * n;                                // per target
     int* assign_inv = reinterpret_cast<int*>(base + 3 * n);     // per target: current owner
     float* inc = base + 4 * n;                                  // per point: running best, then the bid increment
     float* second = base + 5 * n;                               // per point: running second best
     int* bid = reinterpret_cast<int*>(base + 6 * n);            // per point: target it bids for
     int* ulist = reinterpret_cast<int*>(base + 7 * n);          // unassigned points, ascending
+    unsigned* counter = counters + b;
+    unsigned passed = 0;
 
-    for (int j = tid; j < n; j += EMD_THREADS) {                // emd_module.py:44-50 initial state
-        assign[j] = -1; assign_inv[j] = -1; price[j] = 0.0f; emd_poke(maxinc + j, 0.0f);
+    for (int j = gtid; j < n; j += gthreads) {                  // emd_module.py:44-50 initial state
+        emd_st(assign + j, -1); emd_st(assign_inv + j, -1); emd_st(price + j, 0.0f); emd_st(top + j, 0ull);
     }
-    __syncthreads();
+    emd_group_sync(counter, passed, G);
 
     const int per = (n + EMD_THREADS - 1) / EMD_THREADS, j0 = min(n, tid * per), j1 = min(n, j0 + per);
     for (int it = 0; it < iters; ++it) {
         const bool last = it == iters - 1;
         // ---- unassigned points in ascending order (calc_unass_cnt .. calc_unass_idx :30-93; the reference's order
-        //      depends on atomics, the bids do not depend on the order)
+        //      depends on atomics, the bids do not depend on the order).  Every workgroup of the sample builds the
+        //      same list (same values to the same addresses).
         int cnt = 0;
-        for (int j = j0; j < j1; ++j) cnt += assign[j] == -1;
+        for (int j = j0; j < j1; ++j) cnt += emd_ld(assign + j) == -1;
         int scan = cnt;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const int t2 = __shfl_up(scan, o, 64); if (lane >= o) scan += t2; }
@@ -89,32 +125,41 @@ __global__ __launch_bounds__(EMD_THREADS) void emd_auction_kernel(const float* _
         int before = 0, U = 0;
 #pragma unroll
         for (int w = 0; w < EMD_WAVES; ++w) { const int c = wcount[w]; before += w < wave ? c : 0; U += c; }
-        if (U == 0) break;                                      // uniform: every later iteration is a no-op too
+        if (U == 0) break;                                      // uniform over the group: later iterations are no-ops
         int pos = before + scan - cnt;
-        for (int j = j0; j < j1; ++j) if (assign[j] == -1) ulist[pos++] = j;
-        for (int j = tid; j < n; j += EMD_THREADS) emd_poke(maxidx + j, 0x7fffffff);
+        for (int j = j0; j < j1; ++j) if (emd_ld(assign + j) == -1) ulist[pos++] = j;
         __syncthreads();
 
-        // ---- Bid (:95-179): wave w takes bidders w, w+16, ...; its 64 lanes scan the targets of each LDS tile
+        // ---- Bid (:95-179): wave w of workgroup g takes bidders g*16+w, +16G, ...; its 64 lanes scan the targets
         for (int t0 = 0; t0 < n; t0 += EMD_TILE) {
             const int tn = min(EMD_TILE, n - t0);
+            const int tpad = (tn + 64 * EMD_UNROLL - 1) / (64 * EMD_UNROLL) * (64 * EMD_UNROLL);
             const bool final_tile = t0 + EMD_TILE >= n;
             if (t0 > 0) __syncthreads();
-            for (int j = tid; j < tn; j += EMD_THREADS) {
-                const float* q = p2 + (size_t)(t0 + j) * 3;
-                tx[j] = q[0]; ty[j] = q[1]; tz[j] = q[2];
-                tp[j] = price[t0 + j];
+            for (int j = tid; j < tpad; j += EMD_THREADS) {
+                if (j < tn) {
+                    const float* c = p2 + (size_t)(t0 + j) * 3;
+                    tx[j] = c[0]; ty[j] = c[1]; tz[j] = c[2];
+                    tp[j] = emd_ld(price + t0 + j);
+                } else {                                        // padding never wins: value = -inf
+                    tx[j] = 0.0f; ty[j] = 0.0f; tz[j] = 0.0f; tp[j] = __builtin_inff();
+                }
             }
             __syncthreads();
-            for (int u = wave; u < U; u += EMD_WAVES) {
+            for (int u = g * EMD_WAVES + wave; u < U; u += G * EMD_WAVES) {
                 const int i = ulist[u];
                 const float x1 = p1[i * 3], y1 = p1[i * 3 + 1], z1 = p1[i * 3 + 2];
                 Bid3 r{-1e9f, -1e9f, -1};                       // :116
-                for (int k = lane; k < tn; k += 64) {
-                    const float dx = tx[k] - x1, dy = ty[k] - y1, dz = tz[k] - z1;          // :139-141
-                    const float d = (3.0f - sqrtf(((dx * dx) + (dy * dy)) + (dz * dz))) - tp[k];  // :143
-                    if (d > r.best) { r.better = r.best; r.best = d; r.idx = t0 + k; }      // :144-151
-                    else if (d > r.better) r.better = d;
+                for (int k = lane; k < tpad; k += 64 * EMD_UNROLL) {
+#pragma unroll
+                    for (int e = 0; e < EMD_UNROLL; ++e) {
+                        const int kk = k + 64 * e;
+                        const float dx = tx[kk] - x1, dy = ty[kk] - y1, dz = tz[kk] - z1;              // :139-141
+                        const float d = (3.0f - emd_sqrt(((dx * dx) + (dy * dy)) + (dz * dz))) - tp[kk];   // :143
+                        r.idx = d > r.best ? t0 + kk : r.idx;                                          // :144-151
+                        r.better = __builtin_amdgcn_fmed3f(r.best, d, r.better);
+                        r.best = fmaxf(r.best, d);
+                    }
                 }
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) {
@@ -131,44 +176,39 @@ __global__ __launch_bounds__(EMD_THREADS) void emd_auction_kernel(const float* _
                     if (final_tile) {
                         const float v = (r.best - r.better) + eps;                          // :175-176
                         bid[i] = r.idx; inc[i] = v;
-                        __hip_atomic_fetch_max(reinterpret_cast<int*>(maxinc) + r.idx, __float_as_int(v),
-                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // :177; v > 0
+                        // :177 + GetMax :181-194 in one step: the largest increment holds the target, the lowest
+                        // bidder among equal ones (v >= 0: its bit pattern orders like the value)
+                        const unsigned long long key =
+                            ((unsigned long long)(unsigned)__float_as_int(v) << 32) | (unsigned)(0x7fffffff - i);
+                        __hip_atomic_fetch_max(top + r.idx, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     } else {
                         bid[i] = r.idx; inc[i] = r.best; second[i] = r.better;
                     }
                 }
             }
         }
-        __syncthreads();
+        emd_group_sync(counter, passed, G);
 
-        // ---- GetMax (:181-194): the bidder whose increment equals the target's maximum (within 1e-6) holds it;
-        //      among several, the lowest index (the reference keeps whichever store lands last)
-        for (int u = tid; u < U; u += EMD_THREADS) {
+        // ---- Assign (:196-215): each workgroup settles the bidders it bid for (bid / inc stay CU-local)
+        for (int v = tid; v < (U + G * EMD_WAVES - 1) / (G * EMD_WAVES) * EMD_WAVES; v += EMD_THREADS) {
+            const int u = (v / EMD_WAVES) * (G * EMD_WAVES) + g * EMD_WAVES + (v % EMD_WAVES);
+            if (u >= U) continue;
             const int i = ulist[u], t = bid[i];
-            const double v = (double)inc[i], mx = (double)emd_peek(maxinc + t);
-            if (v - 1e-6 <= mx && mx <= v + 1e-6)
-                __hip_atomic_fetch_min(maxidx + t, i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (last) { emd_st(assign + i, t); continue; }      // prices and owners are not read again
+            const unsigned long long key = emd_ld(top + t);
+            if (0x7fffffff - (int)(unsigned)key != i) continue;
+            const int prev = emd_ld(assign_inv + t);
+            if (prev != -1) emd_st(assign + prev, -1);
+            emd_st(assign_inv + t, i);
+            emd_st(assign + i, t);
+            emd_st(price + t, emd_ld(price + t) + inc[i]);
+            emd_st(top + t, 0ull);                              // :212
         }
-        __syncthreads();
-
-        // ---- Assign (:196-215)
-        for (int u = tid; u < U; u += EMD_THREADS) {
-            const int i = ulist[u], t = bid[i];
-            if (last) { assign[i] = t; continue; }              // prices and owners are not read again
-            if (emd_peek(maxidx + t) != i) continue;
-            const int prev = assign_inv[t];
-            if (prev != -1) assign[prev] = -1;
-            assign_inv[t] = i;
-            assign[i] = t;
-            price[t] += inc[i];
-            emd_poke(maxinc + t, -1e9f);
-        }
-        __syncthreads();
+        emd_group_sync(counter, passed, G);
     }
 
-    __syncthreads();
-    for (int j = tid; j < n; j += EMD_THREADS) {                // CalcDist :217-226
-        const int t = assign[j];
+    for (int j = gtid; j < n; j += gthreads) {                  // CalcDist :217-226
+        const int t = emd_ld(assign + j);
         const float dx = p1[j * 3] - p2[t * 3], dy = p1[j * 3 + 1] - p2[t * 3 + 1], dz = p1[j * 3 + 2] - p2[t * 3 + 2];
         dist[(size_t)b * n + j] = ((dx * dx) + (dy * dy)) + (dz * dz);
     }
@@ -194,9 +234,25 @@ __global__ __launch_bounds__(256) void emd_bwd_kernel(const float* __restrict__ 
 
 using namespace vpn;
 
+static int emd_group_size(int B, int n) {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 8;
+    }
+    const int padded = (B + 7) / 8 * 8;
+    int G = 1;                                   // every workgroup of the launch must be resident: B*G <= CUs
+    while (G * 2 <= EMD_MAX_GROUP && padded * G * 2 <= cus && G * 2 * EMD_WAVES * 4 <= n) G *= 2;
+    return G;
+}
+
+static size_t emd_state_bytes(int B, int n) { return (size_t)B * n * EMD_WS_PLANES * sizeof(float); }
+
 extern "C" size_t vpn_emd_workspace(int B, int n) {
     if (B <= 0 || n <= 0) return 0;
-    return (size_t)B * n * EMD_WS_PLANES * sizeof(float);
+    return emd_state_bytes(B, n) + ((size_t)B * sizeof(unsigned) + 7) / 8 * 8;
 }
 
 extern "C" int vpn_emd_fwd(const float* xyz1, const float* xyz2, int B, int n, float eps, int iters, float* dist,
@@ -204,10 +260,14 @@ extern "C" int vpn_emd_fwd(const float* xyz1, const float* xyz2, int B, int n, f
     if (!xyz1 || !xyz2 || !dist || !assignment || !workspace || B < 0 || n < 0 || iters < 1 || !(eps >= 0.0f))
         return VPN_E_BADARG;
     if ((long long)B * n * 3 > 0x7fffffffLL) return VPN_E_TOOBIG;
+    if (((uintptr_t)workspace & 7) != 0) return VPN_E_BADARG;
     if (B == 0 || n == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    VPN_LAUNCH(emd_auction_kernel, dim3(B), dim3(EMD_THREADS), 0, s, xyz1, xyz2, n, eps, iters, dist, assignment,
-               (float*)workspace);
+    const int G = emd_group_size(B, n);
+    unsigned* counters = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + emd_state_bytes(B, n));
+    if (hipMemsetAsync(counters, 0, (size_t)B * sizeof(unsigned), s) != hipSuccess) return (int)hipGetLastError();
+    VPN_LAUNCH(emd_auction_kernel, dim3((B + 7) / 8 * 8 * G), dim3(EMD_THREADS), 0, s, xyz1, xyz2, B, n, G, eps, iters,
+               dist, assignment, (float*)workspace, counters);
     VPN_LAUNCH_CHECK();
     return 0;
 }
