@@ -232,9 +232,45 @@ def main():
         }
         if cpu is not None:
             out['cpu_baseline'] = cpu
+        if world == 1:      # row f1, outside the metric: the auction EMD loss the reference adds to the same step
+            out['emd'] = emd_extra(B, M, dev, vpn_amd, cpu is not None)
         print(json.dumps(out), flush=True)
     if multi:
         dist.destroy_process_group()
+
+
+def emd_extra(B, n, dev, vpn_amd, with_cpu):
+    """EarthMoverDistanceLoss fwd+bwd as train.py:193 calls it (eps=0.005, 50 iterations) on B clouds of n points;
+    not part of `value`.  CPU leg: the oracle's auction on one cloud."""
+    gen = torch.Generator().manual_seed(3)
+    x1 = torch.rand(B, n, 3, generator=gen).to(dev).requires_grad_(True)
+    x2 = torch.rand(B, n, 3, generator=gen).to(dev)
+    emd = vpn_amd.modules.loss.EarthMoverDistanceLoss()
+
+    def once():
+        d, _ = emd(x1, x2, 0.005, 50)
+        x1.grad = None
+        d.mean().backward()
+    once()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        once()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 5 * 1e3
+    out = {'workload': 'EMD auction fwd+bwd, B=%d, n=m=%d, eps=0.005, iters=50' % (B, n), 'ms': round(ms, 3),
+           'clouds_per_s': round(B / ms * 1e3, 1)}
+    if with_cpu:
+        from oracle import vpn_oracle as O
+        a, b = x1.detach()[:1].cpu(), x2[:1].cpu()
+        t0 = time.perf_counter()
+        rd, ra = O.emd_auction(a, b, 0.005, 50)
+        cpu_s = time.perf_counter() - t0
+        d, idx = emd(x1.detach()[:1], x2[:1], 0.005, 50)
+        out['cpu_port_clouds_per_s'] = round(1.0 / cpu_s, 2)
+        out['parity_vs_oracle'] = {'assignment_equal': bool(torch.equal(idx.cpu(), ra)),
+                                   'dist_bit_equal': bool(torch.equal(d.cpu(), rd))}
+    return out
 
 
 def cpu_baseline(params, gt_points, gt_sil, gt_depth, K, n, H, W, sigma, gamma, z_far,

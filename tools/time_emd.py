@@ -1,6 +1,7 @@
 """Time the auction kernel: python tools/time_emd.py [B n eps iters]..."""
 import sys, time, torch
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import vpn_amd
 from vpn_amd import _lib
 emd = vpn_amd.modules.loss.EarthMoverDistanceLoss()
