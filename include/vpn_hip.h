@@ -181,6 +181,17 @@ int vpn_raster_loss_bwd(const float* params, const int32_t* kinds, const float* 
                         const float* grad_losses, void* workspace, float* grad_params, int accumulate,
                         void* stream);
 
+/* ---- fused camera transforms (row f3): view_to_obj_points / obj_to_view_points
+ * (modules/transform/transform.py:21-47, :50-73; called on train.py:158 every step).
+ * points [B,N,3]; dists, elevs, azims, angles [B] (degrees, as the reference's callers pass them; angles may
+ * be NULL when to_object == 0).  to_object != 0: out = dist * R(-z,-e) R(y',-a) R(x,-angle) p;
+ * to_object == 0: out = R(y',a) R(-z,e) p / dist.  One launch instead of 3-4 rotate_points + a scale.
+ * The camera is data (dataset.py:145-165): only the points receive a gradient. */
+int vpn_camera_transform_fwd(const float* points, const float* dists, const float* elevs, const float* azims,
+                             const float* angles, int B, int N, int to_object, float* out, void* stream);
+int vpn_camera_transform_bwd(const float* grad_out, const float* dists, const float* elevs, const float* azims,
+                             const float* angles, int B, int N, int to_object, float* grad_points, void* stream);
+
 /* ---- Earth Mover's Distance, auction approximation (row f1)
  * Replaces emd.forward / emd.backward of the reference's CUDA extension (modules/loss/emd/emd_cuda.cu:228-282,
  * :302-316, bound in emd_module.py:56, :69).  xyz1, xyz2 [B,n,3] (the reference requires equal sizes,

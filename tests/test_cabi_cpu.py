@@ -41,6 +41,7 @@ def test_argument_validation_needs_no_gpu():
     assert L.vpn_sample_fwd(None, None, None, 0, 0, 1, 1, 1, None, None) == -1
     assert L.vpn_raster_fwd(None, None, None, 1, 1, 8, 8, 0.1, 0.1, 2.0, None, None, None, None, None) == -1
     assert L.vpn_raster_loss_fwd(None, None, None, 1, 1, 8, 8, 0.1, 0.1, 2.0, None, None, 0, None, None, None, None, None, 0, 0.0, 0.0, 0.0, None) == -1
+    assert L.vpn_camera_transform_fwd(None, None, None, None, None, 1, 8, 1, None, None) == -1
     assert L.vpn_raster_records_size(2, 3) == 2 * 3 * 7 * 16
     assert L.vpn_raster_bwd_workspace(2, 3, 32, 32) == 2 * 4 * 3 * 12 * 4
     assert L.vpn_raster_bwd_workspace(0, 3, 32, 32) == 0

@@ -148,6 +148,45 @@ def test_transforms_golden(vpn):
     assert rel_err((r + g(gd['t'])[:, None]).cpu(), gd['transform']) <= RTOL
 
 
+def test_camera_transforms_fused_vs_oracle(vpn):
+    """Row f3: the fused view<->object launch against the oracle's chain of rotations (pinned by g6), forward and
+    gradient, on cameras outside the dataset's range too (negative, beyond one turn)."""
+    gen = torch.Generator().manual_seed(21)
+    B, N = 5, 333
+    pts = torch.randn(B, N, 3, generator=gen)
+    d = torch.rand(B, generator=gen) * 2 + 0.5
+    e = (torch.rand(B, generator=gen) - 0.3) * 500
+    a = (torch.rand(B, generator=gen) - 0.5) * 900
+    ang = (torch.rand(B, generator=gen) - 0.5) * 720
+    W = torch.randn(B, N, 3, generator=gen)
+    for name in ('view_to_obj', 'obj_to_view'):
+        pc = pts.clone().requires_grad_(True)
+        ref = O.view_to_obj_points(pc, d, e, a, ang) if name == 'view_to_obj' else O.obj_to_view_points(pc, d, e, a)
+        (ref * W).sum().backward()
+        pg = g(pts).requires_grad_(True)
+        out = (vpn.view_to_obj_points(pg, g(d), g(e), g(a), g(ang)) if name == 'view_to_obj'
+               else vpn.obj_to_view_points(pg, g(d), g(e), g(a)))
+        (out * g(W)).sum().backward()
+        assert rel_err(out.detach().cpu(), ref.detach()) <= 1e-5, name
+        assert rel_err(pg.grad.cpu(), pc.grad) <= 1e-5, name
+    with pytest.raises(RuntimeError, match='dataset values'):
+        vpn.obj_to_view_points(g(pts), g(d).requires_grad_(True), g(e), g(a))
+
+
+def test_camera_transforms_full_size_round_trip(vpn):
+    """C3-sized cloud: object -> view -> object is the identity (angles = 0), and lengths scale by dist."""
+    gen = torch.Generator().manual_seed(22)
+    B, N = 64, 8192
+    pts = g(torch.rand(B, N, 3, generator=gen) - 0.5)
+    d = g(torch.rand(B, generator=gen) + 0.8)
+    e = g(torch.rand(B, generator=gen) * 60 - 10)
+    a = g(torch.rand(B, generator=gen) * 360)
+    view = vpn.obj_to_view_points(pts, d, e, a)
+    back = vpn.view_to_obj_points(view, d, e, a, torch.zeros_like(d))
+    assert rel_err(back.cpu(), pts.cpu()) <= 1e-5
+    assert rel_err((view.norm(dim=-1) * d[:, None]).cpu(), pts.norm(dim=-1).cpu()) <= 1e-5
+
+
 # ----------------------------------------------------------------------------- Chamfer
 def ulp_diff(a, b):
     return int((a.contiguous().view(torch.int32) - b.contiguous().view(torch.int32)).abs().max())

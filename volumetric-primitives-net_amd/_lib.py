@@ -39,6 +39,8 @@ SIGNATURES = {
     'vpn_total_loss': (_i, [_c_f, _i, _f, _f, _f, _c_f, _c_f]),
     'vpn_raster_loss_bwd': (_i, [_c_f, _c_f, _c_f, _i, _i, _i, _i, _f, _f, _f, _c_f, _c_f, _c_f, _c_f, _i, _c_f, _c_f, _c_f,
                                  _i, _c_f]),
+    'vpn_camera_transform_fwd': (_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _i, _i, _i, _c_f, _c_f]),
+    'vpn_camera_transform_bwd': (_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _i, _i, _i, _c_f, _c_f]),
     'vpn_emd_workspace': (_sz, [_i, _i]),
     'vpn_emd_fwd': (_i, [_c_f, _c_f, _i, _i, _f, _i, _c_f, _c_f, _c_f, _c_f]),
     'vpn_emd_bwd': (_i, [_c_f, _c_f, _c_f, _c_f, _i, _i, _c_f, _c_f]),

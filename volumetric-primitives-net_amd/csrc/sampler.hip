@@ -244,6 +244,66 @@ __global__ __launch_bounds__(TR_BLOCK) void transform_bwd_kernel(
     }
 }
 
+// ---- fused camera transforms (modules/transform/transform.py:21-73): the reference chains 3-4 rotate_points
+// calls and a scale over the whole cloud; here the per-sample 3x3 is composed once and applied in one pass.
+//   to_object != 0  view_to_obj_points :21-47:  p * dist <- R(-z,-e) R(y',-a) R(x,-angle) p,  y' = R(-z,e) y
+//   to_object == 0  obj_to_view_points :50-73:  p / dist <- R(y', a) R(-z, e) p
+// (angles in degrees / 360 = turns, the unit of refine_quaternions, rotate.py:59-72)
+__device__ inline Mat3 mat_mul(const Mat3& A, const Mat3& B) {
+    Mat3 C;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) C.m[i][j] = A.m[i][0] * B.m[0][j] + A.m[i][1] * B.m[1][j] + A.m[i][2] * B.m[2][j];
+    return C;
+}
+
+__device__ inline Mat3 camera_matrix(float elev, float azim, float angle, int to_object) {
+    const float e = elev / 360.0f, a = azim / 360.0f;
+    const Mat3 Re = make_pose(0.0f, 0.0f, -1.0f, e).R;                    // :32-33 / :60-64
+    const float yx = Re.m[0][1], yy = Re.m[1][1], yz = Re.m[2][1];         // R(-z,e) (0,1,0)
+    if (to_object) {
+        const Mat3 Rx = make_pose(1.0f, 0.0f, 0.0f, -angle / 360.0f).R;    // :25, :88-92
+        const Mat3 Ra = make_pose(yx, yy, yz, -a).R;                       // :35-36
+        const Mat3 Rb = make_pose(0.0f, 0.0f, -1.0f, -e).R;                // :38-39
+        return mat_mul(Rb, mat_mul(Ra, Rx));
+    }
+    const Mat3 Ra = make_pose(yx, yy, yz, a).R;                            // :66-67
+    return mat_mul(Ra, Re);
+}
+
+// transpose != 0: the backward pass (grad_points = M^T g, same scale)
+__global__ __launch_bounds__(TR_BLOCK) void camera_transform_kernel(
+    const float* __restrict__ pts, const float* __restrict__ dists, const float* __restrict__ elevs,
+    const float* __restrict__ azims, const float* __restrict__ angles, int N, int to_object, int transpose,
+    float* __restrict__ out) {
+    __shared__ Mat3 S;
+    const int b = blockIdx.y;
+    if (threadIdx.x == 0) {
+        Mat3 M = camera_matrix(elevs[b], azims[b], angles ? angles[b] : 0.0f, to_object);
+        if (transpose) {
+            Mat3 T;
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) T.m[i][j] = M.m[j][i];
+            M = T;
+        }
+        S = M;
+    }
+    __syncthreads();
+    const Mat3& R = S;
+    const float d = dists[b];
+    for (int p = blockIdx.x * TR_BLOCK + threadIdx.x; p < N; p += gridDim.x * TR_BLOCK) {
+        const float* pp = pts + ((size_t)b * N + p) * 3;
+        const float x = pp[0], y = pp[1], z = pp[2];
+        float ox = R.m[0][0] * x + R.m[0][1] * y + R.m[0][2] * z;
+        float oy = R.m[1][0] * x + R.m[1][1] * y + R.m[1][2] * z;
+        float oz = R.m[2][0] * x + R.m[2][1] * y + R.m[2][2] * z;
+        if (to_object) { ox *= d; oy *= d; oz *= d; }                      // :44
+        else { ox /= d; oy /= d; oz /= d; }                                // :71
+        float* o = out + ((size_t)b * N + p) * 3;
+        o[0] = ox; o[1] = oy; o[2] = oz;
+    }
+}
+
 }  // namespace vpn
 
 using namespace vpn;
@@ -292,4 +352,30 @@ extern "C" int vpn_transform_bwd(const float* points, const float* q, const floa
                        N, grad_points, grad_q, grad_t);
     VPN_LAUNCH_CHECK();
     return 0;
+}
+
+static int camera_launch(const float* points, const float* dists, const float* elevs, const float* azims,
+                         const float* angles, int B, int N, int to_object, int transpose, float* out, void* stream) {
+    if (!points || !dists || !elevs || !azims || !out) return VPN_E_BADARG;
+    if (to_object && !angles) return VPN_E_BADARG;
+    if (B <= 0 || N <= 0) return VPN_E_BADARG;
+    if (B > 65535) return VPN_E_TOOBIG;
+    int gx = (N + TR_BLOCK - 1) / TR_BLOCK;
+    if (gx > 1024) gx = 1024;
+    VPN_LAUNCH(camera_transform_kernel, dim3(gx, B), dim3(TR_BLOCK), 0, (hipStream_t)stream, points, dists, elevs,
+               azims, angles, N, to_object, transpose, out);
+    VPN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vpn_camera_transform_fwd(const float* points, const float* dists, const float* elevs,
+                                        const float* azims, const float* angles, int B, int N, int to_object,
+                                        float* out, void* stream) {
+    return camera_launch(points, dists, elevs, azims, angles, B, N, to_object, 0, out, stream);
+}
+
+extern "C" int vpn_camera_transform_bwd(const float* grad_out, const float* dists, const float* elevs,
+                                        const float* azims, const float* angles, int B, int N, int to_object,
+                                        float* grad_points, void* stream) {
+    return camera_launch(grad_out, dists, elevs, azims, angles, B, N, to_object, 1, grad_points, stream);
 }

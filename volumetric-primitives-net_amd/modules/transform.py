@@ -2,7 +2,7 @@
 transform kernel.  Same function names, argument order and shape assertions."""
 import torch
 
-from ..ops import TransformFunction
+from ..ops import CameraTransformFunction, TransformFunction
 
 
 def _check_points(points):
@@ -45,27 +45,24 @@ def rotate_points_forward_x_axis(points: torch.Tensor, angles: torch.Tensor):
     return rotate_points(points, _axis_q([1.0, 0.0, 0.0], angles.view(-1) / 360))
 
 
+def _camera_is_data(*tensors):
+    for t in tensors:
+        if t.requires_grad:
+            raise RuntimeError('camera arguments are dataset values here (dataset.py:145-165); gradients with respect '
+                               'to them are not implemented')
+
+
 def obj_to_view_points(points, dists, elevs, azims):
-    """transform.py:50-73."""
+    """transform.py:50-73: two rotations and the division by dist, one fused launch."""
     assert points.ndimension() == 3
     assert dists.ndimension() == elevs.ndimension() == azims.ndimension() == 1
-    elevs, azims = elevs.view(-1, 1) / 360, azims.view(-1, 1) / 360
-    y = torch.tensor([[0.0, 1.0, 0.0]], device=points.device).repeat(points.size(0), 1)
-    q = _axis_q([0.0, 0.0, -1.0], elevs)
-    points = rotate_points(points, q)
-    y = rotate_points(y.unsqueeze(1), q).squeeze(1)
-    points = rotate_points(points, torch.cat([y, azims], 1))
-    return points / dists.view(-1, 1, 1)
+    _camera_is_data(dists, elevs, azims)
+    return CameraTransformFunction.apply(points, dists, elevs, azims, None, False)
 
 
 def view_to_obj_points(points, dists, elevs, azims, angles):
-    """transform.py:21-47."""
+    """transform.py:21-47: three rotations and the scale by dist, one fused launch."""
     assert points.ndimension() == 3
     assert dists.ndimension() == elevs.ndimension() == azims.ndimension() == 1
-    elevs, azims = elevs.view(-1, 1) / 360, azims.view(-1, 1) / 360
-    points = rotate_points_forward_x_axis(points, -angles)
-    y = torch.tensor([[0.0, 1.0, 0.0]], device=points.device).repeat(points.size(0), 1)
-    y = rotate_points(y.unsqueeze(1), _axis_q([0.0, 0.0, -1.0], elevs)).squeeze(1)
-    points = rotate_points(points, torch.cat([y, -azims], 1))
-    points = rotate_points(points, _axis_q([0.0, 0.0, -1.0], -elevs))
-    return points * dists.view(-1, 1, 1)
+    _camera_is_data(dists, elevs, azims, angles)
+    return CameraTransformFunction.apply(points, dists, elevs, azims, angles, True)

@@ -97,6 +97,39 @@ class TransformFunction(Function):
         return gp, gq, gt
 
 
+class CameraTransformFunction(Function):
+    """view_to_obj_points / obj_to_view_points (modules/transform/transform.py:21-73) in one launch.
+    dists, elevs, azims, angles are dataset values (dataset.py:145-165): constants for autograd."""
+
+    @staticmethod
+    def forward(ctx, points, dists, elevs, azims, angles, to_object):
+        points = _f32c(points)
+        B, N, _ = points.shape
+        cam = [_f32c(c.reshape(-1)) for c in (dists, elevs, azims)]
+        ang = _f32c(angles.reshape(-1)) if angles is not None else None
+        for c in cam + ([ang] if ang is not None else []):
+            if c.numel() != B:
+                raise ValueError('camera arguments must hold one value per sample')
+        out = torch.empty_like(points)
+        _lib.call('vpn_camera_transform_fwd', _lib.ptr(points), _lib.ptr(cam[0]), _lib.ptr(cam[1]), _lib.ptr(cam[2]),
+                  _lib.ptr(ang), B, N, int(bool(to_object)), _lib.ptr(out), _lib.stream())
+        ctx.save_for_backward(*cam, *([ang] if ang is not None else []))
+        ctx.to_object = int(bool(to_object))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        saved = ctx.saved_tensors
+        d, e, a = saved[:3]
+        ang = saved[3] if len(saved) > 3 else None
+        g = _f32c(grad_out)
+        B, N, _ = g.shape
+        gp = torch.empty_like(g)
+        _lib.call('vpn_camera_transform_bwd', _lib.ptr(g), _lib.ptr(d), _lib.ptr(e), _lib.ptr(a), _lib.ptr(ang), B, N,
+                  ctx.to_object, _lib.ptr(gp), _lib.stream())
+        return gp, None, None, None, None, None
+
+
 class ChamferFunction(Function):
     """ChamferDistanceLoss.forward up to the per-sample loss (chamfer_distance.py:14-28).
     Returns loss_b [B]; the caller takes .mean() unless each_batch (chamfer_distance.py:30)."""
