@@ -776,16 +776,25 @@ __global__ __launch_bounds__(CF_THREADS) void chamfer_fixup_kernel(const float* 
     }
 }
 
-// balanced v_min3 tree (depth 3): a serial chain of 8 dependent v_min3 made the filter latency-bound
+// balanced v_min3 tree (depth 3): a serial chain of 8 dependent v_min3 made the filter latency-bound.
+// Level 1 reads the matrix-pipe output and stays visible to the compiler (it owns the MFMA -> VALU wait
+// states; inline asm is not covered by its hazard recogniser): five fminf pairs that it fuses into v_min3.
+// The upper levels are written as instructions: left to the compiler, the tree is re-associated so that one
+// 2-operand v_min_f32 reads raw accumulators and needs two extra NaN-quieting v_max per call.
+__device__ inline float vmin3(float a, float b, float c) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 __device__ inline float min16(const f16v& v) {
     const float a = __builtin_fminf(__builtin_fminf(v[0], v[1]), v[2]);
     const float b = __builtin_fminf(__builtin_fminf(v[3], v[4]), v[5]);
     const float c = __builtin_fminf(__builtin_fminf(v[6], v[7]), v[8]);
     const float d = __builtin_fminf(__builtin_fminf(v[9], v[10]), v[11]);
     const float e = __builtin_fminf(__builtin_fminf(v[12], v[13]), v[14]);
-    const float f = __builtin_fminf(__builtin_fminf(a, b), c);
-    const float g = __builtin_fminf(__builtin_fminf(d, e), v[15]);
-    return __builtin_fminf(f, g);
+    // v[15] is read by an asm instruction, but one that also consumes d and e: it cannot issue before they have
+    const float g = vmin3(d, e, v[15]);
+    return vmin3(vmin3(a, b, c), g, g);
 }
 
 template <int PREC>   // 0: fp32-input MFMA (shares the fp32 vector datapath), 1: bf16 3-piece split on the matrix pipe
@@ -832,7 +841,7 @@ __global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_kernel(const float* 
         CM_SEL(sel_, k2_, t_, blk2);      /* c2 ? t : blk2 */                                  \
         CM_SEL(blk2, k1_, blk, sel_);     /* c1 ? blk : sel */                                 \
         CM_SEL(blk, k1_, t_, blk);        /* c1 ? t : blk */                                   \
-        best = __builtin_fminf(best, (m));                                                     \
+        asm volatile("v_min_f32 %0, %1, %2" : "=v"(best) : "v"(best), "v"(m));                    \
     }
     const float* Fb = F + (size_t)b * 4 * Ntp;
     const f16v zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -867,48 +876,63 @@ __global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_kernel(const float* 
             bqA = __builtin_bit_cast(bf8, ua); bqB = __builtin_bit_cast(bf8, ub);
         }
         constexpr int F4 = CM_TILE16 * 4 / CM_BLOCK;                    // float4 per lane per tile (rows are 4 float4)
-        auto fetch = [&](int t0, float4 v[F4]) {
-#pragma unroll
-            for (int u = 0; u < F4; ++u) {
-                const int i = threadIdx.x + u * CM_BLOCK, row = i >> 2, qd = i & 3;
-                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (t0 + row < Ntp) v[u] = *reinterpret_cast<const float4*>(Hb + (size_t)(t0 + row) * 64 + qd * 16);
-            }
+        static_assert(F4 == 4, "tile fetch is written for 4 float4 per lane");
+        // tile t0 = rows [t0, t0 + CM_TILE16): one contiguous 16-KB run; lane i moves float4 i, i+256, ...  No bounds
+        // checks (they cost ~50 instructions per tile): the last tile may run past Ntp into rows that are allocated
+        // (next sample / slack at the end of the workspace), loaded and never used.
+        const float4* Hq = reinterpret_cast<const float4*>(Hb) + threadIdx.x;
+        struct Pre { float4 a, b, c, d; };              // named members: an indexed array ended up in scratch
+        auto fetch = [&](int t0) -> Pre {
+            const float4* p = Hq + t0 * 4;
+            return Pre{p[0], p[CM_BLOCK], p[2 * CM_BLOCK], p[3 * CM_BLOCK]};
         };
-        auto stash = [&](int buf, const float4 v[F4]) {
-#pragma unroll
-            for (int u = 0; u < F4; ++u) {
-                const int i = threadIdx.x + u * CM_BLOCK, row = i >> 2, qd = i & 3;
-                *reinterpret_cast<float4*>(&tileH[buf][row * CM_ROWB + qd * 16]) = v[u];
-            }
+        const int srow = (threadIdx.x >> 2) * CM_ROWB + (threadIdx.x & 3) * 16;      // lane i -> row i/4, quarter i%4
+        auto stash = [&](int buf, const Pre& v) {
+            unsigned char* q = &tileH[buf][srow];
+            *reinterpret_cast<float4*>(q) = v.a;
+            *reinterpret_cast<float4*>(q + 64 * CM_ROWB) = v.b;
+            *reinterpret_cast<float4*>(q + 128 * CM_ROWB) = v.c;
+            *reinterpret_cast<float4*>(q + 192 * CM_ROWB) = v.d;
         };
-        float4 pre[F4];
-        fetch(0, pre);
+        // one 32-target block: lanes (jq, half) read bytes [16 half, +16) and [32 + 16 half, +16) of row jq
+        struct Ops { float4 lo, hi; };
+        auto rd = [&](const unsigned char* T, int blkk) -> Ops {
+            const unsigned char* p = T + blkk * 32 * CM_ROWB;
+            return Ops{*reinterpret_cast<const float4*>(p), *reinterpret_cast<const float4*>(p + 32)};
+        };
+        auto block = [&](const Ops& o) {
+            f16v acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, o.lo), bqA, zero, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, o.hi), bqB, acc, 0, 0, 0);
+            return acc;
+        };
+        Pre pre = fetch(0);
         stash(0, pre);
         __syncthreads();
         int buf = 0;
         for (int t0 = 0; t0 < Ntp; t0 += CM_TILE16, buf ^= 1) {
             const bool more = t0 + CM_TILE16 < Ntp;
-            if (more) fetch(t0 + CM_TILE16, pre);      // in flight during the MFMA loop, stored to LDS after it
+            if (more) pre = fetch(t0 + CM_TILE16);     // in flight during the MFMA loop, stored to LDS after it
             const int nblk = min(CM_TILE16, Ntp - t0) >> 5;
             const unsigned char* T = &tileH[buf][jq * CM_ROWB + half * 16];
-            float4 o0 = *reinterpret_cast<const float4*>(T), o1 = *reinterpret_cast<const float4*>(T + 32);
-            float4 o2 = *reinterpret_cast<const float4*>(T + 32 * CM_ROWB), o3 = *reinterpret_cast<const float4*>(T + 32 * CM_ROWB + 32);
-            for (int u = 0; u < nblk; u += 2) {        // nblk is even (Ntp is a multiple of 64)
-                const float4 c0 = o0, c1 = o1, c2 = o2, c3 = o3;
-                if (u + 2 < nblk) {
-                    const unsigned char* Tn = T + (u + 2) * 32 * CM_ROWB;
-                    o0 = *reinterpret_cast<const float4*>(Tn); o1 = *reinterpret_cast<const float4*>(Tn + 32);
-                    o2 = *reinterpret_cast<const float4*>(Tn + 32 * CM_ROWB); o3 = *reinterpret_cast<const float4*>(Tn + 32 * CM_ROWB + 32);
+            // blocks in groups of 4 with two operand register sets in ping-pong (no register rotation copies);
+            // nblk is even, a trailing half group re-reads in-tile rows and discards them
+            Ops a0 = rd(T, 0), a1 = rd(T, 1);
+            for (int u = 0; u < nblk; u += 4) {
+                const bool tail = u + 2 >= nblk;
+                const Ops b0 = rd(T, tail ? u : u + 2), b1 = rd(T, tail ? u + 1 : u + 3);
+                {
+                    const f16v accA = block(a0), accB = block(a1);
+                    const float mA = min16(accA), mB = min16(accB);
+                    CM_UPDATE(mA, t0 + u * 32)
+                    CM_UPDATE(mB, t0 + u * 32 + 32)
                 }
-                f16v accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, c0), bqA, zero, 0, 0, 0);
-                f16v accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, c2), bqA, zero, 0, 0, 0);
-                accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, c1), bqB, accA, 0, 0, 0);
-                accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, c3), bqB, accB, 0, 0, 0);
-                const float mA = min16(accA);
-                CM_UPDATE(mA, t0 + u * 32)
-                const float mB = min16(accB);
-                CM_UPDATE(mB, t0 + u * 32 + 32)
+                if (u + 4 < nblk) { a0 = rd(T, u + 4); a1 = rd(T, u + 5); }
+                if (!tail) {
+                    const f16v accA = block(b0), accB = block(b1);
+                    const float mA = min16(accA), mB = min16(accB);
+                    CM_UPDATE(mA, t0 + u * 32 + 64)
+                    CM_UPDATE(mB, t0 + u * 32 + 96)
+                }
             }
             if (more) stash(buf ^ 1, pre);
             __syncthreads();
@@ -1064,14 +1088,15 @@ __global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_kernel(const float* 
 }
 
 static inline int pad32(int n) { return (n + 63) & ~63; }   // feature planes padded to 64 targets (blocks are processed in pairs)
-static inline size_t mfma_ws_floats(int B, int N) { return (size_t)B * (4 + 16) * pad32(N) + (size_t)B; }   // fp32 planes + bf16 rows + nmax
+// fp32 planes + bf16 rows + one tile of slack (the row tiles are fetched without bounds checks) + nmax
+static inline size_t mfma_ws_floats(int B, int N) { return (size_t)B * (4 + 16) * pad32(N) + (size_t)CM_TILE16 * 16 + (size_t)B; }
 
 // one direction: features of the targets -> filtered scan of the queries
 static int mfma_nn(const float* q, const float* t, int B, int Nq, int Nt, float* F, float* d, int32_t* idx,
                    bool fp32_filter, hipStream_t s) {
     const int Ntp = pad32(Nt);
     unsigned short* Hrows = reinterpret_cast<unsigned short*>(F + (size_t)B * 4 * Ntp);     // [B][Ntp][32] bf16
-    unsigned int* nmax = reinterpret_cast<unsigned int*>(F + (size_t)B * 20 * Ntp);
+    unsigned int* nmax = reinterpret_cast<unsigned int*>(F + (size_t)B * 20 * Ntp + (size_t)CM_TILE16 * 16);
     VPN_LAUNCH(chamfer_feat_kernel, dim3(B, Ntp >= 4096 ? 4 : (Ntp >= 1024 ? 2 : 1)), dim3(1024), 0, s, t, Nt, Ntp, F, nmax,
                fp32_filter ? nullptr : Hrows);
     hipError_t e = hipGetLastError();
