@@ -15,3 +15,22 @@ for mode in sys.argv[1:]:
     for _ in range(20): vpn_amd.chamfer_nn(pts, gt, mode=mode)
     b.record(); torch.cuda.synchronize()
     print('%-8s both directions: %.1f us' % (mode, a.elapsed_time(b) * 1e3 / 20))
+
+# how many queries the filter leaves to the fix-up kernel (counter at the head of each direction's list)
+from vpn_amd import _lib
+N = pts.shape[1]
+ws = torch.empty((_lib.lib().vpn_chamfer_workspace(B, N, M) // 4,), dtype=torch.float32, device=dev)
+d1 = torch.empty(B, N, device=dev); d2 = torch.empty(B, M, device=dev)
+i1 = torch.empty(B, N, dtype=torch.int32, device=dev); i2 = torch.empty(B, M, dtype=torch.int32, device=dev)
+_lib.call('vpn_chamfer_fwd_ws', _lib.ptr(pts), _lib.ptr(gt), B, N, M, _lib.ptr(d1), _lib.ptr(i1), _lib.ptr(d2), _lib.ptr(i2),
+          _lib.ptr(ws), 3, _lib.stream())
+torch.cuda.synchronize()
+pad = lambda n: (n + 63) & ~63
+p4 = lambda n: (n + 3) & ~3
+wi = ws.view(torch.int32)
+off1 = B * 20 * pad(M) + 4096 + p4(B)                 # direction 1: targets p2 (M), queries p1 (N)
+size1 = off1 + p4(B) + 4 * B * N
+off2 = size1 + B * 20 * pad(N) + 4096 + p4(B)
+c1, c2 = wi[off1:off1 + B], wi[off2:off2 + B]
+print('undecided: direction 1 %d of %d (max %d per sample), direction 2 %d of %d (max %d per sample)'
+      % (int(c1.sum()), B * N, int(c1.max()), int(c2.sum()), B * M, int(c2.max())))

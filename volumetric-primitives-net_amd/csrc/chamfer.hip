@@ -655,24 +655,37 @@ __device__ inline void split3_bf16(float x, unsigned short p[3]) {
 // One workgroup per sample (no atomics, no memset): lanes stride over the points.
 // H[b][Np][32] bf16 rows for the bf16 filter: per coordinate the target pieces (b1 b1 b2 b1 b3 b2) that pair
 // with the query pieces (a1 a2 a1 a3 a1 a2), then the three pieces of |p|^2 (paired with 1.0), then zeros.
-__global__ __launch_bounds__(1024) void chamfer_feat_kernel(const float* __restrict__ pts, int N, int Np,
-                                                            float* __restrict__ F, unsigned int* __restrict__ nmax,
-                                                            unsigned short* __restrict__ H) {
+struct FeatJob {          // one cloud: grid.y slices [0, ysplit) of the launch belong to it
+    const float* pts; int N, Np, ysplit;
+    float* F; unsigned int* nmax; unsigned short* H; int* undecided;
+};
+
+// One launch converts both clouds of a Chamfer call (every launch costs ~8 us here, whatever it does).
+__global__ __launch_bounds__(1024) void chamfer_feat_kernel(const FeatJob j0, const FeatJob j1) {
     __shared__ float red[16];
+    const bool other = (int)blockIdx.y >= j0.ysplit;
+    const float* __restrict__ pts = other ? j1.pts : j0.pts;
+    const int N = other ? j1.N : j0.N, Np = other ? j1.Np : j0.Np, ysplit = other ? j1.ysplit : j0.ysplit;
+    float* __restrict__ F = other ? j1.F : j0.F;
+    unsigned int* __restrict__ nmax = other ? j1.nmax : j0.nmax;
+    unsigned short* __restrict__ H = other ? j1.H : j0.H;
+    int* __restrict__ undecided = other ? j1.undecided : j0.undecided;
+    const int by = (int)blockIdx.y - (other ? j0.ysplit : 0);
     const int b = blockIdx.x;
+    if (by == 0 && threadIdx.x == 0) undecided[b] = 0;     // this sample's list: the scan that follows appends to it
     const float* pb = pts + (size_t)b * N * 3;
     float* f = F + (size_t)b * 4 * Np;
     float nv = 0.f;
     // gridDim.y workgroups share a sample: each converts its slice; the max norm is cheap enough that
     // workgroup 0 simply scans the whole cloud for it (no atomics, no zero-initialised output)
-    if (blockIdx.y == 0)
+    if (by == 0)
         for (int j = threadIdx.x; j < N; j += 1024) {
             const float x = pb[j * 3], y = pb[j * 3 + 1], z = pb[j * 3 + 2];
             nv = fmaxf(nv, x * x + y * y + z * z);
         }
-    const int per = ((Np + (int)gridDim.y - 1) / (int)gridDim.y + 63) & ~63;
-    const int j0 = blockIdx.y * per, j1 = min(Np, j0 + per);
-    for (int j = j0 + threadIdx.x; j < j1; j += 1024) {
+    const int per = ((Np + ysplit - 1) / ysplit + 63) & ~63;
+    const int jlo = by * per, jhi = min(Np, jlo + per);
+    for (int j = jlo + threadIdx.x; j < jhi; j += 1024) {
         float x = 0.f, y = 0.f, z = 0.f, n = 3.0e38f;
         if (j < N) {
             x = pb[j * 3]; y = pb[j * 3 + 1]; z = pb[j * 3 + 2];
@@ -698,7 +711,7 @@ __global__ __launch_bounds__(1024) void chamfer_feat_kernel(const float* __restr
             }
         }
     }
-    if (blockIdx.y != 0) return;
+    if (by != 0) return;
     nv = wave_max_u(nv);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = nv;
     __syncthreads();
@@ -709,70 +722,150 @@ __global__ __launch_bounds__(1024) void chamfer_feat_kernel(const float* __restr
     }
 }
 
-// Queries the filter could not decide (idx == -1: three or more 32-target blocks within the error band,
-// a handful per launch) are resolved exactly here.  One workgroup per 256 queries; workgroups without a
-// marked query leave at once, the others scan all targets with all 256 lanes per marked query.
+// Queries the filter could not decide (another 32-target block within the error band of the best one: 0.2-2 %
+// of them at C3) are listed per sample by the filter kernel and resolved exactly here.  A workgroup takes CF_Q
+// listed queries of ONE sample at a time, so every target it loads (feature planes: SoA, coalesced float4 loads,
+// 16 targets per lane in flight) serves CF_Q queries — one query per workgroup re-read the whole target cloud per query, 216 MB
+// of L2 traffic per launch at C3.  Per lane and query: minimum d2, its first index, the runner-up value; only if
+// some other d2 lies within a few ulp of the minimum (it could share the sqrt) a second pass compares square roots.
 constexpr int CF_THREADS = 256;
+constexpr int CF_Q = 4;
+constexpr int CF_UNROLL = 4;
+constexpr int CF_GROUPS = 16;                      // workgroups per sample
 
-__global__ __launch_bounds__(CF_THREADS) void chamfer_fixup_kernel(const float* __restrict__ qpts,
-                                                                   const float* __restrict__ tpts, int Nq, int Nt,
-                                                                   float* __restrict__ out_dist,
-                                                                   int32_t* __restrict__ out_idx) {
-    __shared__ int marked[CF_THREADS];
-    __shared__ int nmarked;
-    __shared__ float redf[4];
-    __shared__ int redi[4];
-    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float* qb = qpts + (size_t)b * Nq * 3;
-    const float* tb = tpts + (size_t)b * Nt * 3;
-    int32_t* oi = out_idx + (size_t)b * Nq;
-    float* od = out_dist + (size_t)b * Nq;
-    if (threadIdx.x == 0) nmarked = 0;
-    __syncthreads();
-    const int qi = blockIdx.x * CF_THREADS + threadIdx.x;
-    if (qi < Nq && oi[qi] < 0) marked[atomicAdd(&nmarked, 1)] = qi;
-    __syncthreads();
-    const int nm = nmarked;
-    for (int k = 0; k < nm; ++k) {
-        const int q = marked[k];
-        const float qx = qb[q * 3], qy = qb[q * 3 + 1], qz = qb[q * 3 + 2];
-        float m = __builtin_inff();
-        for (int base = 0; base < Nt; base += 4 * CF_THREADS) {
-            float x[4], y[4], z[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = min(base + u * CF_THREADS + (int)threadIdx.x, Nt - 1);
-                x[u] = tb[j * 3]; y[u] = tb[j * 3 + 1]; z[u] = tb[j * 3 + 2];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) m = fminf(m, dist2_exact(qx, qy, qz, x[u], y[u], z[u]));
+// list layout: count[B] then entries[B][Nq] (query numbers of sample b)
+struct FixJob {           // one direction of a Chamfer call
+    const float* F; int Nq, Nt, Ntp;
+    float* out_dist; int32_t* out_idx; const int* undecided;
+};
+
+// list layout (ints): count[pad4(B)], then entries[B][Nq] of 16 bytes: (query number, x, y, z)
+__device__ __host__ inline int pad4(int n) { return (n + 3) & ~3; }
+
+// 1-D grid of 2 * B * CF_GROUPS workgroups.  Workgroups are dealt round-robin to the 8 XCDs; the filter kernel
+// runs sample b on XCD b / (B/8) (its own remap), where the sample's list, planes and outputs now sit in L2 —
+// read from any other XCD each of the dependent loads below costs ~2 us.  So the linear id is decoded such
+// that (sample, group, direction) lands on that XCD again (speed only: any placement is correct).
+__global__ __launch_bounds__(CF_THREADS) void chamfer_fixup_kernel(const FixJob j0, const FixJob j1, int B) {
+    int b, grp, dir;
+    {
+        const int id = blockIdx.x, per = B >> 3;
+        if ((B & 7) == 0) {
+            const int xcd = id & 7, r = id >> 3;
+            b = xcd * per + r % per;
+            grp = (r / per) % CF_GROUPS;
+            dir = r / (per * CF_GROUPS);
+        } else {
+            b = id % B; grp = (id / B) % CF_GROUPS; dir = id / (B * CF_GROUPS);
         }
-        m = wave_min_u(m);
-        if (lane == 0) redf[wave] = m;
-        __syncthreads();
-        m = fminf(fminf(redf[0], redf[1]), fminf(redf[2], redf[3]));
-        const float s = sqrtf(m), lim = m * (1.0f + 1.0e-6f);
-        int loc = 0x7fffffff;
-        for (int base = 0; base < Nt; base += 4 * CF_THREADS) {
-            float x[4], y[4], z[4];
+    }
+    const bool other = dir != 0;
+    const float* __restrict__ F = other ? j1.F : j0.F;
+    const int Nq = other ? j1.Nq : j0.Nq, Nt = other ? j1.Nt : j0.Nt, Ntp = other ? j1.Ntp : j0.Ntp;
+    float* __restrict__ out_dist = other ? j1.out_dist : j0.out_dist;
+    int32_t* __restrict__ out_idx = other ? j1.out_idx : j0.out_idx;
+    const int* __restrict__ undecided = other ? j1.undecided : j0.undecided;
+    __shared__ float redf[CF_Q][4];
+    __shared__ int redi[CF_Q][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int4* list = reinterpret_cast<const int4*>(undecided + pad4(B)) + (size_t)b * Nq;
+    // the count and the first group of entries are read together (entries past the count are stale but in bounds)
+    int4 ent[CF_Q];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = min(base + u * CF_THREADS + (int)threadIdx.x, Nt - 1);
-                x[u] = tb[j * 3]; y[u] = tb[j * 3 + 1]; z[u] = tb[j * 3 + 2];
+    for (int c = 0; c < CF_Q; ++c) ent[c] = list[min(grp * CF_Q + c, Nq - 1)];
+    const int count = undecided[b];
+    const float* fx = F + (size_t)b * 4 * Ntp;
+    const float* fy = fx + Ntp;
+    const float* fz = fy + Ntp;
+    for (int k0 = grp * CF_Q; k0 < count; k0 += CF_GROUPS * CF_Q) {
+        int q[CF_Q];
+        float qx[CF_Q], qy[CF_Q], qz[CF_Q], best[CF_Q], second[CF_Q];
+        int bi[CF_Q];
+        if (k0 != grp * CF_Q) {
+#pragma unroll
+            for (int c = 0; c < CF_Q; ++c) ent[c] = list[min(k0 + c, count - 1)];
+        }
+#pragma unroll
+        for (int c = 0; c < CF_Q; ++c) {
+            const int4 e = (k0 + c < count) ? ent[c] : ent[0];        // a short last group repeats a listed query
+            q[c] = e.x; qx[c] = __int_as_float(e.y); qy[c] = __int_as_float(e.z); qz[c] = __int_as_float(e.w);
+            best[c] = __builtin_inff(); second[c] = __builtin_inff(); bi[c] = 0x7fffffff;
+        }
+        // float4 plane loads: 4 consecutive targets per load, CF_UNROLL x 3 loads in flight per lane (the planes are
+        // padded to Ntp, a multiple of 64, with sentinel rows that never win; loads are clamped inside them)
+        const int n4 = Ntp >> 2;
+        for (int base = threadIdx.x; base < n4; base += CF_UNROLL * CF_THREADS) {
+            float4 x[CF_UNROLL], y[CF_UNROLL], z[CF_UNROLL];
+#pragma unroll
+            for (int u = 0; u < CF_UNROLL; ++u) {
+                const int g4 = min(base + u * CF_THREADS, n4 - 1);
+                x[u] = reinterpret_cast<const float4*>(fx)[g4];
+                y[u] = reinterpret_cast<const float4*>(fy)[g4];
+                z[u] = reinterpret_cast<const float4*>(fz)[g4];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = base + u * CF_THREADS + (int)threadIdx.x;
-                const float d2 = dist2_exact(qx, qy, qz, x[u], y[u], z[u]);
-                if (j < Nt && d2 <= lim && sqrtf(d2) == s) loc = min(loc, j);
+            for (int u = 0; u < CF_UNROLL; ++u) {
+                const int j0 = (base + u * CF_THREADS) * 4;
+                const float xs[4] = {x[u].x, x[u].y, x[u].z, x[u].w}, ys[4] = {y[u].x, y[u].y, y[u].z, y[u].w};
+                const float zs[4] = {z[u].x, z[u].y, z[u].z, z[u].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int j = j0 + e;
+#pragma unroll
+                    for (int c = 0; c < CF_Q; ++c) {
+                        const float d = j < Nt ? dist2_exact(qx[c], qy[c], qz[c], xs[e], ys[e], zs[e]) : __builtin_inff();
+                        second[c] = __builtin_amdgcn_fmed3f(best[c], second[c], d);   // a duplicate minimum counts as runner-up
+                        bi[c] = d < best[c] ? j : bi[c];
+                        best[c] = fminf(best[c], d);
+                    }
+                }
             }
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) loc = min(loc, __shfl_xor(loc, o, 64));
-        if (lane == 0) redi[wave] = loc;
+        for (int c = 0; c < CF_Q; ++c) {
+            const float mw = wave_min_u(best[c]);
+            if (lane == 0) redf[c][wave] = mw;
+        }
         __syncthreads();
-        if (threadIdx.x == 0) { od[q] = s; oi[q] = min(min(redi[0], redi[1]), min(redi[2], redi[3])); }
+        float s[CF_Q], lim[CF_Q];
+        int loc[CF_Q];
+        bool close = false;
+#pragma unroll
+        for (int c = 0; c < CF_Q; ++c) {
+            const float m = fminf(fminf(redf[c][0], redf[c][1]), fminf(redf[c][2], redf[c][3]));
+            s[c] = sqrtf(m); lim[c] = m * (1.0f + 1.0e-6f);
+            // another lane's minimum within a few ulp of m can share its sqrt: that lane's candidate is known (bi),
+            // no rescan needed.  Only two candidates inside ONE lane (runner-up within the limit too) need the rescan.
+            loc[c] = (best[c] == m || (best[c] <= lim[c] && sqrtf(best[c]) == s[c])) ? bi[c] : 0x7fffffff;
+            close |= second[c] <= lim[c];
+        }
+        if (__syncthreads_or(close)) {
+            for (int j = threadIdx.x; j < Nt; j += CF_THREADS) {
+                const float x = fx[j], y = fy[j], z = fz[j];
+#pragma unroll
+                for (int c = 0; c < CF_Q; ++c) {
+                    const float d = dist2_exact(qx[c], qy[c], qz[c], x, y, z);
+                    if (d <= lim[c] && sqrtf(d) == s[c]) loc[c] = min(loc[c], j);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CF_Q; ++c) {
+            int l = loc[c];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) l = min(l, __shfl_xor(l, o, 64));
+            if (lane == 0) redi[c][wave] = l;
+        }
         __syncthreads();
+        if (threadIdx.x < CF_Q && k0 + (int)threadIdx.x < count) {
+            const int c = threadIdx.x;
+            float sc = s[0]; int qc = q[0];
+#pragma unroll
+            for (int e = 1; e < CF_Q; ++e) { sc = c == e ? s[e] : sc; qc = c == e ? q[e] : qc; }
+            out_dist[(size_t)b * Nq + qc] = sc;
+            out_idx[(size_t)b * Nq + qc] = min(min(redi[c][0], redi[c][1]), min(redi[c][2], redi[c][3]));
+        }
+        __syncthreads();                                   // redf / redi are rewritten by the next group
     }
 }
 
@@ -804,7 +897,8 @@ __global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_kernel(const float* 
                                                                    const unsigned short* __restrict__ H,
                                                                    const unsigned int* __restrict__ nmax, int Nq,
                                                                    int Nt, int Ntp, int gx, float* __restrict__ out_dist,
-                                                                   int32_t* __restrict__ out_idx) {
+                                                                   int32_t* __restrict__ out_idx, int* __restrict__ undecided,
+                                                                   int nsamples) {
     // 1-D grid of gx * B workgroups.  Workgroups are dealt round-robin over the 8 XCDs (L2 is per XCD), so the
     // linear id is remapped such that all workgroups of a sample land on ONE XCD and stream its target rows
     // out of that XCD's L2 (speed only: any placement is correct).
@@ -824,24 +918,30 @@ __global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_kernel(const float* 
     const float bq1 = half ? 1.0f : -2.0f * az;
     // A operand (M x K): lane supplies A[i = lane%32][k = lane/32] from the feature planes (through LDS)
 
-    // smallest / second / third smallest block minimum of this lane's half, with the blocks of the first two
-    float best = __builtin_inff(), second = __builtin_inff(), third = __builtin_inff();
-    int blk = 0, blk2 = 0;
+    // smallest and second smallest block minimum of this lane's half and the block of the smallest.  (Tracking the
+    // second block and a third value too cost 8 VALU instructions per block instead of 4, in a loop that is bound
+    // by VALU issue; queries whose runner-up block is within the error band now go to the fix-up list instead.)
+    float best = __builtin_inff(), second = __builtin_inff();
+    int blk = 0;
 // branch-free selects (the compiler otherwise turns the index updates into exec-mask branches)
 #define CM_SEL(dst, cond_mask, a, b) asm volatile("v_cndmask_b32 %0, %1, %2, %3" : "=v"(dst) : "v"(b), "v"(a), "s"(cond_mask))
-#define CM_UPDATE(m, tb0)                                                                  \
+#define CM_UPDATE(m, tb0)                                                                      \
     {                                                                                          \
         const int t_ = (tb0);                                                                  \
-        unsigned long long k1_, k2_;                                                           \
+        unsigned long long k1_;                                                                \
         asm volatile("v_cmp_lt_f32 %0, %1, %2" : "=s"(k1_) : "v"(m), "v"(best));               \
-        asm volatile("v_cmp_lt_f32 %0, %1, %2" : "=s"(k2_) : "v"(m), "v"(second));             \
-        third = __builtin_amdgcn_fmed3f(second, third, (m));                                   \
         second = __builtin_amdgcn_fmed3f(best, second, (m));                                   \
-        int sel_;                                                                              \
-        CM_SEL(sel_, k2_, t_, blk2);      /* c2 ? t : blk2 */                                  \
-        CM_SEL(blk2, k1_, blk, sel_);     /* c1 ? blk : sel */                                 \
         CM_SEL(blk, k1_, t_, blk);        /* c1 ? t : blk */                                   \
-        asm volatile("v_min_f32 %0, %1, %2" : "=v"(best) : "v"(best), "v"(m));                    \
+        asm volatile("v_min_f32 %0, %1, %2" : "=v"(best) : "v"(best), "v"(m));                 \
+    }
+// the same with the block number inside the tile as an inline constant (no v_mov of the index per block)
+#define CM_UPDATE_C(m, J)                                                                      \
+    {                                                                                          \
+        unsigned long long k1_;                                                                \
+        asm volatile("v_cmp_lt_f32 %0, %1, %2" : "=s"(k1_) : "v"(m), "v"(best));               \
+        second = __builtin_amdgcn_fmed3f(best, second, (m));                                   \
+        asm volatile("v_cndmask_b32 %0, %1, " #J ", %2" : "=v"(blkc) : "v"(blkc), "s"(k1_));   \
+        asm volatile("v_min_f32 %0, %1, %2" : "=v"(best) : "v"(best), "v"(m));                 \
     }
     const float* Fb = F + (size_t)b * 4 * Ntp;
     const f16v zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -905,38 +1005,41 @@ __global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_kernel(const float* 
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, o.hi), bqB, acc, 0, 0, 0);
             return acc;
         };
+        static_assert(CM_TILE16 == 256, "the tile loop below is unrolled for 8 blocks per tile");
+#define CM_PAIR(oa, ob, JA, JB)                                                                \
+    {                                                                                          \
+        const f16v accA = block(oa), accB = block(ob);                                         \
+        const float mA = min16(accA), mB = min16(accB);                                        \
+        CM_UPDATE_C(mA, JA)                                                                    \
+        CM_UPDATE_C(mB, JB)                                                                    \
+    }
         Pre pre = fetch(0);
         stash(0, pre);
         __syncthreads();
-        int buf = 0;
+        int buf = 0, blkc = 0;
         for (int t0 = 0; t0 < Ntp; t0 += CM_TILE16, buf ^= 1) {
             const bool more = t0 + CM_TILE16 < Ntp;
             if (more) pre = fetch(t0 + CM_TILE16);     // in flight during the MFMA loop, stored to LDS after it
-            const int nblk = min(CM_TILE16, Ntp - t0) >> 5;
+            const int nblk = min(CM_TILE16, Ntp - t0) >> 5;          // 2, 4, 6 or 8 (Ntp is a multiple of 64)
             const unsigned char* T = &tileH[buf][jq * CM_ROWB + half * 16];
-            // blocks in groups of 4 with two operand register sets in ping-pong (no register rotation copies);
-            // nblk is even, a trailing half group re-reads in-tile rows and discards them
-            Ops a0 = rd(T, 0), a1 = rd(T, 1);
-            for (int u = 0; u < nblk; u += 4) {
-                const bool tail = u + 2 >= nblk;
-                const Ops b0 = rd(T, tail ? u : u + 2), b1 = rd(T, tail ? u + 1 : u + 3);
-                {
-                    const f16v accA = block(a0), accB = block(a1);
-                    const float mA = min16(accA), mB = min16(accB);
-                    CM_UPDATE(mA, t0 + u * 32)
-                    CM_UPDATE(mB, t0 + u * 32 + 32)
-                }
-                if (u + 4 < nblk) { a0 = rd(T, u + 4); a1 = rd(T, u + 5); }
-                if (!tail) {
-                    const f16v accA = block(b0), accB = block(b1);
-                    const float mA = min16(accA), mB = min16(accB);
-                    CM_UPDATE(mA, t0 + u * 32 + 64)
-                    CM_UPDATE(mB, t0 + u * 32 + 96)
+            const float before = best;
+            // two operand register sets in ping-pong; rows past nblk are in the tile, read and not used
+            Ops a0 = rd(T, 0), a1 = rd(T, 1), b0 = rd(T, 2), b1 = rd(T, 3);
+            CM_PAIR(a0, a1, 0, 1)
+            if (nblk > 2) {
+                a0 = rd(T, 4); a1 = rd(T, 5);
+                CM_PAIR(b0, b1, 2, 3)
+                if (nblk > 4) {
+                    b0 = rd(T, 6); b1 = rd(T, 7);
+                    CM_PAIR(a0, a1, 4, 5)
+                    if (nblk > 6) CM_PAIR(b0, b1, 6, 7)
                 }
             }
+            blk = best < before ? t0 + (blkc << 5) : blk;            // the tile improved this lane's minimum
             if (more) stash(buf ^ 1, pre);
             __syncthreads();
         }
+#undef CM_PAIR
     } else {
     // The 4 waves of the workgroup scan the same targets: feature tiles of CM_TILE targets go through LDS
     // (double buffered: the next tile's loads are in flight while this one feeds the matrix pipe).
@@ -989,30 +1092,23 @@ __global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_kernel(const float* 
         __syncthreads();                            // everybody done with `buf`, next tile landed
     }
     }
-    // merge the two half-waves that share a query (they saw disjoint halves of every block): the two best
-    // DISTINCT blocks K, K2 and a lower bound T for the minimum of every other block
-    int K, K2;
-    float Bv, V2, T;
+    // merge the two half-waves that share a query (they saw disjoint halves of every block): the best block K and
+    // the exact smallest block minimum V2 among all the other blocks
+    int K;
+    float Bv, V2;
     {
-        const float ob = __shfl_xor(best, 32, 64), os = __shfl_xor(second, 32, 64), ot = __shfl_xor(third, 32, 64);
-        const int ok = __shfl_xor(blk, 32, 64), ok2 = __shfl_xor(blk2, 32, 64);
-        const float cv[4] = {best, second, ob, os};
-        const int ck[4] = {blk, blk2, ok, ok2};
+        const float ob = __shfl_xor(best, 32, 64), os = __shfl_xor(second, 32, 64);
+        const int ok = __shfl_xor(blk, 32, 64);
         Bv = fminf(best, ob);
         K = (ob < best || (ob == best && ok < blk)) ? ok : blk;
-        V2 = __builtin_inff(); K2 = K;
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-            if (ck[c] != K && (cv[c] < V2 || (cv[c] == V2 && ck[c] < K2))) { V2 = cv[c]; K2 = ck[c]; }
-        T = fminf(third, ot);
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-            if (ck[c] != K && ck[c] != K2) T = fminf(T, cv[c]);
+        V2 = fminf(K == blk ? second : best, K == ok ? os : ob);
     }
-    // exact finish: the 32 targets of block K (16 per lane of the pair), and of K2 when it is within the band
-    // this lane's 16 targets are contiguous in the (padded) feature planes: 4 float4 per coordinate
-    auto exact16 = [&](int base, float out[16]) -> float {
-        float mloc = __builtin_inff();
+    // exact finish: the 32 targets of block K (16 per lane of the pair).  This lane's 16 targets are contiguous in
+    // the (padded) feature planes: 4 float4 per coordinate
+    float d2[16];
+    float m2 = __builtin_inff();
+    {
+        const int base = K + half * 16;
         const float4* px4 = reinterpret_cast<const float4*>(Fb + base);
         const float4* py4 = reinterpret_cast<const float4*>(Fb + (size_t)Ntp + base);
         const float4* pz4 = reinterpret_cast<const float4*>(Fb + 2 * (size_t)Ntp + base);
@@ -1026,33 +1122,22 @@ __global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_kernel(const float* 
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
                 const int e = v * 4 + w;
-                out[e] = (base + e < Nt) ? dist2_exact(ax, ay, az, xs[w], ys[w], zs[w]) : __builtin_inff();
-                mloc = fminf(mloc, out[e]);
+                d2[e] = (base + e < Nt) ? dist2_exact(ax, ay, az, xs[w], ys[w], zs[w]) : __builtin_inff();
+                m2 = fminf(m2, d2[e]);
             }
         }
-        return mloc;
-    };
-    float d2[16];
-    float m2 = exact16(K + half * 16, d2);
+    }
     m2 = fminf(m2, __shfl_xor(m2, 32, 64));
-    // t = d2 - |a|^2 within E; exact d2 within 4e-7 relative: outside `band` nothing can win or tie
+    // t = d2 - |a|^2 within E; exact d2 within 4e-7 relative: a block whose filtered minimum lies outside `band`
+    // can neither win nor tie.  Otherwise the query is undecided here and goes to the fix-up list.
     const float na = ax * ax + ay * ay + az * az, nb = __uint_as_float(nmax[b]);
     const float E = (PREC == 1 ? CM_EPS_BF16 : CM_EPS) * (2.0f * sqrtf(na * nb) + nb + na);
-    const float band = 2.0f * E + 4.0e-6f * m2;
-    const bool need2 = !(V2 > Bv + band);
-    const bool ambiguous = !(T > Bv + band);
-    float e2[16];
-    const bool any2 = __ballot(need2) != 0ull;       // wave-level: about 6 % of the waves
-    if (any2) {
-        const float mk2 = exact16(K2 + half * 16, e2);
-        if (need2) m2 = fminf(m2, mk2);
-        else {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) e2[e] = __builtin_inff();
-        }
-        m2 = fminf(m2, __shfl_xor(m2, 32, 64));
-    }
-    float s = sqrtf(m2);
+    // m2 is exact, so the runner-up is compared with it rather than with the filtered value of the best block:
+    // only the runner-up's own filter error E remains (the band was 2E before; this halves the undecided queries).
+    // 4e-6 m2 covers the rounding of m2 and of |a|^2 and the width of a sqrt bucket.
+    const float band = E + 4.0e-6f * (m2 + na);
+    const bool ambiguous = !(V2 > (m2 - na) + band) || !(m2 - na <= Bv + band);
+    const float s = sqrtf(m2);
     // lowest index attaining the minimum; a different d2 can only share the sqrt if it lies within a few ulp
     // of it, which is rare: only then are the sqrt values compared
     const float lim = m2 * (1.0f + 1.0e-6f);
@@ -1063,24 +1148,18 @@ __global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_kernel(const float* 
         if (d2[e] == m2) idx = K + half * 16 + e;
         near_tie |= (d2[e] != m2) && (d2[e] <= lim);
     }
-    if (any2) {
-#pragma unroll
-        for (int e = 15; e >= 0; --e) {
-            if (e2[e] == m2) idx = min(idx, K2 + half * 16 + e);
-            near_tie |= (e2[e] != m2) && (e2[e] <= lim);
-        }
-    }
     if (__ballot(near_tie)) {
 #pragma unroll
-        for (int e = 15; e >= 0; --e) {
+        for (int e = 15; e >= 0; --e)
             if (d2[e] <= lim && sqrtf(d2[e]) == s) idx = min(idx, K + half * 16 + e);
-            if (any2 && e2[e] <= lim && sqrtf(e2[e]) == s) idx = min(idx, K2 + half * 16 + e);
-        }
     }
     idx = min(idx, __shfl_xor(idx, 32, 64));
     if (half == 0 && qi < Nq) {
         out_dist[(size_t)b * Nq + qi] = s;
-        out_idx[(size_t)b * Nq + qi] = ambiguous ? -1 : idx;      // -1: resolved by chamfer_fixup_kernel
+        out_idx[(size_t)b * Nq + qi] = idx;
+        if (ambiguous)                                             // resolved by chamfer_fixup_kernel
+            reinterpret_cast<int4*>(undecided + pad4(nsamples))[(size_t)b * Nq + atomicAdd(undecided + b, 1)] =
+                make_int4(qi, __float_as_int(ax), __float_as_int(ay), __float_as_int(az));
 #ifdef VPN_CHAMFER_DEBUG
         if (ambiguous) atomicAdd(&g_dbg[6], 1ull);
 #endif
@@ -1088,30 +1167,56 @@ __global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_kernel(const float* 
 }
 
 static inline int pad32(int n) { return (n + 63) & ~63; }   // feature planes padded to 64 targets (blocks are processed in pairs)
-// fp32 planes + bf16 rows + one tile of slack (the row tiles are fetched without bounds checks) + nmax
-static inline size_t mfma_ws_floats(int B, int N) { return (size_t)B * (4 + 16) * pad32(N) + (size_t)CM_TILE16 * 16 + (size_t)B; }
+// one direction: fp32 planes + bf16 rows of the targets + one tile of slack (the row tiles are fetched without
+// bounds checks) + nmax[pad4(B)] + the lists of undecided queries (count[pad4(B)], 16-byte entries[B][Nq])
+static inline size_t mfma_ws_floats(int B, int Nt, int Nq) {
+    return (size_t)B * (4 + 16) * pad32(Nt) + (size_t)CM_TILE16 * 16 + 2 * (size_t)pad4(B) + 4 * (size_t)B * Nq;   // multiple of 4 floats
+}
 
-// one direction: features of the targets -> filtered scan of the queries
-static int mfma_nn(const float* q, const float* t, int B, int Nq, int Nt, float* F, float* d, int32_t* idx,
-                   bool fp32_filter, hipStream_t s) {
-    const int Ntp = pad32(Nt);
-    unsigned short* Hrows = reinterpret_cast<unsigned short*>(F + (size_t)B * 4 * Ntp);     // [B][Ntp][32] bf16
-    unsigned int* nmax = reinterpret_cast<unsigned int*>(F + (size_t)B * 20 * Ntp + (size_t)CM_TILE16 * 16);
-    VPN_LAUNCH(chamfer_feat_kernel, dim3(B, Ntp >= 4096 ? 4 : (Ntp >= 1024 ? 2 : 1)), dim3(1024), 0, s, t, Nt, Ntp, F, nmax,
-               fp32_filter ? nullptr : Hrows);
+struct MfmaWs { float* F; unsigned short* H; unsigned int* nmax; int* undecided; int Ntp; };
+
+static MfmaWs mfma_carve(float* F, int B, int Nt) {
+    MfmaWs w;
+    w.Ntp = pad32(Nt);
+    w.F = F;
+    w.H = reinterpret_cast<unsigned short*>(F + (size_t)B * 4 * w.Ntp);                       // [B][Ntp][32] bf16
+    w.nmax = reinterpret_cast<unsigned int*>(F + (size_t)B * 20 * w.Ntp + (size_t)CM_TILE16 * 16);
+    w.undecided = reinterpret_cast<int*>(w.nmax + pad4(B));
+    return w;
+}
+
+// both directions: features of both clouds (one launch) -> filtered scan of p1 against p2 and of p2 against p1 ->
+// exact fix-up of the undecided queries of both (one launch)
+static int mfma_both(const float* p1, const float* p2, int B, int N, int M, float* ws, float* d1, int32_t* i1, float* d2,
+                     int32_t* i2, bool fp32_filter, hipStream_t s) {
+    const MfmaWs w2 = mfma_carve(ws, B, M);                               // p2 = targets of direction 1
+    const MfmaWs w1 = mfma_carve(ws + mfma_ws_floats(B, M, N), B, N);     // p1 = targets of direction 2
+    auto split = [](int Ntp) { return Ntp >= 4096 ? 4 : (Ntp >= 1024 ? 2 : 1); };
+    const FeatJob f2{p2, M, w2.Ntp, split(w2.Ntp), w2.F, w2.nmax, fp32_filter ? nullptr : w2.H, w2.undecided};
+    const FeatJob f1{p1, N, w1.Ntp, split(w1.Ntp), w1.F, w1.nmax, fp32_filter ? nullptr : w1.H, w1.undecided};
+    VPN_LAUNCH(chamfer_feat_kernel, dim3(B, f2.ysplit + f1.ysplit), dim3(1024), 0, s, f2, f1);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    const int gx = (Nq + 127) / 128;
-    if (fp32_filter)
-        VPN_LAUNCH(chamfer_nn_mfma_kernel<0>, dim3(gx * B), dim3(CM_BLOCK), 0, s, q, t, F, Hrows, nmax, Nq, Nt, Ntp, gx, d,
-                   idx);
-    else
-        VPN_LAUNCH(chamfer_nn_mfma_kernel<1>, dim3(gx * B), dim3(CM_BLOCK), 0, s, q, t, F, Hrows, nmax, Nq, Nt, Ntp, gx, d,
-                   idx);
-    e = hipGetLastError();
-    if (e != hipSuccess) return (int)e;
-    VPN_LAUNCH(chamfer_fixup_kernel, dim3((Nq + CF_THREADS - 1) / CF_THREADS, B), dim3(CF_THREADS), 0, s, q, t,
-                       Nq, Nt, d, idx);
+    for (int dir = 0; dir < 2; ++dir) {
+        const float* q = dir ? p2 : p1;
+        const float* t = dir ? p1 : p2;
+        const int Nq = dir ? M : N, Nt = dir ? N : M;
+        const MfmaWs& w = dir ? w1 : w2;
+        float* d = dir ? d2 : d1;
+        int32_t* idx = dir ? i2 : i1;
+        const int gx = (Nq + 127) / 128;
+        if (fp32_filter)
+            VPN_LAUNCH(chamfer_nn_mfma_kernel<0>, dim3(gx * B), dim3(CM_BLOCK), 0, s, q, t, w.F, w.H, w.nmax, Nq, Nt, w.Ntp, gx,
+                       d, idx, w.undecided, B);
+        else
+            VPN_LAUNCH(chamfer_nn_mfma_kernel<1>, dim3(gx * B), dim3(CM_BLOCK), 0, s, q, t, w.F, w.H, w.nmax, Nq, Nt, w.Ntp, gx,
+                       d, idx, w.undecided, B);
+        e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+    }
+    const FixJob x1{w2.F, N, M, w2.Ntp, d1, i1, w2.undecided};
+    const FixJob x2{w1.F, M, N, w1.Ntp, d2, i2, w1.undecided};
+    VPN_LAUNCH(chamfer_fixup_kernel, dim3(2 * B * CF_GROUPS), dim3(CF_THREADS), 0, s, x1, x2, B);
     e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
@@ -1221,7 +1326,7 @@ extern "C" int vpn_chamfer_bwd(const float* p1, const float* p2, const float* di
 extern "C" size_t vpn_chamfer_workspace(int B, int N, int M) {
     if (B <= 0 || N <= 0 || M <= 0) return 0;
     const size_t pruned = cloud_ws_floats(B, N) + cloud_ws_floats(B, M);
-    const size_t mfma = mfma_ws_floats(B, N) + mfma_ws_floats(B, M);
+    const size_t mfma = mfma_ws_floats(B, M, N) + mfma_ws_floats(B, N, M);
     return (pruned > mfma ? pruned : mfma) * sizeof(float);
 }
 
@@ -1232,7 +1337,7 @@ extern "C" int vpn_chamfer_fwd_ws(const float* p1, const float* p2, int B, int N
                                   float* dist2, int32_t* idx2, void* workspace, int mode, void* stream) {
     if (!p1 || !p2 || !dist1 || !idx1 || !dist2 || !idx2) return VPN_E_BADARG;
     if (B <= 0 || N <= 0 || M <= 0) return VPN_E_BADARG;
-    if (B > 65535) return VPN_E_TOOBIG;
+    if (B > 65535 || (long long)B * N > 0x7fffffffLL || (long long)B * M > 0x7fffffffLL) return VPN_E_TOOBIG;
     if (mode == 0) mode = chamfer_mode();
     // automatic: the MFMA-filtered scan for large clouds (measured 1.3x the brute-force scan at C3), brute force
     // for small ones or without a workspace; the box-pruned scan stays opt-in
@@ -1244,11 +1349,7 @@ extern "C" int vpn_chamfer_fwd_ws(const float* p1, const float* p2, int B, int N
         return nn_dispatch(p2, p1, B, M, N, dist2, idx2, s);
     }
     if (mode == 3 || mode == 4) {
-        float* F2 = (float*)workspace;                           // features of p2 (targets of direction 1)
-        float* F1 = F2 + mfma_ws_floats(B, M);                   // features of p1 (targets of direction 2)
-        int rc = mfma_nn(p1, p2, B, N, M, F2, dist1, idx1, mode == 4, s);
-        if (rc) return rc;
-        return mfma_nn(p2, p1, B, M, N, F1, dist2, idx2, mode == 4, s);
+        return mfma_both(p1, p2, B, N, M, (float*)workspace, dist1, idx1, dist2, idx2, mode == 4, s);
     }
     float* cur = (float*)workspace;
     CloudWs w1 = carve(cur, B, N), w2 = carve(cur, B, M);
