@@ -651,74 +651,84 @@ __device__ inline void split3_bf16(float x, unsigned short p[3]) {
     p[2] = (unsigned short)(__float_as_uint(r2) >> 16);
 }
 
-// feature planes F[b][4][Np] = (x, y, z, |p|^2) (padded with a never-winning sentinel), nmax[b] = max |p|^2.
-// One workgroup per sample (no atomics, no memset): lanes stride over the points.
+// feature planes F[b][4][Np] = (x, y, z, |p|^2) (padded with a never-winning sentinel) and
 // H[b][Np][32] bf16 rows for the bf16 filter: per coordinate the target pieces (b1 b1 b2 b1 b3 b2) that pair
 // with the query pieces (a1 a2 a1 a3 a1 a2), then the three pieces of |p|^2 (paired with 1.0), then zeros.
-struct FeatJob {          // one cloud: grid.y slices [0, ysplit) of the launch belong to it
+// nmax[b][CFEAT_SLOTS]: max |p|^2 of each workgroup's slice (the filter takes the max of the slots: no atomics,
+// no zero-initialised output, no workgroup that scans the whole cloud).
+constexpr int CFEAT_THREADS = 256;
+constexpr int CFEAT_SLOTS = 16;                    // workgroups per cloud and sample, at most
+constexpr int CFEAT_PTS = 4;                       // points per lane in flight
+
+struct FeatJob {          // one cloud: slices [0, ysplit) of a sample's workgroups belong to it
     const float* pts; int N, Np, ysplit;
     float* F; unsigned int* nmax; unsigned short* H; int* undecided;
 };
 
-// One launch converts both clouds of a Chamfer call (every launch costs ~8 us here, whatever it does).
-__global__ __launch_bounds__(1024) void chamfer_feat_kernel(const FeatJob j0, const FeatJob j1) {
-    __shared__ float red[16];
-    const bool other = (int)blockIdx.y >= j0.ysplit;
+// One launch converts both clouds of a Chamfer call.  1-D grid of B * (j0.ysplit + j1.ysplit) workgroups, decoded
+// such that sample b runs on XCD b / (B/8) — where the filter kernel will read what is written here (its own remap).
+__global__ __launch_bounds__(CFEAT_THREADS) void chamfer_feat_kernel(const FeatJob j0, const FeatJob j1, int B) {
+    __shared__ float red[CFEAT_THREADS / 64];
+    int b, sy;
+    {
+        const int id = blockIdx.x, per = B >> 3, ys = j0.ysplit + j1.ysplit;
+        if ((B & 7) == 0) { const int xcd = id & 7, r = id >> 3; b = xcd * per + r % per; sy = r / per; }
+        else { b = id % B; sy = id / B; }
+        (void)ys;
+    }
+    const bool other = sy >= j0.ysplit;
     const float* __restrict__ pts = other ? j1.pts : j0.pts;
     const int N = other ? j1.N : j0.N, Np = other ? j1.Np : j0.Np, ysplit = other ? j1.ysplit : j0.ysplit;
     float* __restrict__ F = other ? j1.F : j0.F;
     unsigned int* __restrict__ nmax = other ? j1.nmax : j0.nmax;
     unsigned short* __restrict__ H = other ? j1.H : j0.H;
     int* __restrict__ undecided = other ? j1.undecided : j0.undecided;
-    const int by = (int)blockIdx.y - (other ? j0.ysplit : 0);
-    const int b = blockIdx.x;
+    const int by = sy - (other ? j0.ysplit : 0);
     if (by == 0 && threadIdx.x == 0) undecided[b] = 0;     // this sample's list: the scan that follows appends to it
+    if (by == 0 && (int)threadIdx.x >= ysplit && threadIdx.x < CFEAT_SLOTS) nmax[b * CFEAT_SLOTS + threadIdx.x] = 0u;
     const float* pb = pts + (size_t)b * N * 3;
     float* f = F + (size_t)b * 4 * Np;
     float nv = 0.f;
-    // gridDim.y workgroups share a sample: each converts its slice; the max norm is cheap enough that
-    // workgroup 0 simply scans the whole cloud for it (no atomics, no zero-initialised output)
-    if (by == 0)
-        for (int j = threadIdx.x; j < N; j += 1024) {
-            const float x = pb[j * 3], y = pb[j * 3 + 1], z = pb[j * 3 + 2];
-            nv = fmaxf(nv, x * x + y * y + z * z);
-        }
     const int per = ((Np + ysplit - 1) / ysplit + 63) & ~63;
     const int jlo = by * per, jhi = min(Np, jlo + per);
-    for (int j = jlo + threadIdx.x; j < jhi; j += 1024) {
-        float x = 0.f, y = 0.f, z = 0.f, n = 3.0e38f;
-        if (j < N) {
-            x = pb[j * 3]; y = pb[j * 3 + 1]; z = pb[j * 3 + 2];
-            n = x * x + y * y + z * z;
+    for (int j0p = jlo + threadIdx.x; j0p < jhi; j0p += CFEAT_PTS * CFEAT_THREADS) {
+        float xs[CFEAT_PTS], ys[CFEAT_PTS], zs[CFEAT_PTS];
+#pragma unroll
+        for (int u = 0; u < CFEAT_PTS; ++u) {
+            const int j = min(j0p + u * CFEAT_THREADS, N - 1);
+            xs[u] = pb[j * 3]; ys[u] = pb[j * 3 + 1]; zs[u] = pb[j * 3 + 2];
         }
-        f[j] = x; f[Np + j] = y; f[2 * Np + j] = z; f[3 * Np + j] = n;
-        if (H) {
-            unsigned short px[3], py[3], pz[3], pn[3], row[32];
-            split3_bf16(x, px); split3_bf16(y, py); split3_bf16(z, pz); split3_bf16(n, pn);
-            const int BI[6] = {0, 0, 1, 0, 2, 1};
 #pragma unroll
-            for (int t = 0; t < 6; ++t) { row[t] = px[BI[t]]; row[6 + t] = py[BI[t]]; row[12 + t] = pz[BI[t]]; }
-            row[18] = pn[0]; row[19] = pn[1]; row[20] = pn[2];
-#pragma unroll
-            for (int t = 21; t < 32; ++t) row[t] = 0;
-            uint4* dst = reinterpret_cast<uint4*>(H + ((size_t)b * Np + j) * 32);
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                uint4 v;
-                v.x = row[qd * 8 + 0] | ((unsigned)row[qd * 8 + 1] << 16); v.y = row[qd * 8 + 2] | ((unsigned)row[qd * 8 + 3] << 16);
-                v.z = row[qd * 8 + 4] | ((unsigned)row[qd * 8 + 5] << 16); v.w = row[qd * 8 + 6] | ((unsigned)row[qd * 8 + 7] << 16);
-                dst[qd] = v;
+        for (int u = 0; u < CFEAT_PTS; ++u) {
+            const int j = j0p + u * CFEAT_THREADS;
+            if (j >= jhi) break;
+            float x = 0.f, y = 0.f, z = 0.f, n = 3.0e38f;
+            if (j < N) {
+                x = xs[u]; y = ys[u]; z = zs[u];
+                n = x * x + y * y + z * z;
+                nv = fmaxf(nv, n);
+            }
+            f[j] = x; f[Np + j] = y; f[2 * Np + j] = z; f[3 * Np + j] = n;
+            if (H) {
+                unsigned short px[3], py[3], pz[3], pn[3];
+                split3_bf16(x, px); split3_bf16(y, py); split3_bf16(z, pz); split3_bf16(n, pn);
+                auto pk = [](unsigned short lo, unsigned short hi) { return (unsigned)lo | ((unsigned)hi << 16); };
+                // K slots: x (b1 b1 b2 b1 b3 b2), y (...), z (...), |p|^2 (3 pieces), 11 zeros
+                uint4* dst = reinterpret_cast<uint4*>(H + ((size_t)b * Np + j) * 32);
+                dst[0] = make_uint4(pk(px[0], px[0]), pk(px[1], px[0]), pk(px[2], px[1]), pk(py[0], py[0]));
+                dst[1] = make_uint4(pk(py[1], py[0]), pk(py[2], py[1]), pk(pz[0], pz[0]), pk(pz[1], pz[0]));
+                dst[2] = make_uint4(pk(pz[2], pz[1]), pk(pn[0], pn[1]), pk(pn[2], 0), 0u);
+                dst[3] = make_uint4(0u, 0u, 0u, 0u);
             }
         }
     }
-    if (by != 0) return;
     nv = wave_max_u(nv);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = nv;
     __syncthreads();
     if (threadIdx.x == 0) {
         float m = red[0];
-        for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w]);
-        nmax[b] = __float_as_uint(m);
+        for (int w = 1; w < CFEAT_THREADS / 64; ++w) m = fmaxf(m, red[w]);
+        nmax[b * CFEAT_SLOTS + by] = __float_as_uint(m);
     }
 }
 
@@ -1130,7 +1140,10 @@ __global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_kernel(const float* 
     m2 = fminf(m2, __shfl_xor(m2, 32, 64));
     // t = d2 - |a|^2 within E; exact d2 within 4e-7 relative: a block whose filtered minimum lies outside `band`
     // can neither win nor tie.  Otherwise the query is undecided here and goes to the fix-up list.
-    const float na = ax * ax + ay * ay + az * az, nb = __uint_as_float(nmax[b]);
+    float nb = 0.0f;
+#pragma unroll
+    for (int w = 0; w < CFEAT_SLOTS; ++w) nb = fmaxf(nb, __uint_as_float(nmax[b * CFEAT_SLOTS + w]));
+    const float na = ax * ax + ay * ay + az * az;
     const float E = (PREC == 1 ? CM_EPS_BF16 : CM_EPS) * (2.0f * sqrtf(na * nb) + nb + na);
     // m2 is exact, so the runner-up is compared with it rather than with the filtered value of the best block:
     // only the runner-up's own filter error E remains (the band was 2E before; this halves the undecided queries).
@@ -1168,9 +1181,9 @@ __global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_kernel(const float* 
 
 static inline int pad32(int n) { return (n + 63) & ~63; }   // feature planes padded to 64 targets (blocks are processed in pairs)
 // one direction: fp32 planes + bf16 rows of the targets + one tile of slack (the row tiles are fetched without
-// bounds checks) + nmax[pad4(B)] + the lists of undecided queries (count[pad4(B)], 16-byte entries[B][Nq])
+// bounds checks) + nmax[B][CFEAT_SLOTS] + the lists of undecided queries (count[pad4(B)], 16-byte entries[B][Nq])
 static inline size_t mfma_ws_floats(int B, int Nt, int Nq) {
-    return (size_t)B * (4 + 16) * pad32(Nt) + (size_t)CM_TILE16 * 16 + 2 * (size_t)pad4(B) + 4 * (size_t)B * Nq;   // multiple of 4 floats
+    return (size_t)B * (4 + 16) * pad32(Nt) + (size_t)CM_TILE16 * 16 + (size_t)B * CFEAT_SLOTS + (size_t)pad4(B) + 4 * (size_t)B * Nq;   // multiple of 4 floats
 }
 
 struct MfmaWs { float* F; unsigned short* H; unsigned int* nmax; int* undecided; int Ntp; };
@@ -1181,7 +1194,7 @@ static MfmaWs mfma_carve(float* F, int B, int Nt) {
     w.F = F;
     w.H = reinterpret_cast<unsigned short*>(F + (size_t)B * 4 * w.Ntp);                       // [B][Ntp][32] bf16
     w.nmax = reinterpret_cast<unsigned int*>(F + (size_t)B * 20 * w.Ntp + (size_t)CM_TILE16 * 16);
-    w.undecided = reinterpret_cast<int*>(w.nmax + pad4(B));
+    w.undecided = reinterpret_cast<int*>(w.nmax + (size_t)B * CFEAT_SLOTS);
     return w;
 }
 
@@ -1191,10 +1204,10 @@ static int mfma_both(const float* p1, const float* p2, int B, int N, int M, floa
                      int32_t* i2, bool fp32_filter, hipStream_t s) {
     const MfmaWs w2 = mfma_carve(ws, B, M);                               // p2 = targets of direction 1
     const MfmaWs w1 = mfma_carve(ws + mfma_ws_floats(B, M, N), B, N);     // p1 = targets of direction 2
-    auto split = [](int Ntp) { return Ntp >= 4096 ? 4 : (Ntp >= 1024 ? 2 : 1); };
+    auto split = [](int Ntp) { const int y = (Ntp + 1023) / 1024; return y > CFEAT_SLOTS ? CFEAT_SLOTS : y; };
     const FeatJob f2{p2, M, w2.Ntp, split(w2.Ntp), w2.F, w2.nmax, fp32_filter ? nullptr : w2.H, w2.undecided};
     const FeatJob f1{p1, N, w1.Ntp, split(w1.Ntp), w1.F, w1.nmax, fp32_filter ? nullptr : w1.H, w1.undecided};
-    VPN_LAUNCH(chamfer_feat_kernel, dim3(B, f2.ysplit + f1.ysplit), dim3(1024), 0, s, f2, f1);
+    VPN_LAUNCH(chamfer_feat_kernel, dim3(B * (f2.ysplit + f1.ysplit)), dim3(CFEAT_THREADS), 0, s, f2, f1, B);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     for (int dir = 0; dir < 2; ++dir) {
