@@ -197,7 +197,7 @@ def _chamfer_exact(vpn, p1, p2, torch_sqrt_too=True):
     CPU sqrt (MKL VML, <= 1 ulp, see vpn_oracle.chamfer_nn_ieee) indices must still agree and
     distances agree to 1 ulp."""
     m1, j1, m2, j2 = O.chamfer_nn_ieee(p1, p2)
-    for mode in ('brute', 'pruned', 'mfma', 'mfma32'):   # every scan strategy must give the same bits
+    for mode in ('brute', 'pruned', 'mfma', 'mfma32', 'sorted'):   # every scan strategy must give the same bits
         d1, i1, d2, i2 = vpn.chamfer_nn(g(p1), g(p2), mode=mode)
         assert torch.equal(i1.cpu().long(), j1), 'argmin direction 1 differs (%s)' % mode
         assert torch.equal(i2.cpu().long(), j2), 'argmin direction 2 differs (%s)' % mode
@@ -211,7 +211,7 @@ def _chamfer_exact(vpn, p1, p2, torch_sqrt_too=True):
 @pytest.mark.parametrize('name', ['g4_chamfer_b4_n128_m96', 'g4_chamfer_b2_n257_m2048', 'g4_chamfer_ties'])
 def test_chamfer_golden(vpn, name):
     gd = load_golden(name)
-    for mode in ('brute', 'pruned', 'mfma', 'mfma32'):
+    for mode in ('brute', 'pruned', 'mfma', 'mfma32', 'sorted'):
         d1, i1, d2, i2 = vpn.chamfer_nn(g(gd['p1']), g(gd['p2']), mode=mode)
         assert torch.equal(i1.cpu(), gd['idx1']) and torch.equal(i2.cpu(), gd['idx2'])
     assert torch.equal(i1.cpu(), gd['idx1']) and torch.equal(i2.cpu(), gd['idx2'])
@@ -325,9 +325,20 @@ def test_chamfer_full_size_properties(vpn):
     e1, j1, e2, j2 = vpn.chamfer_nn(p1, p2, mode='brute')
     assert torch.equal(d1, e1) and torch.equal(i1, j1) and torch.equal(d2, e2) and torch.equal(i2, j2), \
         'pruned and brute-force scans disagree'
-    f1, k1, f2, k2 = vpn.chamfer_nn(p1, p2, mode='mfma')
-    assert torch.equal(f1, e1) and torch.equal(k1, j1) and torch.equal(f2, e2) and torch.equal(k2, j2), \
-        'mfma-filtered and brute-force scans disagree'
+    for mode in ('mfma', 'sorted'):
+        f1, k1, f2, k2 = vpn.chamfer_nn(p1, p2, mode=mode)
+        assert torch.equal(f1, e1) and torch.equal(k1, j1) and torch.equal(f2, e2) and torch.equal(k2, j2), \
+            '%s-filtered and brute-force scans disagree' % mode
+    # clustered clouds (points on a few small spheres, the shape of the real workload): the box pruning of the
+    # sorted scan actually skips most blocks here
+    c = torch.rand(B, 32, 3, generator=gen) * 0.7 - 0.35
+    u = torch.randn(B, N, 3, generator=gen)
+    q1 = g(c.repeat_interleave(N // 32, 1) + 0.08 * u / u.norm(dim=-1, keepdim=True))
+    a1, b1, a2, b2 = vpn.chamfer_nn(q1, p2, mode='brute')
+    for mode in ('mfma', 'sorted'):
+        f1, k1, f2, k2 = vpn.chamfer_nn(q1, p2, mode=mode)
+        assert torch.equal(f1, a1) and torch.equal(k1, b1) and torch.equal(f2, a2) and torch.equal(k2, b2), \
+            '%s-filtered and brute-force scans disagree on clustered clouds' % mode
     # (1) the reported distance is the distance to the reported index (same fp32 expression)
     def dist_to(a, b, idx):
         diff = a - torch.gather(b, 1, idx.long()[..., None].expand(-1, -1, 3))

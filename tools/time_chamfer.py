@@ -1,5 +1,6 @@
 import sys, torch
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import vpn_amd
 from bench import synth_inputs
 dev = torch.device('cuda')

@@ -747,6 +747,7 @@ constexpr int CF_GROUPS = 16;                      // workgroups per sample
 struct FixJob {           // one direction of a Chamfer call
     const float* F; int Nq, Nt, Ntp;
     float* out_dist; int32_t* out_idx; const int* undecided;
+    const int32_t* perm;  // planes in Morton order: perm[b][pos] = original target index (NULL: planes in original order)
 };
 
 // list layout (ints): count[pad4(B)], then entries[B][Nq] of 16 bytes: (query number, x, y, z)
@@ -775,6 +776,7 @@ __global__ __launch_bounds__(CF_THREADS) void chamfer_fixup_kernel(const FixJob 
     float* __restrict__ out_dist = other ? j1.out_dist : j0.out_dist;
     int32_t* __restrict__ out_idx = other ? j1.out_idx : j0.out_idx;
     const int* __restrict__ undecided = other ? j1.undecided : j0.undecided;
+    const int32_t* __restrict__ perm = other ? j1.perm : j0.perm;
     __shared__ float redf[CF_Q][4];
     __shared__ int redi[CF_Q][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -787,6 +789,7 @@ __global__ __launch_bounds__(CF_THREADS) void chamfer_fixup_kernel(const FixJob 
     const float* fx = F + (size_t)b * 4 * Ntp;
     const float* fy = fx + Ntp;
     const float* fz = fy + Ntp;
+    const int32_t* pm = perm ? perm + (size_t)b * Ntp : nullptr;
     for (int k0 = grp * CF_Q; k0 < count; k0 += CF_GROUPS * CF_Q) {
         int q[CF_Q];
         float qx[CF_Q], qy[CF_Q], qz[CF_Q], best[CF_Q], second[CF_Q];
@@ -806,18 +809,21 @@ __global__ __launch_bounds__(CF_THREADS) void chamfer_fixup_kernel(const FixJob 
         const int n4 = Ntp >> 2;
         for (int base = threadIdx.x; base < n4; base += CF_UNROLL * CF_THREADS) {
             float4 x[CF_UNROLL], y[CF_UNROLL], z[CF_UNROLL];
+            int4 o[CF_UNROLL];
 #pragma unroll
             for (int u = 0; u < CF_UNROLL; ++u) {
                 const int g4 = min(base + u * CF_THREADS, n4 - 1);
                 x[u] = reinterpret_cast<const float4*>(fx)[g4];
                 y[u] = reinterpret_cast<const float4*>(fy)[g4];
                 z[u] = reinterpret_cast<const float4*>(fz)[g4];
+                o[u] = pm ? reinterpret_cast<const int4*>(pm)[g4] : make_int4(g4 * 4, g4 * 4 + 1, g4 * 4 + 2, g4 * 4 + 3);
             }
 #pragma unroll
             for (int u = 0; u < CF_UNROLL; ++u) {
                 const int j0 = (base + u * CF_THREADS) * 4;
                 const float xs[4] = {x[u].x, x[u].y, x[u].z, x[u].w}, ys[4] = {y[u].x, y[u].y, y[u].z, y[u].w};
                 const float zs[4] = {z[u].x, z[u].y, z[u].z, z[u].w};
+                const int os[4] = {o[u].x, o[u].y, o[u].z, o[u].w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int j = j0 + e;
@@ -825,7 +831,8 @@ __global__ __launch_bounds__(CF_THREADS) void chamfer_fixup_kernel(const FixJob 
                     for (int c = 0; c < CF_Q; ++c) {
                         const float d = j < Nt ? dist2_exact(qx[c], qy[c], qz[c], xs[e], ys[e], zs[e]) : __builtin_inff();
                         second[c] = __builtin_amdgcn_fmed3f(best[c], second[c], d);   // a duplicate minimum counts as runner-up
-                        bi[c] = d < best[c] ? j : bi[c];
+                        // lowest ORIGINAL index among equal minima (in original order that is simply the first one)
+                        bi[c] = (d < best[c] || (pm && d == best[c] && os[e] < bi[c])) ? os[e] : bi[c];
                         best[c] = fminf(best[c], d);
                     }
                 }
@@ -852,10 +859,11 @@ __global__ __launch_bounds__(CF_THREADS) void chamfer_fixup_kernel(const FixJob 
         if (__syncthreads_or(close)) {
             for (int j = threadIdx.x; j < Nt; j += CF_THREADS) {
                 const float x = fx[j], y = fy[j], z = fz[j];
+                const int oj = pm ? pm[j] : j;
 #pragma unroll
                 for (int c = 0; c < CF_Q; ++c) {
                     const float d = dist2_exact(qx[c], qy[c], qz[c], x, y, z);
-                    if (d <= lim[c] && sqrtf(d) == s[c]) loc[c] = min(loc[c], j);
+                    if (d <= lim[c] && sqrtf(d) == s[c]) loc[c] = min(loc[c], oj);
                 }
             }
         }
@@ -1179,22 +1187,357 @@ __global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_kernel(const float* 
     }
 }
 
+// =====================================================================================
+// Sorted + pruned variant of the matrix-pipe filter (mode 5).
+//
+// Both clouds are put in Morton order once (chamfer_sortfeat_kernel: feature planes, bf16 rows, permutation and a
+// bounding box per 32-target block, all in sorted order).  A wave then owns 32 CONSECUTIVE SORTED queries — a
+// compact set with a box — and runs the same two-MFMA block filter only over the target blocks whose box can
+// still hold a target as near as the wave's worst current best: first the nearest block, then, 64 blocks at a
+// time, every block with  box-to-box distance^2 <= max_q(best_q) (+ the filter error and a rounding margin).
+// A skipped block can neither win nor tie (same argument as CP_PRUNE_MARGIN above).  Each wave streams its
+// blocks straight from L2 with a 4-deep prefetch ring; there are no LDS tiles and no workgroup barriers.
+// The exact finish and the undecided list are those of chamfer_nn_mfma_kernel, on ORIGINAL indices.
+// =====================================================================================
+constexpr int CS_THREADS = 1024;
+constexpr int CS_BOXF = 8;                         // floats per block box: lo xyz, hi xyz, 2 pad
+
+struct SortJob {
+    const float* pts; int N, Np;
+    float* F; unsigned int* nmax; unsigned short* H; int* undecided; int32_t* perm; float* boxes;
+};
+
+__device__ inline void write_row(unsigned short* H, size_t row, float x, float y, float z, float n) {
+    unsigned short px[3], py[3], pz[3], pn[3];
+    split3_bf16(x, px); split3_bf16(y, py); split3_bf16(z, pz); split3_bf16(n, pn);
+    auto pk = [](unsigned short lo, unsigned short hi) { return (unsigned)lo | ((unsigned)hi << 16); };
+    uint4* dst = reinterpret_cast<uint4*>(H + row * 32);
+    dst[0] = make_uint4(pk(px[0], px[0]), pk(px[1], px[0]), pk(px[2], px[1]), pk(py[0], py[0]));
+    dst[1] = make_uint4(pk(py[1], py[0]), pk(py[2], py[1]), pk(pz[0], pz[0]), pk(pz[1], pz[0]));
+    dst[2] = make_uint4(pk(pz[2], pz[1]), pk(pn[0], pn[1]), pk(pn[2], 0), 0u);
+    dst[3] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+// 1-D grid of 2 * B workgroups (both clouds of a Chamfer call), sample b on XCD b / (B/8) like the other kernels.
+__global__ __launch_bounds__(CS_THREADS) void chamfer_sortfeat_kernel(const SortJob j0, const SortJob j1, int B) {
+    __shared__ int hist[CP_CELLS];
+    __shared__ float red[7][CS_THREADS / 64];
+    __shared__ float bb[7];
+    __shared__ int wtot[CS_THREADS / 64];
+    int b, which;
+    {
+        const int id = blockIdx.x, per = B >> 3;
+        if ((B & 7) == 0) { const int xcd = id & 7, r = id >> 3; b = xcd * per + r % per; which = r / per; }
+        else { b = id % B; which = id / B; }
+    }
+    const bool other = which != 0;
+    const float* __restrict__ pts = other ? j1.pts : j0.pts;
+    const int N = other ? j1.N : j0.N, Np = other ? j1.Np : j0.Np;
+    float* __restrict__ F = other ? j1.F : j0.F;
+    unsigned int* __restrict__ nmax = other ? j1.nmax : j0.nmax;
+    unsigned short* __restrict__ H = other ? j1.H : j0.H;
+    int* __restrict__ undecided = other ? j1.undecided : j0.undecided;
+    int32_t* __restrict__ perm = other ? j1.perm : j0.perm;
+    float* __restrict__ boxes = other ? j1.boxes : j0.boxes;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* p = pts + (size_t)b * N * 3;
+    if (tid == 0) undecided[b] = 0;
+    // ---- bounding box and max norm
+    float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    float nv = 0.0f;
+    for (int i = tid; i < N; i += CS_THREADS) {
+        const float x = p[i * 3], y = p[i * 3 + 1], z = p[i * 3 + 2];
+        lo[0] = fminf(lo[0], x); hi[0] = fmaxf(hi[0], x);
+        lo[1] = fminf(lo[1], y); hi[1] = fmaxf(hi[1], y);
+        lo[2] = fminf(lo[2], z); hi[2] = fmaxf(hi[2], z);
+        nv = fmaxf(nv, x * x + y * y + z * z);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        // wave_min_u / wave_max_u order floats as given (DPP fmin/fmax): fine for signed values too
+        const float l = wave_min_u(lo[a]), h = wave_max_u(hi[a]);
+        if (lane == 0) { red[a][wave] = l; red[3 + a][wave] = h; }
+    }
+    {
+        const float m = wave_max_u(nv);
+        if (lane == 0) red[6][wave] = m;
+    }
+    for (int i = tid; i < CP_CELLS; i += CS_THREADS) hist[i] = 0;
+    __syncthreads();
+    if (tid < 7) {
+        float v = red[tid][0];
+        for (int w = 1; w < CS_THREADS / 64; ++w) v = tid < 3 ? fminf(v, red[tid][w]) : fmaxf(v, red[tid][w]);
+        bb[tid] = v;
+    }
+    __syncthreads();
+    if (tid < CFEAT_SLOTS) nmax[b * CFEAT_SLOTS + tid] = tid == 0 ? __float_as_uint(bb[6]) : 0u;
+    float sc[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) sc[a] = bb[3 + a] > bb[a] ? 15.99f / (bb[3 + a] - bb[a]) : 0.0f;
+    auto key_of = [&](float x, float y, float z) -> unsigned {
+        const unsigned cx = (unsigned)min(15, max(0, (int)((x - bb[0]) * sc[0])));
+        const unsigned cy = (unsigned)min(15, max(0, (int)((y - bb[1]) * sc[1])));
+        const unsigned cz = (unsigned)min(15, max(0, (int)((z - bb[2]) * sc[2])));
+        return spread4(cx) | (spread4(cy) << 1) | (spread4(cz) << 2);
+    };
+    // ---- counting sort by Morton cell (the order inside a cell is whatever the LDS atomics give: every
+    //      grouping is exact, the results do not depend on it)
+    for (int i = tid; i < N; i += CS_THREADS) atomicAdd(&hist[key_of(p[i * 3], p[i * 3 + 1], p[i * 3 + 2])], 1);
+    __syncthreads();
+    {
+        static_assert(CP_CELLS == 4 * CS_THREADS, "4 cells per lane in the prefix sum");
+        const int h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+        const int sum4 = h0 + h1 + h2 + h3;
+        int inc = sum4;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t2 = __shfl_up(inc, o, 64); if (lane >= o) inc += t2; }
+        if (lane == 63) wtot[wave] = inc;
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < wave; ++w) base += wtot[w];
+        const int ex = base + inc - sum4;
+        hist[4 * tid] = ex; hist[4 * tid + 1] = ex + h0; hist[4 * tid + 2] = ex + h0 + h1; hist[4 * tid + 3] = ex + h0 + h1 + h2;
+    }
+    __syncthreads();
+    float* f = F + (size_t)b * 4 * Np;
+    int32_t* po = perm + (size_t)b * Np;
+    for (int i = tid; i < Np; i += CS_THREADS) {
+        float x = 0.f, y = 0.f, z = 0.f, n = 3.0e38f;      // padding: a sentinel that never wins, kept at the end
+        int pos = i;
+        if (i < N) {
+            x = p[i * 3]; y = p[i * 3 + 1]; z = p[i * 3 + 2];
+            n = x * x + y * y + z * z;
+            pos = atomicAdd(&hist[key_of(x, y, z)], 1);
+        }
+        f[pos] = x; f[Np + pos] = y; f[2 * Np + pos] = z; f[3 * Np + pos] = n;
+        po[pos] = i < N ? i : 0x7fffffff;
+        write_row(H, (size_t)b * Np + pos, x, y, z, n);
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- a box per block of 32 consecutive sorted points (padding excluded; an all-padding block gets an empty
+    //      box, +inf / -inf, whose distance to anything is +inf)
+    const int nb32 = Np >> 5;
+    for (int c = wave; c < nb32; c += CS_THREADS / 64) {
+        const int j = c * 32 + (lane & 31);
+        const bool ok = j < N;
+        const float x = ok ? f[j] : 0.f, y = ok ? f[Np + j] : 0.f, z = ok ? f[2 * Np + j] : 0.f;
+        const float inf = __builtin_inff();
+        const float lx = wave_min_u(ok ? x : inf), ly = wave_min_u(ok ? y : inf), lz = wave_min_u(ok ? z : inf);
+        const float hx = wave_max_u(ok ? x : -inf), hy = wave_max_u(ok ? y : -inf), hz = wave_max_u(ok ? z : -inf);
+        if (lane == 0) {
+            float4* o = reinterpret_cast<float4*>(boxes + ((size_t)b * nb32 + c) * CS_BOXF);
+            o[0] = make_float4(lx, ly, lz, hx);
+            o[1] = make_float4(hy, hz, 0.f, 0.f);
+        }
+    }
+}
+
+constexpr int CPR_RING = 4;                        // blocks in flight per wave
+
+__global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_pruned_kernel(
+    const float* __restrict__ Fq, const int32_t* __restrict__ permq, int Nqp,      // queries: sorted planes + permutation
+    const float* __restrict__ F, const unsigned short* __restrict__ H, const unsigned int* __restrict__ nmax,
+    const int32_t* __restrict__ permt, const float* __restrict__ boxes,           // targets, sorted
+    int Nq, int Nt, int Ntp, int gx, float* __restrict__ out_dist, int32_t* __restrict__ out_idx,
+    int* __restrict__ undecided, int nsamples) {
+    int vid = blockIdx.x;
+    {
+        const int G = gridDim.x, per = G >> 3;
+        if (vid < (per << 3)) vid = (vid & 7) * per + (vid >> 3);
+    }
+    const int b = vid / gx, bx = vid - b * gx;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, jq = lane & 31, half = lane >> 5;
+    const int pos = (bx * 4 + wave) * 32 + jq;                     // sorted position of this lane's query
+    if ((bx * 4 + wave) * 32 >= Nq) return;                        // whole wave past the end (no barriers in here)
+    const int pc = min(pos, Nq - 1);
+    const float* fq = Fq + (size_t)b * 4 * Nqp;
+    const float ax = fq[pc], ay = fq[Nqp + pc], az = fq[2 * Nqp + pc];
+    float best = __builtin_inff(), second = __builtin_inff();
+    int blk = 0;
+    const float* Fb = F + (size_t)b * 4 * Ntp;
+    const f16v zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    bf8 bqA, bqB;
+    {
+        unsigned short qx[3], qy[3], qz[3];
+        split3_bf16(-2.0f * ax, qx); split3_bf16(-2.0f * ay, qy); split3_bf16(-2.0f * az, qz);
+        auto slot = [&](int k) -> unsigned short {
+            const int c = k / 6, t = k % 6;
+            const int pi = (t == 1 || t == 5) ? 1 : (t == 3 ? 2 : 0);
+            if (k < 18) {
+                const unsigned short v0 = c == 0 ? qx[0] : (c == 1 ? qy[0] : qz[0]);
+                const unsigned short v1 = c == 0 ? qx[1] : (c == 1 ? qy[1] : qz[1]);
+                const unsigned short v2 = c == 0 ? qx[2] : (c == 1 ? qy[2] : qz[2]);
+                return pi == 0 ? v0 : (pi == 1 ? v1 : v2);
+            }
+            return k < 21 ? (unsigned short)0x3F80 : (unsigned short)0;
+        };
+        us8 ua, ub;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const unsigned short lo0 = slot(e), hi0 = slot(8 + e), lo1 = slot(16 + e), hi1 = slot(24 + e);
+            ua[e] = half ? hi0 : lo0;
+            ub[e] = half ? hi1 : lo1;
+        }
+        bqA = __builtin_bit_cast(bf8, ua); bqB = __builtin_bit_cast(bf8, ub);
+    }
+    float nb = 0.0f;
+#pragma unroll
+    for (int w = 0; w < CFEAT_SLOTS; ++w) nb = fmaxf(nb, __uint_as_float(nmax[b * CFEAT_SLOTS + w]));
+    const float na = ax * ax + ay * ay + az * az;
+    const float E = CM_EPS_BF16 * (2.0f * sqrtf(na * nb) + nb + na);
+    // box of the wave's queries (lanes past the end repeat the last query)
+    const float qlx = wave_min_u(ax), qly = wave_min_u(ay), qlz = wave_min_u(az);
+    const float qhx = wave_max_u(ax), qhy = wave_max_u(ay), qhz = wave_max_u(az);
+    const int nblk = Ntp >> 5;
+    const float* bxs = boxes + (size_t)b * nblk * CS_BOXF;
+    auto box_d2 = [&](int k) -> float {            // squared distance between the query box and the box of block k
+        const float4 u = *reinterpret_cast<const float4*>(bxs + (size_t)k * CS_BOXF);
+        const float4 v = *reinterpret_cast<const float4*>(bxs + (size_t)k * CS_BOXF + 4);
+        const float dx = fmaxf(0.0f, fmaxf(u.x - qhx, qlx - u.w));
+        const float dy = fmaxf(0.0f, fmaxf(u.y - qhy, qly - v.x));
+        const float dz = fmaxf(0.0f, fmaxf(u.z - qhz, qlz - v.y));
+        return dx * dx + dy * dy + dz * dz;
+    };
+    const unsigned char* Hb = reinterpret_cast<const unsigned char*>(H) + (size_t)b * Ntp * 64 + jq * 64 + half * 16;
+    struct Ops { float4 lo, hi; };
+    auto ld = [&](int k) -> Ops {
+        const unsigned char* r = Hb + (size_t)k * 2048;
+        return Ops{*reinterpret_cast<const float4*>(r), *reinterpret_cast<const float4*>(r + 32)};
+    };
+    auto process = [&](const Ops& o, int k) {
+        f16v acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, o.lo), bqA, zero, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, o.hi), bqB, acc, 0, 0, 0);
+        const float m = min16(acc);
+        CM_UPDATE(m, k << 5)
+    };
+    // ---- the nearest block first
+    int home;
+    {
+        float hb = __builtin_inff();
+        int hk = 0;
+        for (int k = lane; k < nblk; k += 64) {
+            const float d = box_d2(k);
+            if (d < hb) { hb = d; hk = k; }
+        }
+        const float m = wave_min_u(hb);
+        const unsigned long long at = __ballot(hb == m);
+        home = __builtin_amdgcn_readlane(hk, (int)__builtin_ctzll(at));
+        process(ld(home), home);
+    }
+    // ---- then, 64 blocks at a time, every block that can still matter
+    for (int base = 0; base < nblk; base += 64) {
+        const int k = base + lane;
+        const float d = k < nblk ? box_d2(k) : __builtin_inff();
+        const float bq = fminf(best, __shfl_xor(best, 32, 64));               // this query's best over both halves
+        const float T = wave_max_u(bq + na + E);                              // >= the final d2 of every query here
+        unsigned long long m = __ballot(k < nblk && k != home && d <= T * (1.0f + 4.0e-6f));
+        const int cnt = __builtin_popcountll(m);
+#ifdef VPN_CHAMFER_DEBUG
+        if (lane == 0) { atomicAdd(&g_dbg[0], (unsigned long long)cnt); atomicAdd(&g_dbg[1], (unsigned long long)min(64, nblk - base)); }
+#endif
+        Ops ring[CPR_RING];
+        int kk[CPR_RING];
+#pragma unroll
+        for (int r = 0; r < CPR_RING; ++r) {
+            kk[r] = 0;
+            if (r < cnt) { kk[r] = base + (int)__builtin_ctzll(m); m &= m - 1; ring[r] = ld(kk[r]); }
+        }
+        for (int i = 0; i < cnt; i += CPR_RING) {
+#pragma unroll
+            for (int r = 0; r < CPR_RING; ++r) {
+                if (i + r < cnt) {
+                    process(ring[r], kk[r]);
+                    if (i + r + CPR_RING < cnt) { kk[r] = base + (int)__builtin_ctzll(m); m &= m - 1; ring[r] = ld(kk[r]); }
+                }
+            }
+        }
+    }
+    // ---- merge the half-waves, exact finish of the best block (as in chamfer_nn_mfma_kernel), original indices
+    int K;
+    float Bv, V2;
+    {
+        const float ob = __shfl_xor(best, 32, 64), os = __shfl_xor(second, 32, 64);
+        const int ok = __shfl_xor(blk, 32, 64);
+        Bv = fminf(best, ob);
+        K = (ob < best || (ob == best && ok < blk)) ? ok : blk;
+        V2 = fminf(K == blk ? second : best, K == ok ? os : ob);
+    }
+    float d2[16];
+    int og[16];
+    float m2 = __builtin_inff();
+    {
+        const int base = K + half * 16;
+        const float4* px4 = reinterpret_cast<const float4*>(Fb + base);
+        const float4* py4 = reinterpret_cast<const float4*>(Fb + (size_t)Ntp + base);
+        const float4* pz4 = reinterpret_cast<const float4*>(Fb + 2 * (size_t)Ntp + base);
+        const int4* pm4 = reinterpret_cast<const int4*>(permt + (size_t)b * Ntp + base);
+        float4 X[4], Y[4], Z[4];
+        int4 P[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { X[v] = px4[v]; Y[v] = py4[v]; Z[v] = pz4[v]; P[v] = pm4[v]; }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const float xs[4] = {X[v].x, X[v].y, X[v].z, X[v].w}, ys[4] = {Y[v].x, Y[v].y, Y[v].z, Y[v].w};
+            const float zs[4] = {Z[v].x, Z[v].y, Z[v].z, Z[v].w};
+            const int ps[4] = {P[v].x, P[v].y, P[v].z, P[v].w};
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const int e = v * 4 + w;
+                og[e] = ps[w];                                          // 0x7fffffff on padding rows
+                d2[e] = (base + e < Nt) ? dist2_exact(ax, ay, az, xs[w], ys[w], zs[w]) : __builtin_inff();
+                m2 = fminf(m2, d2[e]);
+            }
+        }
+    }
+    m2 = fminf(m2, __shfl_xor(m2, 32, 64));
+    const float band = E + 4.0e-6f * (m2 + na);
+    const bool ambiguous = !(V2 > (m2 - na) + band) || !(m2 - na <= Bv + band);
+    const float s = sqrtf(m2);
+    const float lim = m2 * (1.0f + 1.0e-6f);
+    int idx = 0x7fffffff;
+    bool near_tie = false;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        if (d2[e] == m2) idx = min(idx, og[e]);
+        near_tie |= (d2[e] != m2) && (d2[e] <= lim);
+    }
+    if (__ballot(near_tie)) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            if (d2[e] <= lim && sqrtf(d2[e]) == s) idx = min(idx, og[e]);
+    }
+    idx = min(idx, __shfl_xor(idx, 32, 64));
+    if (half == 0 && pos < Nq) {
+        const int oq = permq[(size_t)b * Nqp + pos];                    // original query number
+        out_dist[(size_t)b * Nq + oq] = s;
+        out_idx[(size_t)b * Nq + oq] = idx;
+        if (ambiguous)
+            reinterpret_cast<int4*>(undecided + pad4(nsamples))[(size_t)b * Nq + atomicAdd(undecided + b, 1)] =
+                make_int4(oq, __float_as_int(ax), __float_as_int(ay), __float_as_int(az));
+    }
+}
+
 static inline int pad32(int n) { return (n + 63) & ~63; }   // feature planes padded to 64 targets (blocks are processed in pairs)
 // one direction: fp32 planes + bf16 rows of the targets + one tile of slack (the row tiles are fetched without
 // bounds checks) + nmax[B][CFEAT_SLOTS] + the lists of undecided queries (count[pad4(B)], 16-byte entries[B][Nq])
 static inline size_t mfma_ws_floats(int B, int Nt, int Nq) {
-    return (size_t)B * (4 + 16) * pad32(Nt) + (size_t)CM_TILE16 * 16 + (size_t)B * CFEAT_SLOTS + (size_t)pad4(B) + 4 * (size_t)B * Nq;   // multiple of 4 floats
+    return (size_t)B * (4 + 16) * pad32(Nt) + (size_t)CM_TILE16 * 16 + (size_t)B * CFEAT_SLOTS + (size_t)pad4(B) + 4 * (size_t)B * Nq
+           + (size_t)B * pad32(Nt) + (size_t)B * (pad32(Nt) / 32) * CS_BOXF;   // + permutation + block boxes (sorted mode); multiple of 4 floats
 }
 
-struct MfmaWs { float* F; unsigned short* H; unsigned int* nmax; int* undecided; int Ntp; };
+struct MfmaWs { float* F; unsigned short* H; unsigned int* nmax; int* undecided; int32_t* perm; float* boxes; int Ntp; };
 
-static MfmaWs mfma_carve(float* F, int B, int Nt) {
+static MfmaWs mfma_carve(float* F, int B, int Nt, int Nq) {
     MfmaWs w;
     w.Ntp = pad32(Nt);
     w.F = F;
     w.H = reinterpret_cast<unsigned short*>(F + (size_t)B * 4 * w.Ntp);                       // [B][Ntp][32] bf16
     w.nmax = reinterpret_cast<unsigned int*>(F + (size_t)B * 20 * w.Ntp + (size_t)CM_TILE16 * 16);
     w.undecided = reinterpret_cast<int*>(w.nmax + (size_t)B * CFEAT_SLOTS);
+    w.perm = reinterpret_cast<int32_t*>(w.undecided + pad4(B) + 4 * (size_t)B * Nq);
+    w.boxes = reinterpret_cast<float*>(w.perm + (size_t)B * w.Ntp);
     return w;
 }
 
@@ -1202,8 +1545,8 @@ static MfmaWs mfma_carve(float* F, int B, int Nt) {
 // exact fix-up of the undecided queries of both (one launch)
 static int mfma_both(const float* p1, const float* p2, int B, int N, int M, float* ws, float* d1, int32_t* i1, float* d2,
                      int32_t* i2, bool fp32_filter, hipStream_t s) {
-    const MfmaWs w2 = mfma_carve(ws, B, M);                               // p2 = targets of direction 1
-    const MfmaWs w1 = mfma_carve(ws + mfma_ws_floats(B, M, N), B, N);     // p1 = targets of direction 2
+    const MfmaWs w2 = mfma_carve(ws, B, M, N);                            // p2 = targets of direction 1
+    const MfmaWs w1 = mfma_carve(ws + mfma_ws_floats(B, M, N), B, N, M);  // p1 = targets of direction 2
     auto split = [](int Ntp) { const int y = (Ntp + 1023) / 1024; return y > CFEAT_SLOTS ? CFEAT_SLOTS : y; };
     const FeatJob f2{p2, M, w2.Ntp, split(w2.Ntp), w2.F, w2.nmax, fp32_filter ? nullptr : w2.H, w2.undecided};
     const FeatJob f1{p1, N, w1.Ntp, split(w1.Ntp), w1.F, w1.nmax, fp32_filter ? nullptr : w1.H, w1.undecided};
@@ -1227,8 +1570,8 @@ static int mfma_both(const float* p1, const float* p2, int B, int N, int M, floa
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
     }
-    const FixJob x1{w2.F, N, M, w2.Ntp, d1, i1, w2.undecided};
-    const FixJob x2{w1.F, M, N, w1.Ntp, d2, i2, w1.undecided};
+    const FixJob x1{w2.F, N, M, w2.Ntp, d1, i1, w2.undecided, nullptr};
+    const FixJob x2{w1.F, M, N, w1.Ntp, d2, i2, w1.undecided, nullptr};
     VPN_LAUNCH(chamfer_fixup_kernel, dim3(2 * B * CF_GROUPS), dim3(CF_THREADS), 0, s, x1, x2, B);
     e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
@@ -1258,11 +1601,39 @@ static int pruned_nn(const CloudWs& q, const CloudWs& t, int B, int Nq, int Nt, 
 
 // 0: automatic, 1: brute force, 2: box-pruned, 3: bf16 matrix-pipe filter, 4: fp32-MFMA filter
 // (VPN_CHAMFER_MODE=brute|pruned|mfma|mfma32 overrides the automatic choice)
+// mode 5: both clouds Morton-sorted (one launch: planes, rows, permutation, block boxes) -> pruned filtered scans
+// -> fix-up of the undecided queries on the sorted planes (one launch)
+static int mfma_sorted_both(const float* p1, const float* p2, int B, int N, int M, float* ws, float* d1, int32_t* i1,
+                            float* d2, int32_t* i2, hipStream_t s) {
+    const MfmaWs w2 = mfma_carve(ws, B, M, N);
+    const MfmaWs w1 = mfma_carve(ws + mfma_ws_floats(B, M, N), B, N, M);
+    const SortJob s2{p2, M, w2.Ntp, w2.F, w2.nmax, w2.H, w2.undecided, w2.perm, w2.boxes};
+    const SortJob s1{p1, N, w1.Ntp, w1.F, w1.nmax, w1.H, w1.undecided, w1.perm, w1.boxes};
+    VPN_LAUNCH(chamfer_sortfeat_kernel, dim3(2 * B), dim3(CS_THREADS), 0, s, s2, s1, B);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    for (int dir = 0; dir < 2; ++dir) {
+        const MfmaWs& wq = dir ? w2 : w1;             // the query cloud's own sorted planes
+        const MfmaWs& wt = dir ? w1 : w2;
+        const int Nq = dir ? M : N, Nt = dir ? N : M;
+        const int gx = (Nq + 127) / 128;
+        VPN_LAUNCH(chamfer_nn_mfma_pruned_kernel, dim3(gx * B), dim3(CM_BLOCK), 0, s, wq.F, wq.perm, wq.Ntp, wt.F, wt.H,
+                   wt.nmax, wt.perm, wt.boxes, Nq, Nt, wt.Ntp, gx, dir ? d2 : d1, dir ? i2 : i1, wt.undecided, B);
+        e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+    }
+    const FixJob x1{w2.F, N, M, w2.Ntp, d1, i1, w2.undecided, w2.perm};
+    const FixJob x2{w1.F, M, N, w1.Ntp, d2, i2, w1.undecided, w1.perm};
+    VPN_LAUNCH(chamfer_fixup_kernel, dim3(2 * B * CF_GROUPS), dim3(CF_THREADS), 0, s, x1, x2, B);
+    e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
 static int chamfer_mode() {
     static int mode = -1;
     if (mode < 0) {
         const char* e = getenv("VPN_CHAMFER_MODE");
-        mode = !e ? 0 : (e[0] == 'b' ? 1 : (e[0] == 'p' ? 2 : (e[0] == 'm' ? (strstr(e, "32") ? 4 : 3) : 0)));
+        mode = !e ? 0 : (e[0] == 'b' ? 1 : (e[0] == 'p' ? 2 : (e[0] == 'm' ? (strstr(e, "32") ? 4 : 3) : (e[0] == 's' ? 5 : 0))));
     }
     return mode;
 }
@@ -1364,6 +1735,7 @@ extern "C" int vpn_chamfer_fwd_ws(const float* p1, const float* p2, int B, int N
     if (mode == 3 || mode == 4) {
         return mfma_both(p1, p2, B, N, M, (float*)workspace, dist1, idx1, dist2, idx2, mode == 4, s);
     }
+    if (mode == 5) return mfma_sorted_both(p1, p2, B, N, M, (float*)workspace, dist1, idx1, dist2, idx2, s);
     float* cur = (float*)workspace;
     CloudWs w1 = carve(cur, B, N), w2 = carve(cur, B, M);
     VPN_LAUNCH(cloud_sort_kernel, dim3(B), dim3(1024), 0, s, p1, N, w1.sorted, w1.perm, w1.boxes, w1.C);
