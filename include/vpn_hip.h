@@ -192,6 +192,20 @@ int vpn_camera_transform_fwd(const float* points, const float* dists, const floa
 int vpn_camera_transform_bwd(const float* grad_out, const float* dists, const float* elevs, const float* azims,
                              const float* angles, int B, int N, int to_object, float* grad_points, void* stream);
 
+/* ---- head post-processing into packed primitive parameters (row f4)
+ * restrict_range + split + restrict_volumes of the reference's model (modules/network/vpnet_one_resnet.py:34-41,
+ * :67-85): volumes [B,3K], rotates [B,4K], translates [B,3K] (raw head outputs) -> params [B,K,10].
+ * is_sigmoid != 0 (config.py:25): v = (sigmoid(x) + 0.1) / restrict[j], q = sigmoid(x), t = tanh(x);
+ * else v = clamp(x, clamp_min + 1e-8, clamp_max) / restrict[j], q, t = clamp(x, -1, 1) (config.py:22-23, :26). */
+int vpn_head_pack_fwd(const float* volumes, const float* rotates, const float* translates, int B, int K,
+                      int is_sigmoid, float clamp_min, float clamp_max, float restrict0, float restrict1,
+                      float restrict2, float* params, void* stream);
+/* grad_params [B,K,10] -> gradients of the raw head outputs (any of the three may be NULL). */
+int vpn_head_pack_bwd(const float* volumes, const float* rotates, const float* translates, const float* grad_params,
+                      int B, int K, int is_sigmoid, float clamp_min, float clamp_max, float restrict0,
+                      float restrict1, float restrict2, float* grad_volumes, float* grad_rotates,
+                      float* grad_translates, void* stream);
+
 /* ---- Earth Mover's Distance, auction approximation (row f1)
  * Replaces emd.forward / emd.backward of the reference's CUDA extension (modules/loss/emd/emd_cuda.cu:228-282,
  * :302-316, bound in emd_module.py:56, :69).  xyz1, xyz2 [B,n,3] (the reference requires equal sizes,

@@ -501,3 +501,26 @@ def emd_backward(xyz1, xyz2, grad_dist, assignment):
     """NmDistanceGradKernel (emd_cuda.cu:284-300): grad_xyz1 = (2 g)(x1 - x2[assignment]); none for xyz2."""
     idx = assignment.long()[..., None].expand(-1, -1, 3)
     return (grad_dist * 2)[..., None] * (xyz1 - torch.gather(xyz2, 1, idx))
+
+
+# ----------------------------------------------------------------------------- head post-processing, row f4
+# PARITY UNPINNED in the strict sense: modules/network/vpnet_one_resnet.py imports torchvision (absent here), so its
+# static methods cannot be run; the three lines they consist of are restated below (torch's own sigmoid / tanh /
+# clamp, so the arithmetic is the reference's).
+
+def head_post_process(volumes, rotates, translates, is_sigmoid=True, clamp_min=0.01, clamp_max=0.8,
+                      volume_restrict=(8, 10, 10)):
+    """restrict_range (vpnet_one_resnet.py:67-77) -> split(3|4|3, dim=1) (:36-38) -> restrict_volumes (:79-85),
+    returned packed as (B,K,10) = (v, q, t) per primitive (the layout of sample_primitives / raster above)."""
+    if is_sigmoid:
+        v = torch.sigmoid(volumes) + 0.1
+        q = torch.sigmoid(rotates)
+        t = torch.tanh(translates)
+    else:
+        v = torch.clamp(volumes, min=clamp_min + 1e-8, max=clamp_max)
+        q = torch.clamp(rotates, min=-1, max=1)
+        t = torch.clamp(translates, min=-1, max=1)
+    B = volumes.shape[0]
+    K = volumes.shape[1] // 3
+    v = v.reshape(B, K, 3) / torch.tensor(list(volume_restrict), dtype=v.dtype)
+    return torch.cat([v, q.reshape(B, K, 4), t.reshape(B, K, 3)], dim=2)

@@ -4,6 +4,10 @@ SAMPLE_NUM = 128            # config.py:8
 CD_W1 = 1.0                 # config.py:11
 CD_W2 = 1.0                 # config.py:12
 MANUAL_SEED = 1234          # config.py:20
+VP_CLAMP_MIN = 0.01         # config.py:22
+VP_CLAMP_MAX = 0.8          # config.py:23
+IS_SIGMOID = True           # config.py:25
+VOLUME_RESTRICT = [8, 10, 10]   # config.py:26
 SILHOUETTE_LOSS_FUNC = 'L1'  # config.py:27
 CUBOID_NUM = 0              # config.py:33
 SPHERE_NUM = 16             # config.py:34

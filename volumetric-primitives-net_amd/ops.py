@@ -97,6 +97,40 @@ class TransformFunction(Function):
         return gp, gq, gt
 
 
+class HeadPackFunction(Function):
+    """restrict_range + split + restrict_volumes of the reference's model (vpnet_one_resnet.py:34-41, :67-85) fused:
+    raw head outputs volumes [B,3K], rotates [B,4K], translates [B,3K] -> packed params [B,K,10]."""
+
+    @staticmethod
+    def forward(ctx, volumes, rotates, translates, is_sigmoid, clamp_min, clamp_max, restrict):
+        volumes, rotates, translates = _f32c(volumes), _f32c(rotates), _f32c(translates)
+        B = volumes.shape[0]
+        assert volumes.shape[1] % 3 == 0
+        K = volumes.shape[1] // 3
+        assert rotates.shape == (B, 4 * K) and translates.shape == (B, 3 * K)
+        r = [float(x) for x in restrict]
+        assert len(r) == 3
+        params = torch.empty((B, K, PARAM_STRIDE), dtype=torch.float32, device=volumes.device)
+        _lib.call('vpn_head_pack_fwd', _lib.ptr(volumes), _lib.ptr(rotates), _lib.ptr(translates), B, K,
+                  int(bool(is_sigmoid)), float(clamp_min), float(clamp_max), r[0], r[1], r[2], _lib.ptr(params),
+                  _lib.stream())
+        ctx.save_for_backward(volumes, rotates, translates)
+        ctx.cfg = (B, K, int(bool(is_sigmoid)), float(clamp_min), float(clamp_max), r)
+        return params
+
+    @staticmethod
+    def backward(ctx, grad_params):
+        volumes, rotates, translates = ctx.saved_tensors
+        B, K, sig, cmin, cmax, r = ctx.cfg
+        g = _f32c(grad_params)
+        gv = torch.empty_like(volumes) if ctx.needs_input_grad[0] else None
+        gq = torch.empty_like(rotates) if ctx.needs_input_grad[1] else None
+        gt = torch.empty_like(translates) if ctx.needs_input_grad[2] else None
+        _lib.call('vpn_head_pack_bwd', _lib.ptr(volumes), _lib.ptr(rotates), _lib.ptr(translates), _lib.ptr(g), B, K, sig,
+                  cmin, cmax, r[0], r[1], r[2], _lib.ptr(gv), _lib.ptr(gq), _lib.ptr(gt), _lib.stream())
+        return gv, gq, gt, None, None, None, None
+
+
 class CameraTransformFunction(Function):
     """view_to_obj_points / obj_to_view_points (modules/transform/transform.py:21-73) in one launch.
     dists, elevs, azims, angles are dataset values (dataset.py:145-165): constants for autograd."""
