@@ -23,7 +23,8 @@ PER_FILE = {
     # bit-equal to the oracle's auction: same rounding rules as the Chamfer scan
     'emd.hip': ['-ffp-contract=off', '-fno-slp-vectorize'],     # packed fp32 is half rate: keep the scan scalar
     # the raster is compared with a 1e-4 tolerance: 1-ulp v_rcp/v_sqrt instead of the IEEE sequences
-    'raster.hip': ['-fno-hip-fp32-correctly-rounded-divide-sqrt'],
+    # -fgpu-flush-denormals-to-zero: no denormal-safe scaling around v_rcp / v_sqrt / v_exp
+    'raster.hip': ['-fno-hip-fp32-correctly-rounded-divide-sqrt', '-fgpu-flush-denormals-to-zero'],
 }
 
 

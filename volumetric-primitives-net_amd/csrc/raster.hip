@@ -31,6 +31,9 @@
 #include "vpn_common.h"
 
 #define R_EXP(x) __expf(x)   // v_exp_f32 based; the raster is a 1e-4 contract
+// a / b as a * v_rcp_f32(b): the compiler's fp32 division is a ~8-instruction sequence (range scaling for huge and
+// denormal divisors) even with the 1-ulp option, and these kernels divide 3-6 times per pixel x primitive
+#define R_RCP(x) __builtin_amdgcn_rcpf(x)
 
 namespace vpn {
 
@@ -163,18 +166,19 @@ __global__ __launch_bounds__(256) void raster_prep_kernel(const float* __restric
 // ellipse: the centre if it is inside, otherwise the maximum of the concave quadratic over the 4 edges.
 __device__ inline bool conic_hits_rect(const float4 qa, const float4 qb, float x0, float x1, float y0, float y1) {
     const float A00 = qa.x, A01 = qa.y, A11 = qa.z, b0 = qb.x, b1 = qb.y, c0 = qb.z, det = qb.w;
-    const float xs = -(A11 * b0 - A01 * b1) / det, ys = -(A00 * b1 - A01 * b0) / det;
+    const float idet = R_RCP(det);
+    const float xs = -(A11 * b0 - A01 * b1) * idet, ys = -(A00 * b1 - A01 * b0) * idet;
     if (xs >= x0 && xs <= x1 && ys >= y0 && ys <= y1) return true;
     float best = -1.0f;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         const float x = e ? x1 : x0;                                         // vertical edges
         const float lin = A01 * x + b1, cst = (A00 * x + 2.0f * b0) * x + c0;
-        const float yv = fminf(fmaxf(-lin / A11, y0), y1);
+        const float yv = fminf(fmaxf(-lin * R_RCP(A11), y0), y1);
         best = fmaxf(best, (A11 * yv + 2.0f * lin) * yv + cst);
         const float y = e ? y1 : y0;                                         // horizontal edges
         const float lin2 = A01 * y + b0, cst2 = (A11 * y + 2.0f * b1) * y + c0;
-        const float xv = fminf(fmaxf(-lin2 / A00, x0), x1);
+        const float xv = fminf(fmaxf(-lin2 * R_RCP(A00), x0), x1);
         best = fmaxf(best, (A00 * xv + 2.0f * lin2) * xv + cst2);
     }
     return best >= 0.0f;
@@ -203,13 +207,13 @@ __device__ inline void eval_prim(const float4 r0, const float4 r1, const float4 
     if (kind == VPN_SPHERE) {
         q.A = q.d[0] * q.d[0] + q.d[1] * q.d[1] + q.d[2] * q.d[2];
         q.Bq = o[0] * q.d[0] + o[1] * q.d[1] + o[2] * q.d[2];
-        q.invA = 1.0f / q.A;
+        q.invA = R_RCP(q.A);
         q.s = -q.Bq * q.invA;
         q.wv[0] = o[0] + q.s * q.d[0]; q.wv[1] = o[1] + q.s * q.d[1]; q.wv[2] = o[2] + q.s * q.d[2];
         q.m2 = q.wv[0] * q.wv[0] + q.wv[1] * q.wv[1] + q.wv[2] * q.wv[2];
         const float u = 1.0f - q.m2;                 // h = squareplus(u), cancellation-free for u < 0
         q.rr = sqrtf(u * u + R_EPS_H);
-        q.h = u >= 0.0f ? 0.5f * (u + q.rr) : (0.5f * R_EPS_H) / (q.rr - u);
+        q.h = u >= 0.0f ? 0.5f * (u + q.rr) : (0.5f * R_EPS_H) * R_RCP(q.rr - u);
         q.chord = sqrtf(q.h * q.invA);
         q.z = q.s - q.chord;
     } else {
@@ -217,7 +221,7 @@ __device__ inline void eval_prim(const float4 r0, const float4 r1, const float4 
         float n01 = o[1] * q.d[0] - o[0] * q.d[1], d01 = ad[0] + ad[1] + R_EPS_D;
         float n02 = o[2] * q.d[0] - o[0] * q.d[2], d02 = ad[0] + ad[2] + R_EPS_D;
         float n12 = o[2] * q.d[1] - o[1] * q.d[2], d12 = ad[1] + ad[2] + R_EPS_D;
-        float l01 = fabsf(n01) / d01, l02 = fabsf(n02) / d02, l12 = fabsf(n12) / d12;
+        float l01 = fabsf(n01) * R_RCP(d01), l02 = fabsf(n02) * R_RCP(d02), l12 = fabsf(n12) * R_RCP(d12);
         q.lam = l01; q.n = n01; q.den = d01; q.sel = 0;
         if (l02 > q.lam) { q.lam = l02; q.n = n02; q.den = d02; q.sel = 1; }
         if (l12 > q.lam) { q.lam = l12; q.n = n12; q.den = d12; q.sel = 2; }
@@ -227,7 +231,7 @@ __device__ inline void eval_prim(const float4 r0, const float4 r1, const float4 
         for (int i = 0; i < 3; ++i) {
             float sg = q.d[i] < 0.0f ? -1.0f : 1.0f;
             ds[i] = ad[i] < R_EPS_D ? sg * R_EPS_D : q.d[i];
-            tn[i] = -(q.L * sg + o[i]) / ds[i];
+            tn[i] = -(q.L * sg + o[i]) * R_RCP(ds[i]);
         }
         q.z = tn[0]; q.zi = 0;
         if (tn[1] > q.z) { q.z = tn[1]; q.zi = 1; }
@@ -240,7 +244,7 @@ __device__ inline void eval_prim(const float4 r0, const float4 r1, const float4 
     q.xin = (xr >= -R_X_CLAMP) && (xr <= R_X_CLAMP);
     float x = fminf(fmaxf(xr, -R_X_CLAMP), R_X_CLAMP);
     float ex = R_EXP(-fabsf(x));
-    float dn = 1.0f / (1.0f + ex);
+    float dn = R_RCP(1.0f + ex);
     float big = dn, small = ex * dn;
     q.a = x >= 0.0f ? big : small;
     q.c = x >= 0.0f ? small : big;
@@ -259,7 +263,7 @@ __device__ inline void prim_backward(const float4 r0, const PixPrim& q, float gz
     if (__float_as_int(r0.w) == VPN_SPHERE) {
         const float gchord = -gz;                       // z = s - chord, chord = sqrt(h * invA)
         // d chord/d u = (0.5/chord) invA dh/du with dh/du = h/r  ->  0.5 chord / r ;  u = 1 - m2
-        gm2 -= gchord * 0.5f * q.chord / q.rr;
+        gm2 -= gchord * 0.5f * q.chord * R_RCP(q.rr);
         float ginvA = gchord * 0.5f * q.chord * q.A;    // d chord/d invA = 0.5 h / chord = 0.5 chord A
         float gs = gz;
         const float gwv[3] = {2.0f * gm2 * q.wv[0], 2.0f * gm2 * q.wv[1], 2.0f * gm2 * q.wv[2]};   // m2 = w.w
@@ -277,7 +281,7 @@ __device__ inline void prim_backward(const float4 r0, const PixPrim& q, float gz
         const int zi = q.zi;
         const float dzi = zi == 0 ? q.d[0] : (zi == 1 ? q.d[1] : q.d[2]);
         const float sg = dzi < 0.0f ? -1.0f : 1.0f;
-        const float ids = 1.0f / q.dsafe;
+        const float ids = R_RCP(q.dsafe);
         const float gL = -gz * sg * ids;
         const float go_z = -gz * ids;
         const float gd_z = fabsf(dzi) < R_EPS_D ? 0.0f : -gz * q.tn * ids;
@@ -285,8 +289,9 @@ __device__ inline void prim_backward(const float4 r0, const PixPrim& q, float gz
         if (q.lam >= 1.0f) glam += gL;                  // L = max(lam, 1)
         // lam = |n| / den
         const float sn = q.n > 0.0f ? 1.0f : (q.n < 0.0f ? -1.0f : 0.0f);
-        const float gn = glam * sn / q.den;
-        const float gden = -glam * q.lam / q.den;
+        const float iden = R_RCP(q.den);
+        const float gn = glam * sn * iden;
+        const float gden = -glam * q.lam * iden;
         // pair (i,j): sel 0 -> (0,1), 1 -> (0,2), 2 -> (1,2);  n = o_j d_i - o_i d_j, den = |d_i| + |d_j| + eps
         const int pi = q.sel == 2 ? 1 : 0, pj = q.sel == 0 ? 1 : 2;
 #pragma unroll
@@ -404,7 +409,7 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(const float4* __restrict
         if (col < W && row < H) {
             const float A = 1.0f - P[s];
             const float S = S0[s] + R_DELTA_S0;
-            const float zbar = S1[s] / S;
+            const float zbar = S1[s] * R_RCP(S);
             const float D = z_far + A * (zbar - z_far);
             const size_t pix = (size_t)row * W + col;
             if (MODE == 0) {
@@ -528,7 +533,7 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(const float4* __restrict
             const size_t pix = (size_t)row * W + col;
             P[s] = aux[(b * 3 + 0) * hw + pix];
             zbar[s] = aux[(b * 3 + 1) * hw + pix];
-            invS[s] = 1.0f / aux[(b * 3 + 2) * hw + pix];
+            invS[s] = R_RCP(aux[(b * 3 + 2) * hw + pix]);
             float gA = 0.0f, gD = 0.0f;
             if (MODE == 0) {
                 gA = galpha ? galpha[b * hw + pix] : 0.0f;
@@ -567,7 +572,7 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(const float4* __restrict
                 const float gw = gZbar[s] * (q.z - zbar[s]) * invS[s];
                 float gz = gZbar[s] * q.wgt * invS[s];
                 if (q.ein) gz -= gw * q.wgt * inv_gamma;
-                const float ga = gAtot[s] * (P[s] / q.c) + gw * q.E;
+                const float ga = gAtot[s] * (P[s] * R_RCP(q.c)) + gw * q.E;
                 const float gx = q.xin ? ga * q.a * q.c : 0.0f;
                 const float gm2 = -gx * inv_sigma;
                 float go[3], gd[3];
