@@ -24,7 +24,8 @@ PER_FILE = {
     'emd.hip': ['-ffp-contract=off', '-fno-slp-vectorize'],     # packed fp32 is half rate: keep the scan scalar
     # the raster is compared with a 1e-4 tolerance: 1-ulp v_rcp/v_sqrt instead of the IEEE sequences
     # -fgpu-flush-denormals-to-zero: no denormal-safe scaling around v_rcp / v_sqrt / v_exp
-    'raster.hip': ['-fno-hip-fp32-correctly-rounded-divide-sqrt', '-fgpu-flush-denormals-to-zero'],
+    # -fno-slp-vectorize: packed fp32 is half rate here and the packing costs v_mov shuffles and 25 VGPRs
+    'raster.hip': ['-fno-hip-fp32-correctly-rounded-divide-sqrt', '-fgpu-flush-denormals-to-zero', '-fno-slp-vectorize'],
 }
 
 
