@@ -74,6 +74,17 @@ int vpn_sample_fwd(const float* params, const int32_t* kinds, const float* u,
 int vpn_sample_bwd(const float* params, const int32_t* kinds, const float* u,
                    uint64_t seed, uint64_t sample_base, int B, int K, int n,
                    const float* grad_points, float* grad_params, void* stream);
+/* Backward of ChamferDistanceLoss(sample(params), gt_points) straight to grad_params [B,K,10], for the pair of
+ * calls train.py:117-120 + :160-161 makes: equals vpn_chamfer_bwd (gradient of the predicted cloud only, GT gets
+ * none) followed by vpn_sample_bwd, without the [B,K*n,3] point gradient in between and in a fixed summation
+ * order.  points [B,K*n,3] = what vpn_sample_fwd produced from the same (params, kinds, u | seed, sample_base);
+ * dist/idx from vpn_chamfer_fwd*(points, gt_points); grad_loss_b [B] as in vpn_chamfer_bwd.
+ * M <= 15360 (VPN_E_TOOBIG beyond: use the two separate calls). */
+int vpn_sample_chamfer_bwd(const float* params, const int32_t* kinds, const float* u,
+                           uint64_t seed, uint64_t sample_base, int B, int K, int n,
+                           const float* points, const float* gt_points, int M,
+                           const float* dist1, const int32_t* idx1, const float* dist2, const int32_t* idx2,
+                           const float* grad_loss_b, float w1, float w2, float* grad_params, void* stream);
 
 /* ---------------------------------------------------------------- transform
  * Replaces transform_points / rotate_points (modules/transform/transform.py:6-9,

@@ -187,6 +187,38 @@ def test_camera_transforms_full_size_round_trip(vpn):
     assert rel_err((view.norm(dim=-1) * d[:, None]).cpu(), pts.norm(dim=-1).cpu()) <= 1e-5
 
 
+def test_fused_chamfer_sampler_backward(vpn):
+    """vpn_sample_chamfer_bwd == vpn_chamfer_bwd followed by vpn_sample_bwd (explicit uniforms and Philox),
+    mixed primitive kinds, unequal weights, and bitwise reproducible."""
+    from vpn_amd import _lib
+    gen = torch.Generator().manual_seed(77)
+    B, K, n, M = 3, 5, 96, 333
+    params = g(rand_params(gen, B, K))
+    kinds = vpn.kinds_tensor([1, 1, 0, 0, 0], torch.device(DEV))
+    gt = g(torch.rand(B, M, 3, generator=gen) - 0.5)
+    gl = g(torch.rand(B, generator=gen) + 0.5)
+    for u in (g(torch.rand(B, K, n, 3, generator=gen)), None):
+        seed = 0 if u is not None else 4242
+        pts = vpn.Sampling.sample_primitives(params, kinds, n, u=u, seed=None if u is not None else seed)
+        d1, i1, d2, i2 = vpn.chamfer_nn(pts, gt)
+        N = K * n
+        gp = torch.empty_like(pts)
+        _lib.call('vpn_chamfer_bwd', _lib.ptr(pts), _lib.ptr(gt), _lib.ptr(d1), _lib.ptr(i1), _lib.ptr(d2), _lib.ptr(i2),
+                  _lib.ptr(gl), B, N, M, 0.7, 1.3, _lib.ptr(gp), None, _lib.stream())
+        ref = torch.empty_like(params)
+        _lib.call('vpn_sample_bwd', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(u), seed, 0, B, K, n, _lib.ptr(gp),
+                  _lib.ptr(ref), _lib.stream())
+        outs = []
+        for _ in range(2):
+            out = torch.empty_like(params)
+            _lib.call('vpn_sample_chamfer_bwd', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(u), seed, 0, B, K, n,
+                      _lib.ptr(pts), _lib.ptr(gt), M, _lib.ptr(d1), _lib.ptr(i1), _lib.ptr(d2), _lib.ptr(i2), _lib.ptr(gl),
+                      0.7, 1.3, _lib.ptr(out), _lib.stream())
+            outs.append(out)
+        assert rel_err(outs[0].cpu(), ref.cpu()) <= 1e-5
+        assert torch.equal(outs[0], outs[1])
+
+
 # ----------------------------------------------------------------------------- Chamfer
 def ulp_diff(a, b):
     return int((a.contiguous().view(torch.int32) - b.contiguous().view(torch.int32)).abs().max())

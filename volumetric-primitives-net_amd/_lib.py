@@ -21,6 +21,8 @@ SIGNATURES = {
     'vpn_profile_read': (_i, [ctypes.c_char_p, _i, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int), _i]),
     'vpn_sample_fwd': (_i, [_c_f, _c_f, _c_f, _u64, _u64, _i, _i, _i, _c_f, _c_f]),
     'vpn_sample_bwd': (_i, [_c_f, _c_f, _c_f, _u64, _u64, _i, _i, _i, _c_f, _c_f, _c_f]),
+    'vpn_sample_chamfer_bwd': (_i, [_c_f, _c_f, _c_f, _u64, _u64, _i, _i, _i, _c_f, _c_f, _i, _c_f, _c_f, _c_f, _c_f, _c_f,
+                                    _f, _f, _c_f, _c_f]),
     'vpn_transform_fwd': (_i, [_c_f, _c_f, _c_f, _i, _i, _c_f, _c_f]),
     'vpn_transform_bwd': (_i, [_c_f, _c_f, _c_f, _i, _i, _c_f, _c_f, _c_f, _c_f]),
     'vpn_chamfer_fwd': (_i, [_c_f, _c_f, _i, _i, _i, _c_f, _c_f, _c_f, _c_f, _c_f]),

@@ -160,6 +160,109 @@ __global__ __launch_bounds__(SAMP_BLOCK) void sample_bwd_kernel(
     }
 }
 
+// ---- Chamfer backward + sampler backward in one pass (the hot-path step; train.py:243-262 backward)
+// The sampler's backward needs of the point gradients only G = sum_p g_p c_p^T and sum_p g_p per primitive, so the
+// gradient of ChamferDistanceLoss (chamfer_distance.py:14-30) never has to exist per point: one workgroup per
+// (primitive, sample) adds the direct term of its own points (their nearest GT point) and the scatter term of the
+// GT points whose nearest predicted point is one of its own, each weighted by the canonical coefficient c_p that
+// the forward pass used (recomputed from the same uniforms / Philox counter).  Fixed summation order: bitwise
+// reproducible, unlike the LDS-atomic scatter of chamfer_bwd_lds_kernel.  Replaces that kernel (one workgroup
+// per sample) plus sample_bwd_kernel and the [B,N,3] gradient between them.
+__global__ __launch_bounds__(SAMP_BLOCK) void sample_chamfer_bwd_kernel(
+    const float* __restrict__ params, const int32_t* __restrict__ kinds, const float* __restrict__ u,
+    uint64_t seed, uint64_t sample_base, int K, int n, const float* __restrict__ points,
+    const float* __restrict__ gt, int M, const float* __restrict__ dist1, const int32_t* __restrict__ idx1,
+    const float* __restrict__ dist2, const int32_t* __restrict__ idx2, const float* __restrict__ grad_loss_b,
+    float w1, float w2, float* __restrict__ grad_params) {
+    __shared__ PrimLds P;
+    __shared__ float red[SAMP_BLOCK / 64][12];
+    const int k = blockIdx.x, b = blockIdx.y, N = K * n;
+    const float* prm = params + ((size_t)b * K + k) * VPN_PARAM_STRIDE;
+    if (threadIdx.x == 0) load_prim(P, prm, kinds[k], n);
+    __syncthreads();
+    const float* ub = u ? u + ((size_t)b * K + k) * n * 3 : nullptr;
+    const float* A = points + (size_t)b * N * 3;
+    const float* G2 = gt + (size_t)b * M * 3;
+    const float gl = grad_loss_b[b];
+    const float ca = gl * w1 / (float)N, cb = gl * w2 / (float)M;       // means over N and M (chamfer_distance.py:25-28)
+    float acc[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc[i] = 0.0f;
+    auto add = [&](int pl, float gx, float gy, float gz) {              // point pl of this primitive gets gradient g
+        float uu[3];
+        if (ub) { uu[0] = ub[pl * 3]; uu[1] = ub[pl * 3 + 1]; uu[2] = ub[pl * 3 + 2]; }
+        else philox_uniform3(seed, sample_base + (uint64_t)b, (uint32_t)k, (uint32_t)pl, uu);
+        float c[3];
+        canonical_coeff(P, pl, uu, c);
+        const float g[3] = {gx, gy, gz};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) acc[r * 3 + a] += g[r] * c[a];
+            acc[9 + r] += g[r];
+        }
+    };
+    for (int pl = threadIdx.x; pl < n; pl += SAMP_BLOCK) {              // own nearest neighbour
+        const int i = k * n + pl, j = idx1[(size_t)b * N + i];
+        const float coef = ca / dist1[(size_t)b * N + i];
+        add(pl, coef * (A[i * 3] - G2[j * 3]), coef * (A[i * 3 + 1] - G2[j * 3 + 1]), coef * (A[i * 3 + 2] - G2[j * 3 + 2]));
+    }
+    // being a GT point's nearest neighbour: about M/K of the M entries concern this primitive, spread so that almost
+    // every pass over 256 entries has a lane with a match — handled in place, the heavy body (dependent loads,
+    // Philox) ran M/256 times with one or two active lanes.  So each wave first compacts its matches into LDS
+    // (ballot prefix: a fixed order) and then handles them densely.
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    extern __shared__ int match[];                                      // [SAMP_BLOCK/64][cap]
+    const int cap = (M + SAMP_BLOCK - 1) / SAMP_BLOCK * 64;             // entries one wave looks at
+    int* mine = match + wave * cap;
+    int cnt = 0;
+    for (int e0 = 0; e0 < M; e0 += SAMP_BLOCK) {
+        const int e = e0 + threadIdx.x;
+        const int i = e < M ? idx2[(size_t)b * M + e] : -1;
+        const bool hit = i >= k * n && i < (k + 1) * n;
+        const unsigned long long m = __ballot(hit);
+        if (hit) mine[cnt + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = e;
+        cnt += __builtin_popcountll(m);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");             // the wave reads its own LDS writes below
+    __builtin_amdgcn_wave_barrier();
+    for (int l = lane; l < cnt; l += 64) {
+        const int e = mine[l], i = idx2[(size_t)b * M + e];
+        const float coef = cb / dist2[(size_t)b * M + e];
+        add(i - k * n, coef * (A[i * 3] - G2[e * 3]), coef * (A[i * 3 + 1] - G2[e * 3 + 1]), coef * (A[i * 3 + 2] - G2[e * 3 + 2]));
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        float s = wave_sum(acc[i]);
+        if (lane == 0) red[wave][i] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float G[3][3], gt3[3];
+        for (int r = 0; r < 3; ++r) {
+            for (int a = 0; a < 3; ++a) {
+                float s = 0.0f;
+                for (int w = 0; w < SAMP_BLOCK / 64; ++w) s += red[w][r * 3 + a];
+                G[r][a] = s;
+            }
+            float s = 0.0f;
+            for (int w = 0; w < SAMP_BLOCK / 64; ++w) s += red[w][9 + r];
+            gt3[r] = s;
+        }
+        const Mat3& R = P.pose.R;
+        float gR[3][3], gv[3], gq[4];
+        for (int a = 0; a < 3; ++a) {
+            gv[a] = R.m[0][a] * G[0][a] + R.m[1][a] * G[1][a] + R.m[2][a] * G[2][a];   // p = R (c*v) + t
+            for (int r = 0; r < 3; ++r) gR[r][a] = G[r][a] * P.v[a];
+        }
+        pose_backward(P.pose, prm[3], prm[4], prm[5], gR, gq);
+        float* o = grad_params + ((size_t)b * K + k) * VPN_PARAM_STRIDE;
+        o[0] = gv[0]; o[1] = gv[1]; o[2] = gv[2];
+        o[3] = gq[0]; o[4] = gq[1]; o[5] = gq[2]; o[6] = gq[3];
+        o[7] = gt3[0]; o[8] = gt3[1]; o[9] = gt3[2];
+    }
+}
+
 // ---- standalone transform (modules/transform/transform.py:6-9): out = R(q) p + t
 constexpr int TR_BLOCK = 256;
 
@@ -378,4 +481,21 @@ extern "C" int vpn_camera_transform_bwd(const float* grad_out, const float* dist
                                         const float* azims, const float* angles, int B, int N, int to_object,
                                         float* grad_points, void* stream) {
     return camera_launch(grad_out, dists, elevs, azims, angles, B, N, to_object, 1, grad_points, stream);
+}
+
+extern "C" int vpn_sample_chamfer_bwd(const float* params, const int32_t* kinds, const float* u, uint64_t seed,
+                                      uint64_t sample_base, int B, int K, int n, const float* points,
+                                      const float* gt_points, int M, const float* dist1, const int32_t* idx1,
+                                      const float* dist2, const int32_t* idx2, const float* grad_loss_b, float w1,
+                                      float w2, float* grad_params, void* stream) {
+    if (!params || !kinds || !points || !gt_points || !dist1 || !idx1 || !dist2 || !idx2 || !grad_loss_b || !grad_params)
+        return VPN_E_BADARG;
+    if (B <= 0 || K <= 0 || n <= 0 || M <= 0) return VPN_E_BADARG;
+    if (B > 65535 || (long long)K * n > 0x7fffffffLL / 3) return VPN_E_TOOBIG;
+    const size_t lds = (size_t)((M + SAMP_BLOCK - 1) / SAMP_BLOCK) * 64 * (SAMP_BLOCK / 64) * sizeof(int);   // = M rounded up
+    if (lds > 60 * 1024) return VPN_E_TOOBIG;                           // 15 k GT points; beyond: vpn_chamfer_bwd + vpn_sample_bwd
+    VPN_LAUNCH(sample_chamfer_bwd_kernel, dim3(K, B), dim3(SAMP_BLOCK), lds, (hipStream_t)stream, params, kinds, u, seed,
+               sample_base, K, n, points, gt_points, M, dist1, idx1, dist2, idx2, grad_loss_b, w1, w2, grad_params);
+    VPN_LAUNCH_CHECK();
+    return 0;
 }

@@ -448,11 +448,10 @@ class HotPathLossFunction(Function):
                           gamma, z_far, _lib.ptr(aux), _lib.ptr(rec), _lib.ptr(gt_sil) if has_sil else None,
                           _lib.ptr(gt_depth) if has_depth else None, 0, g2, _lib.ptr(ws), _lib.ptr(grad_raster), 0,
                           _lib.stream())
-        grad_points = torch.empty_like(points)
-        _lib.call('vpn_chamfer_bwd', _lib.ptr(points), _lib.ptr(gt_points), _lib.ptr(d1), _lib.ptr(i1), _lib.ptr(d2),
-                  _lib.ptr(i2), _lib.ptr(gvec), B, N, M, 1.0, 1.0, _lib.ptr(grad_points), None, s)
+        # Chamfer backward and sampler backward in one launch: the [B,N,3] point gradient never exists
         grad_params = torch.empty_like(params)
-        _lib.call('vpn_sample_bwd', _lib.ptr(params), _lib.ptr(kinds), None, seed, base, B, K, n, _lib.ptr(grad_points),
+        _lib.call('vpn_sample_chamfer_bwd', _lib.ptr(params), _lib.ptr(kinds), None, seed, base, B, K, n, _lib.ptr(points),
+                  _lib.ptr(gt_points), M, _lib.ptr(d1), _lib.ptr(i1), _lib.ptr(d2), _lib.ptr(i2), _lib.ptr(gvec), 1.0, 1.0,
                   _lib.ptr(grad_params), s)
         if side is not None:
             main.wait_stream(side)
