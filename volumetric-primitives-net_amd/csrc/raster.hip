@@ -323,29 +323,35 @@ __device__ inline void stage_records(const float4* __restrict__ rec_b, int K, fl
     __syncthreads();
 }
 
-// visibility mask of primitives [k0, k0+64) for this wave's 16x16 tile: pixel box first, then the
-// exact conic-vs-tile test (one primitive per lane)
+// does primitive (pixel box bb, conic qa/qb) touch the 16x16 tile at (c0, r0)?  Pixel box first, then the exact
+// conic-vs-tile test.  NOT inlined on purpose: raster_bwd_kernel writes a partial for exactly the (primitive,
+// tile) pairs this returns true for and raster_bwd_finish_kernel reads exactly those, so both must run the very
+// same instructions (two inlined copies could be contracted into FMAs differently).
+__device__ __attribute__((noinline)) bool prim_hits_tile(const float4 bb, const float4* __restrict__ rec_k, int c0,
+                                                         int r0, int H, int W) {
+    const int jmin = __float_as_int(bb.x), jmax = __float_as_int(bb.y);
+    const int imin = __float_as_int(bb.z), imax = __float_as_int(bb.w);
+    bool vis = (jmin <= c0 + R_TW - 1) && (jmax >= c0) && (imin <= r0 + R_TH - 1) && (imax >= r0);
+    if (vis) {
+        const float4 qa = rec_k[5];
+        if (qa.w != 0.0f) {
+            const float4 qb = rec_k[6];
+            // tile rectangle in slope units, half a pixel of margin on every side
+            const float sx = 2.0f * (R_TAN_HALF_FOV * (float)W / (float)H) / (float)W, sy = 2.0f * R_TAN_HALF_FOV / (float)H;
+            const float x0 = ((float)c0 - 0.5f * (float)W) * sx, x1 = ((float)(c0 + R_TW) - 0.5f * (float)W) * sx;
+            const float y1 = (0.5f * (float)H - (float)r0) * sy, y0 = (0.5f * (float)H - (float)(r0 + R_TH)) * sy;
+            vis = conic_hits_rect(qa, qb, x0, x1, y0, y1);
+        }
+    }
+    return vis;
+}
+
+// visibility mask of primitives [k0, k0+64) for this wave's 16x16 tile (one primitive per lane)
 __device__ inline unsigned long long tile_mask(const float4* lds, const float4* __restrict__ rec_b, int k0, int K,
                                                int c0, int r0, int H, int W) {
     const int lane = threadIdx.x & 63;
     bool vis = false;
-    if (k0 + lane < K) {
-        float4 bb = lds[(k0 + lane) * R_LREC + 4];
-        int jmin = __float_as_int(bb.x), jmax = __float_as_int(bb.y);
-        int imin = __float_as_int(bb.z), imax = __float_as_int(bb.w);
-        vis = (jmin <= c0 + R_TW - 1) && (jmax >= c0) && (imin <= r0 + R_TH - 1) && (imax >= r0);
-        if (vis) {
-            const float4 qa = rec_b[(k0 + lane) * R_REC + 5];
-            if (qa.w != 0.0f) {
-                const float4 qb = rec_b[(k0 + lane) * R_REC + 6];
-                // tile rectangle in slope units, half a pixel of margin on every side
-                const float sx = 2.0f * (R_TAN_HALF_FOV * (float)W / (float)H) / (float)W, sy = 2.0f * R_TAN_HALF_FOV / (float)H;
-                const float x0 = ((float)c0 - 0.5f * (float)W) * sx, x1 = ((float)(c0 + R_TW) - 0.5f * (float)W) * sx;
-                const float y1 = (0.5f * (float)H - (float)r0) * sy, y0 = (0.5f * (float)H - (float)(r0 + R_TH)) * sy;
-                vis = conic_hits_rect(qa, qb, x0, x1, y0, y1);
-            }
-        }
-    }
+    if (k0 + lane < K) vis = prim_hits_tile(lds[(k0 + lane) * R_LREC + 4], rec_b + (size_t)(k0 + lane) * R_REC, c0, r0, H, W);
     return __ballot(vis);
 }
 
@@ -511,10 +517,8 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(const float4* __restrict
                                                         const float* __restrict__ galpha,
                                                         const float* __restrict__ gdepth,
                                                         float* __restrict__ partial, LossArgs la) {
-    extern __shared__ __attribute__((aligned(16))) float4 lds[];   // [K*5]: ray coefficients + pixel box records | accum [K][12]
-    float* accum = reinterpret_cast<float*>(lds + (size_t)K * R_LREC);
+    extern __shared__ __attribute__((aligned(16))) float4 lds[];   // [K*5]: ray coefficients + pixel box records
     const int b = blockIdx.z;
-    for (int i = threadIdx.x; i < K * 12; i += 64) accum[i] = 0.0f;
     stage_records(rec + (size_t)b * K * R_REC, K, lds);
     const int lane = threadIdx.x;
     const int c0 = blockIdx.x * R_TW, r0 = blockIdx.y * R_TH;
@@ -554,6 +558,7 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(const float4* __restrict
         }
     }
 
+    const int ntile = gridDim.x * gridDim.y, tile = blockIdx.y * gridDim.x + blockIdx.x;
     for (int k0 = 0; k0 < K; k0 += 64) {
         unsigned long long m = tile_mask(lds, rec + (size_t)b * K * R_REC, k0, K, c0, r0, H, W);
         while (m) {
@@ -583,29 +588,34 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(const float4* __restrict
                 v[9] += gd[0]; v[10] += gd[1]; v[11] += gd[2];
             }
             const float tot = wave_reduce16(v);
-            if ((lane & 3) == 0 && (lane >> 2) < 12) accum[k * 12 + (lane >> 2)] = tot;   // one writer per slot
+            // partial[b][k][tile][12]: 48 contiguous bytes per visible (primitive, tile); the others are never
+            // written and never read (raster_bwd_finish_kernel repeats the visibility test)
+            if ((lane & 3) == 0 && (lane >> 2) < 12)
+                partial[(((size_t)b * K + k) * ntile + tile) * 12 + (lane >> 2)] = tot;
         }
     }
-    __syncthreads();
-    const int ntile = gridDim.x * gridDim.y, tile = blockIdx.y * gridDim.x + blockIdx.x;
-    float* out = partial + ((size_t)b * ntile + tile) * K * 12;
-    for (int i = threadIdx.x; i < K * 12; i += 64) out[i] = accum[i];
 }
 
 // one wave per (b,k): sum the per-tile partials in a fixed order, then chain rule to (v,q,t)
 __global__ __launch_bounds__(256) void raster_bwd_finish_kernel(const float* __restrict__ params,
                                                                 const float* __restrict__ cam, int BK, int K,
-                                                                int ntile, const float* __restrict__ partial,
+                                                                int ntile, int tiles_x, int H, int W,
+                                                                const float4* __restrict__ rec,
+                                                                const float* __restrict__ partial,
                                                                 float* __restrict__ gparams, int accumulate) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int bk = blockIdx.x * 4 + wave;
     if (bk >= BK) return;
-    const int b = bk / K, k = bk - b * K;
+    const int b = bk / K;
+    const float4* rec_k = rec + (size_t)bk * R_REC;
+    const float4 bb = rec_k[4];
     float v[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) v[i] = 0.0f;
     for (int tile = lane; tile < ntile; tile += 64) {
-        const float4* src = reinterpret_cast<const float4*>(partial + (((size_t)b * ntile + tile) * K + k) * 12);
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        if (!prim_hits_tile(bb, rec_k, tx * R_TW, ty * R_TH, H, W)) continue;      // nothing was written for this pair
+        const float4* src = reinterpret_cast<const float4*>(partial + ((size_t)bk * ntile + tile) * 12);
         const float4 a = src[0], c = src[1], d = src[2];
         v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
         v[4] += c.x; v[5] += c.y; v[6] += c.z; v[7] += c.w;
@@ -649,7 +659,7 @@ __global__ __launch_bounds__(256) void raster_bwd_finish_kernel(const float* __r
 
 static inline dim3 raster_grid(int B, int H, int W) { return dim3((W + R_TW - 1) / R_TW, (H + R_TH - 1) / R_TH, B); }
 static inline size_t fwd_lds(int K) { return (size_t)K * R_LREC * sizeof(float4); }
-static inline size_t bwd_lds(int K) { return (size_t)K * (R_LREC * sizeof(float4) + 12 * sizeof(float)); }
+static inline size_t bwd_lds(int K) { return (size_t)K * R_LREC * sizeof(float4); }
 
 // kernels may need more than the 64 KB default of dynamic LDS (K up to VPN_MAX_PRIMS)
 static int raise_lds_limit() {
@@ -756,7 +766,7 @@ extern "C" int vpn_raster_bwd(const float* params, const int32_t* kinds, const f
     VPN_LAUNCH_CHECK();
     const int BK = B * K;
     VPN_LAUNCH(raster_bwd_finish_kernel, dim3((BK + 3) / 4), dim3(256), 0, (hipStream_t)stream, params, cam,
-                       BK, K, (int)(g.x * g.y), (const float*)workspace, grad_params, 0);
+                       BK, K, (int)(g.x * g.y), (int)g.x, H, W, (const float4*)records, (const float*)workspace, grad_params, 0);
     VPN_LAUNCH_CHECK();
     return 0;
 }
@@ -778,7 +788,8 @@ extern "C" int vpn_raster_loss_bwd(const float* params, const int32_t* kinds, co
     VPN_LAUNCH_CHECK();
     const int BK = B * K;
     VPN_LAUNCH(raster_bwd_finish_kernel, dim3((BK + 3) / 4), dim3(256), 0, (hipStream_t)stream, params, cam,
-                       BK, K, (int)(g.x * g.y), (const float*)workspace, grad_params, accumulate);
+                       BK, K, (int)(g.x * g.y), (int)g.x, H, W, (const float4*)records, (const float*)workspace, grad_params,
+                       accumulate);
     VPN_LAUNCH_CHECK();
     return 0;
 }
