@@ -29,9 +29,9 @@ torch.cuda.synchronize()
 pad = lambda n: (n + 63) & ~63
 p4 = lambda n: (n + 3) & ~3
 wi = ws.view(torch.int32)
-off1 = B * 20 * pad(M) + 4096 + B * 16                # direction 1: targets p2 (M), queries p1 (N)
-size1 = off1 + p4(B) + 4 * B * N
-off2 = size1 + B * 20 * pad(N) + 4096 + B * 16
+off1 = B * 16 * pad(M) + 3072 + B * 16                # direction 1: targets p2 (M), queries p1 (N)
+size1 = off1 + p4(B) + 4 * B * N + B * pad(M) + B * (pad(M) // 32) * 8   # + permutation + block boxes
+off2 = size1 + B * 16 * pad(N) + 3072 + B * 16
 c1, c2 = wi[off1:off1 + B], wi[off2:off2 + B]
 print('undecided: direction 1 %d of %d (max %d per sample), direction 2 %d of %d (max %d per sample)'
       % (int(c1.sum()), B * N, int(c1.max()), int(c2.sum()), B * M, int(c2.max())))

@@ -636,9 +636,13 @@ constexpr float CM_EPS = 8.0f * 5.9604644775390625e-08f;   // 8 * 2^-24: bound o
 // (<= 4.2 * 2^-24 |a||b|), rounding of |b|^2 (3 * 2^-24): 32 * 2^-24 covers all of it
 constexpr float CM_EPS_BF16 = 32.0f * 5.9604644775390625e-08f;
 constexpr int CM_TILE16 = 256;           // targets per LDS tile of bf16 rows
-constexpr int CM_ROWB = 80;              // LDS row stride (64 B of data): ds_read_b128 of 16 consecutive rows hits 64 distinct banks
+constexpr int CM_ROWB = 48;              // bytes per bf16 row: K slots 0..15 for v_mfma_f32_32x32x16_bf16, 16..23 for v_mfma_f32_32x32x8_bf16
+                                         // (21 used).  Also the LDS stride: 16 consecutive rows x 16 B hit 64 distinct banks (12 r mod 64)
+constexpr int CM_ROWW = CM_ROWB / 4;     // the same in 4-byte words
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 typedef unsigned short us8 __attribute__((ext_vector_type(8)));
+typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+typedef short bs4 __attribute__((ext_vector_type(4)));      // operand type of v_mfma_f32_32x32x8_bf16
 
 // exact 3-way split of an fp32 into bf16 pieces (truncation): x == p0 + p1 + p2
 __device__ inline void split3_bf16(float x, unsigned short p[3]) {
@@ -652,10 +656,21 @@ __device__ inline void split3_bf16(float x, unsigned short p[3]) {
 }
 
 // feature planes F[b][4][Np] = (x, y, z, |p|^2) (padded with a never-winning sentinel) and
-// H[b][Np][32] bf16 rows for the bf16 filter: per coordinate the target pieces (b1 b1 b2 b1 b3 b2) that pair
+// H[b][Np][24] bf16 rows (48 B) for the bf16 filter: per coordinate the target pieces (b1 b1 b2 b1 b3 b2) that pair
 // with the query pieces (a1 a2 a1 a3 a1 a2), then the three pieces of |p|^2 (paired with 1.0), then zeros.
 // nmax[b][CFEAT_SLOTS]: max |p|^2 of each workgroup's slice (the filter takes the max of the slots: no atomics,
 // no zero-initialised output, no workgroup that scans the whole cloud).
+// one 48-byte row of bf16 pieces: K slots  x (b1 b1 b2 b1 b3 b2), y (...), z (...), |p|^2 (3 pieces), 3 zeros
+__device__ inline void write_row(unsigned short* H, size_t row, float x, float y, float z, float n) {
+    unsigned short px[3], py[3], pz[3], pn[3];
+    split3_bf16(x, px); split3_bf16(y, py); split3_bf16(z, pz); split3_bf16(n, pn);
+    auto pk = [](unsigned short lo, unsigned short hi) { return (unsigned)lo | ((unsigned)hi << 16); };
+    uint4* dst = reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(H) + row * CM_ROWB);
+    dst[0] = make_uint4(pk(px[0], px[0]), pk(px[1], px[0]), pk(px[2], px[1]), pk(py[0], py[0]));
+    dst[1] = make_uint4(pk(py[1], py[0]), pk(py[2], py[1]), pk(pz[0], pz[0]), pk(pz[1], pz[0]));
+    dst[2] = make_uint4(pk(pz[2], pz[1]), pk(pn[0], pn[1]), pk(pn[2], 0), 0u);
+}
+
 constexpr int CFEAT_THREADS = 256;
 constexpr int CFEAT_SLOTS = 16;                    // workgroups per cloud and sample, at most
 constexpr int CFEAT_PTS = 4;                       // points per lane in flight
@@ -709,17 +724,7 @@ __global__ __launch_bounds__(CFEAT_THREADS) void chamfer_feat_kernel(const FeatJ
                 nv = fmaxf(nv, n);
             }
             f[j] = x; f[Np + j] = y; f[2 * Np + j] = z; f[3 * Np + j] = n;
-            if (H) {
-                unsigned short px[3], py[3], pz[3], pn[3];
-                split3_bf16(x, px); split3_bf16(y, py); split3_bf16(z, pz); split3_bf16(n, pn);
-                auto pk = [](unsigned short lo, unsigned short hi) { return (unsigned)lo | ((unsigned)hi << 16); };
-                // K slots: x (b1 b1 b2 b1 b3 b2), y (...), z (...), |p|^2 (3 pieces), 11 zeros
-                uint4* dst = reinterpret_cast<uint4*>(H + ((size_t)b * Np + j) * 32);
-                dst[0] = make_uint4(pk(px[0], px[0]), pk(px[1], px[0]), pk(px[2], px[1]), pk(py[0], py[0]));
-                dst[1] = make_uint4(pk(py[1], py[0]), pk(py[2], py[1]), pk(pz[0], pz[0]), pk(pz[1], pz[0]));
-                dst[2] = make_uint4(pk(pz[2], pz[1]), pk(pn[0], pn[1]), pk(pn[2], 0), 0u);
-                dst[3] = make_uint4(0u, 0u, 0u, 0u);
-            }
+            if (H) write_row(H, (size_t)b * Np + j, x, y, z, n);
         }
     }
     nv = wave_max_u(nv);
@@ -964,10 +969,12 @@ __global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_kernel(const float* 
     const float* Fb = F + (size_t)b * 4 * Ntp;
     const f16v zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if constexpr (PREC == 1) {
-        // ---- bf16 filter: 2 x v_mfma_f32_32x32x16_bf16 per 32x32 block, on the matrix pipe beside the VALU
+        // ---- bf16 filter: v_mfma_f32_32x32x16_bf16 (K slots 0..15) + v_mfma_f32_32x32x8_bf16 (K slots 16..23) per 32x32
+        //      block, on the matrix pipe beside the VALU
         __shared__ __attribute__((aligned(16))) unsigned char tileH[2][CM_TILE16 * CM_ROWB];
-        const unsigned char* Hb = reinterpret_cast<const unsigned char*>(H) + (size_t)b * Ntp * 64;
-        bf8 bqA, bqB;                                // this lane's query: K slots [8 half, 8 half + 8) of the two MFMAs
+        const unsigned char* Hb = reinterpret_cast<const unsigned char*>(H) + (size_t)b * Ntp * CM_ROWB;
+        bf8 bqA;                                     // this lane's query: K slots [8 half, +8) of the first MFMA
+        bs4 bqB;                                     //                    K slots 16 + [4 half, +4) of the second
         {
             unsigned short qx[3], qy[3], qz[3];
             split3_bf16(-2.0f * ax, qx); split3_bf16(-2.0f * ay, qy); split3_bf16(-2.0f * az, qz);
@@ -984,43 +991,39 @@ __global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_kernel(const float* 
                 }
                 return k < 21 ? (unsigned short)0x3F80 : (unsigned short)0;      // bf16 1.0 for the |b|^2 pieces
             };
-            us8 ua, ub;
+            us8 ua;
+            us4 ub;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const unsigned short lo0 = slot(e), hi0 = slot(8 + e), lo1 = slot(16 + e), hi1 = slot(24 + e);
-                ua[e] = half ? hi0 : lo0;
-                ub[e] = half ? hi1 : lo1;
-            }
-            bqA = __builtin_bit_cast(bf8, ua); bqB = __builtin_bit_cast(bf8, ub);
+            for (int e = 0; e < 8; ++e) ua[e] = half ? slot(8 + e) : slot(e);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ub[e] = half ? slot(20 + e) : slot(16 + e);
+            bqA = __builtin_bit_cast(bf8, ua); bqB = __builtin_bit_cast(bs4, ub);
         }
-        constexpr int F4 = CM_TILE16 * 4 / CM_BLOCK;                    // float4 per lane per tile (rows are 4 float4)
-        static_assert(F4 == 4, "tile fetch is written for 4 float4 per lane");
-        // tile t0 = rows [t0, t0 + CM_TILE16): one contiguous 16-KB run; lane i moves float4 i, i+256, ...  No bounds
-        // checks (they cost ~50 instructions per tile): the last tile may run past Ntp into rows that are allocated
-        // (next sample / slack at the end of the workspace), loaded and never used.
+        constexpr int F4 = CM_TILE16 * CM_ROWB / 16 / CM_BLOCK;        // float4 per lane per tile
+        static_assert(F4 == 3, "tile fetch is written for 3 float4 per lane");
+        // tile t0 = rows [t0, t0 + CM_TILE16): one contiguous 12-KB run, copied as it is (the LDS stride is the row
+        // size); lane i moves float4 i, i+256, i+512.  No bounds checks (they cost ~50 instructions per tile): the last
+        // tile may run past Ntp into rows that are allocated (next sample / slack at the end of the workspace),
+        // loaded and never used.
         const float4* Hq = reinterpret_cast<const float4*>(Hb) + threadIdx.x;
-        struct Pre { float4 a, b, c, d; };              // named members: an indexed array ended up in scratch
+        struct Pre { float4 a, b, c; };                 // named members: an indexed array ended up in scratch
         auto fetch = [&](int t0) -> Pre {
-            const float4* p = Hq + t0 * 4;
-            return Pre{p[0], p[CM_BLOCK], p[2 * CM_BLOCK], p[3 * CM_BLOCK]};
+            const float4* p = Hq + t0 * (CM_ROWB / 16);
+            return Pre{p[0], p[CM_BLOCK], p[2 * CM_BLOCK]};
         };
-        const int srow = (threadIdx.x >> 2) * CM_ROWB + (threadIdx.x & 3) * 16;      // lane i -> row i/4, quarter i%4
         auto stash = [&](int buf, const Pre& v) {
-            unsigned char* q = &tileH[buf][srow];
-            *reinterpret_cast<float4*>(q) = v.a;
-            *reinterpret_cast<float4*>(q + 64 * CM_ROWB) = v.b;
-            *reinterpret_cast<float4*>(q + 128 * CM_ROWB) = v.c;
-            *reinterpret_cast<float4*>(q + 192 * CM_ROWB) = v.d;
+            float4* q = reinterpret_cast<float4*>(&tileH[buf][0]) + threadIdx.x;
+            q[0] = v.a; q[CM_BLOCK] = v.b; q[2 * CM_BLOCK] = v.c;
         };
-        // one 32-target block: lanes (jq, half) read bytes [16 half, +16) and [32 + 16 half, +16) of row jq
-        struct Ops { float4 lo, hi; };
+        // one 32-target block: lane (jq, half) reads bytes [16 half, +16) and [32 + 8 half, +8) of row jq
+        struct Ops { float4 lo; float2 hi; };
         auto rd = [&](const unsigned char* T, int blkk) -> Ops {
             const unsigned char* p = T + blkk * 32 * CM_ROWB;
-            return Ops{*reinterpret_cast<const float4*>(p), *reinterpret_cast<const float4*>(p + 32)};
+            return Ops{*reinterpret_cast<const float4*>(p), *reinterpret_cast<const float2*>(p + 32 - 8 * half)};
         };
         auto block = [&](const Ops& o) {
             f16v acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, o.lo), bqA, zero, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, o.hi), bqB, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(bs4, o.hi), bqB, acc, 0, 0, 0);
             return acc;
         };
         static_assert(CM_TILE16 == 256, "the tile loop below is unrolled for 8 blocks per tile");
@@ -1207,17 +1210,6 @@ struct SortJob {
     float* F; unsigned int* nmax; unsigned short* H; int* undecided; int32_t* perm; float* boxes;
 };
 
-__device__ inline void write_row(unsigned short* H, size_t row, float x, float y, float z, float n) {
-    unsigned short px[3], py[3], pz[3], pn[3];
-    split3_bf16(x, px); split3_bf16(y, py); split3_bf16(z, pz); split3_bf16(n, pn);
-    auto pk = [](unsigned short lo, unsigned short hi) { return (unsigned)lo | ((unsigned)hi << 16); };
-    uint4* dst = reinterpret_cast<uint4*>(H + row * 32);
-    dst[0] = make_uint4(pk(px[0], px[0]), pk(px[1], px[0]), pk(px[2], px[1]), pk(py[0], py[0]));
-    dst[1] = make_uint4(pk(py[1], py[0]), pk(py[2], py[1]), pk(pz[0], pz[0]), pk(pz[1], pz[0]));
-    dst[2] = make_uint4(pk(pz[2], pz[1]), pk(pn[0], pn[1]), pk(pn[2], 0), 0u);
-    dst[3] = make_uint4(0u, 0u, 0u, 0u);
-}
-
 // 1-D grid of 2 * B workgroups (both clouds of a Chamfer call), sample b on XCD b / (B/8) like the other kernels.
 __global__ __launch_bounds__(CS_THREADS) void chamfer_sortfeat_kernel(const SortJob j0, const SortJob j1, int B) {
     __shared__ int hist[CP_CELLS];
@@ -1358,7 +1350,8 @@ __global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_pruned_kernel(
     int blk = 0;
     const float* Fb = F + (size_t)b * 4 * Ntp;
     const f16v zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    bf8 bqA, bqB;
+    bf8 bqA;
+    bs4 bqB;
     {
         unsigned short qx[3], qy[3], qz[3];
         split3_bf16(-2.0f * ax, qx); split3_bf16(-2.0f * ay, qy); split3_bf16(-2.0f * az, qz);
@@ -1373,14 +1366,13 @@ __global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_pruned_kernel(
             }
             return k < 21 ? (unsigned short)0x3F80 : (unsigned short)0;
         };
-        us8 ua, ub;
+        us8 ua;
+        us4 ub;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const unsigned short lo0 = slot(e), hi0 = slot(8 + e), lo1 = slot(16 + e), hi1 = slot(24 + e);
-            ua[e] = half ? hi0 : lo0;
-            ub[e] = half ? hi1 : lo1;
-        }
-        bqA = __builtin_bit_cast(bf8, ua); bqB = __builtin_bit_cast(bf8, ub);
+        for (int e = 0; e < 8; ++e) ua[e] = half ? slot(8 + e) : slot(e);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ub[e] = half ? slot(20 + e) : slot(16 + e);
+        bqA = __builtin_bit_cast(bf8, ua); bqB = __builtin_bit_cast(bs4, ub);
     }
     float nb = 0.0f;
 #pragma unroll
@@ -1400,15 +1392,15 @@ __global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_pruned_kernel(
         const float dz = fmaxf(0.0f, fmaxf(u.z - qhz, qlz - v.y));
         return dx * dx + dy * dy + dz * dz;
     };
-    const unsigned char* Hb = reinterpret_cast<const unsigned char*>(H) + (size_t)b * Ntp * 64 + jq * 64 + half * 16;
-    struct Ops { float4 lo, hi; };
+    const unsigned char* Hb = reinterpret_cast<const unsigned char*>(H) + ((size_t)b * Ntp + jq) * CM_ROWB;
+    struct Ops { float4 lo; float2 hi; };
     auto ld = [&](int k) -> Ops {
-        const unsigned char* r = Hb + (size_t)k * 2048;
-        return Ops{*reinterpret_cast<const float4*>(r), *reinterpret_cast<const float4*>(r + 32)};
+        const unsigned char* r = Hb + (size_t)k * 32 * CM_ROWB;
+        return Ops{*reinterpret_cast<const float4*>(r + 16 * half), *reinterpret_cast<const float2*>(r + 32 + 8 * half)};
     };
     auto process = [&](const Ops& o, int k) {
         f16v acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, o.lo), bqA, zero, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, o.hi), bqB, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(bs4, o.hi), bqB, acc, 0, 0, 0);
         const float m = min16(acc);
         CM_UPDATE(m, k << 5)
     };
@@ -1523,7 +1515,7 @@ static inline int pad32(int n) { return (n + 63) & ~63; }   // feature planes pa
 // one direction: fp32 planes + bf16 rows of the targets + one tile of slack (the row tiles are fetched without
 // bounds checks) + nmax[B][CFEAT_SLOTS] + the lists of undecided queries (count[pad4(B)], 16-byte entries[B][Nq])
 static inline size_t mfma_ws_floats(int B, int Nt, int Nq) {
-    return (size_t)B * (4 + 16) * pad32(Nt) + (size_t)CM_TILE16 * 16 + (size_t)B * CFEAT_SLOTS + (size_t)pad4(B) + 4 * (size_t)B * Nq
+    return (size_t)B * (4 + CM_ROWW) * pad32(Nt) + (size_t)CM_TILE16 * CM_ROWW + (size_t)B * CFEAT_SLOTS + (size_t)pad4(B) + 4 * (size_t)B * Nq
            + (size_t)B * pad32(Nt) + (size_t)B * (pad32(Nt) / 32) * CS_BOXF;   // + permutation + block boxes (sorted mode); multiple of 4 floats
 }
 
@@ -1533,8 +1525,8 @@ static MfmaWs mfma_carve(float* F, int B, int Nt, int Nq) {
     MfmaWs w;
     w.Ntp = pad32(Nt);
     w.F = F;
-    w.H = reinterpret_cast<unsigned short*>(F + (size_t)B * 4 * w.Ntp);                       // [B][Ntp][32] bf16
-    w.nmax = reinterpret_cast<unsigned int*>(F + (size_t)B * 20 * w.Ntp + (size_t)CM_TILE16 * 16);
+    w.H = reinterpret_cast<unsigned short*>(F + (size_t)B * 4 * w.Ntp);                       // [B][Ntp][24] bf16
+    w.nmax = reinterpret_cast<unsigned int*>(F + (size_t)B * (4 + CM_ROWW) * w.Ntp + (size_t)CM_TILE16 * CM_ROWW);
     w.undecided = reinterpret_cast<int*>(w.nmax + (size_t)B * CFEAT_SLOTS);
     w.perm = reinterpret_cast<int32_t*>(w.undecided + pad4(B) + 4 * (size_t)B * Nq);
     w.boxes = reinterpret_cast<float*>(w.perm + (size_t)B * w.Ntp);
