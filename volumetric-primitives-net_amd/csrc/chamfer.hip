@@ -795,6 +795,7 @@ __global__ __launch_bounds__(CF_THREADS) void chamfer_fixup_kernel(const FixJob 
     const float* fy = fx + Ntp;
     const float* fz = fy + Ntp;
     const int32_t* pm = perm ? perm + (size_t)b * Ntp : nullptr;
+    const bool sorted = pm != nullptr;
     for (int k0 = grp * CF_Q; k0 < count; k0 += CF_GROUPS * CF_Q) {
         int q[CF_Q];
         float qx[CF_Q], qy[CF_Q], qz[CF_Q], best[CF_Q], second[CF_Q];
@@ -831,13 +832,16 @@ __global__ __launch_bounds__(CF_THREADS) void chamfer_fixup_kernel(const FixJob 
                 const int os[4] = {o[u].x, o[u].y, o[u].z, o[u].w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int j = j0 + e;
+                    // rows past Nt (padding, clamped loads) are pushed to +inf by an additive penalty: written as a
+                    // conditional, every evaluation became an exec-mask branch
+                    const float pen = (j0 + e < Nt) ? 0.0f : __builtin_inff();
 #pragma unroll
                     for (int c = 0; c < CF_Q; ++c) {
-                        const float d = j < Nt ? dist2_exact(qx[c], qy[c], qz[c], xs[e], ys[e], zs[e]) : __builtin_inff();
+                        const float d = dist2_exact(qx[c], qy[c], qz[c], xs[e], ys[e], zs[e]) + pen;
                         second[c] = __builtin_amdgcn_fmed3f(best[c], second[c], d);   // a duplicate minimum counts as runner-up
                         // lowest ORIGINAL index among equal minima (in original order that is simply the first one)
-                        bi[c] = (d < best[c] || (pm && d == best[c] && os[e] < bi[c])) ? os[e] : bi[c];
+                        const bool take = (d < best[c]) | (sorted & (d == best[c]) & (os[e] < bi[c]));
+                        bi[c] = take ? os[e] : bi[c];
                         best[c] = fminf(best[c], d);
                     }
                 }
