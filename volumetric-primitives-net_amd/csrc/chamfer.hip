@@ -1147,7 +1147,7 @@ __global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_kernel(const float* 
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
                 const int e = v * 4 + w;
-                d2[e] = (base + e < Nt) ? dist2_exact(ax, ay, az, xs[w], ys[w], zs[w]) : __builtin_inff();
+                d2[e] = dist2_exact(ax, ay, az, xs[w], ys[w], zs[w]) + ((base + e < Nt) ? 0.0f : __builtin_inff());   // no branch
                 m2 = fminf(m2, d2[e]);
             }
         }
@@ -1482,7 +1482,7 @@ __global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_pruned_kernel(
             for (int w = 0; w < 4; ++w) {
                 const int e = v * 4 + w;
                 og[e] = ps[w];                                          // 0x7fffffff on padding rows
-                d2[e] = (base + e < Nt) ? dist2_exact(ax, ay, az, xs[w], ys[w], zs[w]) : __builtin_inff();
+                d2[e] = dist2_exact(ax, ay, az, xs[w], ys[w], zs[w]) + ((base + e < Nt) ? 0.0f : __builtin_inff());   // no branch
                 m2 = fminf(m2, d2[e]);
             }
         }
