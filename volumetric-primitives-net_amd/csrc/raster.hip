@@ -43,7 +43,7 @@ constexpr float R_E_CLAMP = 8.0f;
 constexpr float R_EPS_H = 1e-3f;     // squareplus smoothing of relu(1 - m2) under the chord sqrt
 constexpr float R_DELTA_S0 = 1e-12f;
 constexpr float R_EPS_D = 1e-9f;
-constexpr float R_X_CUT = 32.0f;     // primitives whose coverage logit is below -X_CUT on a tile are skipped
+constexpr float R_X_CUT = 16.0f;     // primitives whose coverage logit is below -X_CUT on a tile are skipped: coverage < 1.2e-7
 constexpr int R_TW = 16, R_TH = 16;  // pixel tile per wave
 constexpr int R_PPL = 4;             // pixels per lane (row groups of 4 rows)
 constexpr int R_REC = 7;             // float4 per primitive record in HBM
