@@ -175,6 +175,7 @@ def main():
         'raster_bwd_kernel<0>': B * (8 * H * W + 80 * K), 'raster_bwd_kernel<1>': B * (8 * H * W + 80 * K),
         'sample_fwd_kernel': B * (40 * K + 12 * N), 'sample_bwd_kernel': B * (12 * N + 80 * K),
         'chamfer_bwd_lds_kernel': B * (12 * (N + M) + 8 * (N + M) + 12 * N),
+        'sample_chamfer_bwd_kernel': B * (12 * (N + M) + 8 * (N + M) + 80 * K),
     }
     pair_flops = 8.0 * B * N * M                      # 8 flop per point pair (3 sub, 3 mul, 2 add  ==  K=4 MAC on the matrix pipe)
     dom = max((k for k in kern if k in alg_bytes), key=lambda k: kern[k][0] * kern[k][1])
@@ -190,9 +191,9 @@ def main():
                                  '(157.3 TFLOP/s, vector = fp32-input MFMA; MI355X_MICROARCH.md)',
                     'hbm_view': {'algorithmic_bytes_per_launch': alg_bytes[dom], 'achieved_GBps': round(hbm_gbs, 2),
                                  'frac_of_8TBps': round(hbm_gbs / HBM_PEAK_GBS, 5)}}
-        if bf16:    # executed on the bf16 matrix pipe: 2 x v_mfma_f32_32x32x16_bf16 per 32x32 pairs = 64 flop per pair
-            ex = 64.0 * B * N * M / dom_s / 1e12
-            roofline['matrix_pipe'] = {'instruction': 'v_mfma_f32_32x32x16_bf16 (fp32 coordinates split exactly into 3 bf16 pieces)',
+        if bf16:    # executed on the bf16 matrix pipe: v_mfma_f32_32x32x16_bf16 + v_mfma_f32_32x32x8_bf16 per 32x32 pairs = 48 flop per pair
+            ex = 48.0 * B * N * M / dom_s / 1e12
+            roofline['matrix_pipe'] = {'instruction': 'v_mfma_f32_32x32x16_bf16 + v_mfma_f32_32x32x8_bf16 (fp32 coordinates split exactly into 3 bf16 pieces, 21 of 24 K slots used)',
                                        'executed_TFLOPs': round(ex, 1), 'dense_bf16_peak_TFLOPs': 2500.0,
                                        'frac': round(ex / 2500.0, 4)}
     else:
@@ -205,10 +206,10 @@ def main():
 
     # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 cannot run inside bench.py)
     try:
-        tr = json.load(open(os.path.join(ROOT, 'profiles', 'r01h_traffic.json')))['kernels'].get(dom)
+        tr = json.load(open(os.path.join(ROOT, 'profiles', 'r01i_traffic.json')))['kernels'].get(dom)
         if tr and (B, K, n, M, H) == (64, 32, 256, 2048, 256):
             roofline['traffic'] = tr['traffic_bytes']
-            roofline['traffic_source'] = 'profiles/r01h_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same workload)'
+            roofline['traffic_source'] = 'profiles/r01i_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same workload)'
     except (OSError, ValueError, KeyError):
         pass
 
