@@ -2,7 +2,7 @@
 
 A step = one pass of the hot path over one batch of synthetic input already resident in HBM:
   sampler fwd (Philox in-kernel) -> Chamfer(pred, gt) fwd -> raster fwd (silhouette+depth)
-  -> L1(sil) + L1(depth) -> backward of all of it to d/d(v,q,t) [-> RCCL all-reduce if N>1].
+  -> L1(sil) + L1(depth) -> backward of all of it to d/d(v,q,t) [-> RCCL all-gather of the per-rank gradient slices if N>1].
 Workload (config.workload): BASELINE configs[2] = C3: B=64 per GPU, K=32 sphere primitives,
 256x256, n=256 points per primitive (N=8192) vs M=2048 GT points.
 
@@ -49,7 +49,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='launch every step eagerly instead of replaying a HIP graph')
     ap.add_argument('--dist-selftest', action='store_true',
-                    help='run the multi-rank code path (RCCL group, gradient all-reduce) even with one rank')
+                    help='run the multi-rank code path (RCCL group, gradient all-gather) even with one rank')
     ap.add_argument('--cpu-sample', type=int, default=32, help='images in the CPU baseline sample')
     args = ap.parse_args()
 
@@ -72,7 +72,7 @@ def main():
 
     import vpn_amd
     from vpn_amd import _lib
-    from vpn_amd.dist import GradAllReduce
+    from vpn_amd.dist import GradAllGather
     _lib.lib()
 
     B, K, n, M, H = args.batch, args.prims, args.points, args.gt_points, args.size
@@ -91,7 +91,7 @@ def main():
                                               vpn_amd.config.RASTER_Z_FAR)
     gt_sil = (a2 > 0.5).float()
     gt_depth = d2.clone()
-    reducer = GradAllReduce(B * world, K, dev, rank, world) if multi else None
+    reducer = GradAllGather(B * world, K, dev, rank, world) if multi else None
     cd_fn = vpn_amd.ChamferDistanceLoss()
     sigma, gamma, z_far = vpn_amd.config.RASTER_SIGMA, vpn_amd.config.RASTER_GAMMA, vpn_amd.config.RASTER_Z_FAR
 
@@ -116,7 +116,7 @@ def main():
         torch.cuda.synchronize()
 
     # The step is launch-bound on the host when issued eagerly (about 20 launches of 5-200 us), so the
-    # compute part is captured once into a HIP graph and replayed; the RCCL all-reduce stays outside.
+    # compute part is captured once into a HIP graph and replayed; the RCCL all-gather stays outside.
     use_graph = not args.no_graph
     run_step = step
     if use_graph:
@@ -131,13 +131,16 @@ def main():
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             g_loss = compute(0)
+            if reducer is not None:
+                reducer.pack(params.grad, g_loss)          # scaled copy into the send buffer: part of the graph
         g_grad = params.grad
 
         def run_step(i):
             graph.replay()
             if reducer is not None:
-                return reducer.reduce(g_grad, g_loss)
-            return g_grad, g_loss
+                reducer.gather()                           # the one collective of the step, outside the graph
+                return reducer.views()                     # (overlapping it with the next step through a second
+            return g_grad, g_loss                          #  graph + communication stream measured slower at 1 rank)
 
     for i in range(args.warmup):
         run_step(i)
@@ -228,7 +231,7 @@ def main():
             'config': {'workload': 'C3: B=%d/GPU, K=%d sphere primitives, %dx%d silhouette+depth, n=%d pts/prim '
                                    '(N=%d) vs M=%d GT points, Chamfer+L1 fwd+bwd' % (B, K, H, W, n, N, M),
                        'global_batch': B * world, 'parallelism': 'dp%d' % world,
-                       'collective': 'rccl all-reduce %d B/step' % ((B * world * K * 10 + 1) * 4) if multi else 'none'},
+                       'collective': 'rccl all-gather %d B/rank/step' % ((B * K * 10 + 4) * 4) if multi else 'none'},
             'roofline': roofline, 'kernel_us': kernel_us, 'entry_us': entry_us,
         }
         if cpu is not None:

@@ -27,7 +27,7 @@ def _worker(rank, world, port, out):
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     import vpn_amd
-    from vpn_amd.dist import GradAllReduce, shard_bounds
+    from vpn_amd.dist import GradAllGather, GradAllReduce, shard_bounds
     from oracle import vpn_oracle as O
     Bg, K, n, M = 4, 3, 16, 32
     g = torch.Generator().manual_seed(1234)
@@ -42,8 +42,12 @@ def _worker(rank, world, port, out):
     red = GradAllReduce(Bg, K, torch.device('cpu'), rank, world)
     # local mean is over B/world samples: scale so the sum over ranks is the global-batch mean
     ggrad, gloss = red.reduce(grad / world, loss)
+    # the all-gather formulation (what bench.py runs over RCCL) must give the same global gradient and loss
+    gat = GradAllGather(Bg, K, torch.device('cpu'), rank, world)
+    ggrad2, gloss2 = gat.reduce(grad, loss)
+    assert torch.allclose(ggrad2, ggrad, rtol=1e-6, atol=1e-9) and torch.allclose(gloss2, gloss, rtol=1e-6)
     if rank == 0:
-        torch.save({'grad': ggrad.clone(), 'loss': gloss.clone()}, out)
+        torch.save({'grad': ggrad.clone(), 'loss': gloss.clone(), 'grad2': ggrad2.clone(), 'loss2': gloss2.clone()}, out)
     dist.destroy_process_group()
 
 
@@ -60,6 +64,8 @@ def test_dp_two_ranks_matches_single_process(tmp_path):
     loss, grad = _loss_and_grad(params, gt, [1, 0, 0], O.philox_uniforms(1234, 0, Bg, K, n))
     assert torch.allclose(got['grad'], grad, rtol=1e-5, atol=1e-8)
     assert torch.allclose(got['loss'], loss, rtol=1e-5)
+    assert torch.allclose(got['grad2'], grad, rtol=1e-5, atol=1e-8)
+    assert torch.allclose(got['loss2'], loss, rtol=1e-5)
 
 
 def test_shard_bounds():

@@ -2,9 +2,12 @@
 one RCCL all-reduce (sum) of the primitive-parameter gradients per step.
 
 Every hot-path function is per-sample (sampler, Chamfer min, raster), so the only exchange
-is the gradient (and loss) reduction.  The buffer is the GLOBAL [B_global, K, 10] gradient:
-each rank fills its own slice, the rest stays zero, and the sum leaves the full gradient on
-every rank.  The loss rides in the same buffer so a step is ONE collective."""
+is the gradient (and loss) of disjoint samples.  Two equivalent collectives:
+  * GradAllGather (what bench.py runs): every rank contributes its own [B_local, K, 10] slice plus its loss
+    and an all-gather leaves the global gradient on every rank — half the bytes and half the ring steps of an
+    all-reduce, nothing to zero, and the packing is a plain copy that can sit inside a captured HIP graph;
+  * GradAllReduce: the GLOBAL [B_global, K, 10] buffer, own slice filled, rest zero, summed.
+The loss rides in the same buffer so a step is ONE collective either way."""
 import torch
 import torch.distributed as dist
 
@@ -36,3 +39,47 @@ class GradAllReduce:
         if self.world > 1 or dist.is_initialized():
             dist.all_reduce(self.buf, op=dist.ReduceOp.SUM)
         return self.grad, self.buf[-1]
+
+
+class GradAllGather:
+    """Same result as GradAllReduce through one all-gather.  `pack(local_grad, local_loss)` only enqueues
+    copies on the current stream (capturable); `gather()` is the collective; `views()` exposes the gathered buffer
+    without a copy, `result()` returns (global grad [B_global, K, 10], mean loss).  `reduce()` = the three in a row."""
+
+    def __init__(self, global_batch, K, device, rank=None, world=None):
+        self.rank = dist.get_rank() if rank is None else rank
+        self.world = dist.get_world_size() if world is None else world
+        self.lo, self.hi = shard_bounds(global_batch, self.rank, self.world)
+        self.per, self.K, self.global_batch = self.hi - self.lo, K, global_batch
+        self.G = self.per * K * 10
+        self.row = self.G + 4                                   # + loss, padded to 16 bytes
+        self.local = torch.zeros(self.row, dtype=torch.float32, device=device)
+        self.all = torch.zeros(self.world, self.row, dtype=torch.float32, device=device)
+
+    def pack(self, local_grad, local_loss):
+        # d(global mean loss) = d(local mean loss) / world for this rank's samples
+        torch.mul(local_grad.reshape(-1), 1.0 / self.world, out=self.local[:self.G])
+        self.local[self.G:self.G + 1].copy_(local_loss.detach().reshape(1))
+
+    def gather(self):
+        if dist.is_initialized():
+            if dist.get_backend() == 'gloo':                    # the CPU tests
+                dist.all_gather([self.all[r] for r in range(self.world)], self.local)
+            else:
+                dist.all_gather_into_tensor(self.all.view(-1), self.local)
+        else:
+            self.all[0].copy_(self.local)
+
+    def views(self):
+        """No-copy views of the gathered buffer: grad [world, B_local, K, 10] (rank-major = global sample order)
+        and the per-rank losses [world]."""
+        return self.all[:, :self.G].view(self.world, self.per, self.K, 10), self.all[:, self.G]
+
+    def result(self):
+        grad, losses = self.views()
+        return grad.reshape(self.global_batch, self.K, 10), losses.mean()
+
+    def reduce(self, local_grad, local_loss):
+        self.pack(local_grad, local_loss)
+        self.gather()
+        return self.result()
