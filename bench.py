@@ -172,7 +172,8 @@ def main():
     N = K * n
     nn_bytes = B * 16 * (N + M)                       # mean of the two directions: both clouds in, dist + idx out
     alg_bytes = {
-        'chamfer_nn_mfma_kernel<1>': nn_bytes, 'chamfer_nn_mfma_kernel<0>': nn_bytes, 'chamfer_nn_kernel<R>': nn_bytes,
+        'chamfer_nn_mfma_kernel<1>': 2 * nn_bytes, 'chamfer_nn_mfma_kernel<0>': 2 * nn_bytes,     # one launch = both directions
+        'chamfer_nn_kernel<R>': nn_bytes,
         'chamfer_nn_pruned_kernel<1>': nn_bytes,
         'raster_fwd_kernel<0>': B * (40 * K + 8 * H * W), 'raster_fwd_kernel<1>': B * (40 * K + 8 * H * W),
         'raster_bwd_kernel<0>': B * (8 * H * W + 80 * K), 'raster_bwd_kernel<1>': B * (8 * H * W + 80 * K),
@@ -184,7 +185,8 @@ def main():
     dom = max((k for k in kern if k in alg_bytes), key=lambda k: kern[k][0] * kern[k][1])
     dom_s = kern[dom][1] * 1e-3
     hbm_gbs = alg_bytes[dom] / dom_s / 1e9
-    if dom.startswith('chamfer_nn_mfma_kernel'):      # the exact scan with the matrix-pipe filter
+    if dom.startswith('chamfer_nn_mfma_kernel'):      # the exact scan with the matrix-pipe filter, both directions per launch
+        pair_flops *= 2.0
         tf = pair_flops / dom_s / 1e12
         bf16 = dom.endswith('<1>')
         roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': round(tf, 2), 'peak': VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s',
@@ -195,7 +197,7 @@ def main():
                     'hbm_view': {'algorithmic_bytes_per_launch': alg_bytes[dom], 'achieved_GBps': round(hbm_gbs, 2),
                                  'frac_of_8TBps': round(hbm_gbs / HBM_PEAK_GBS, 5)}}
         if bf16:    # executed on the bf16 matrix pipe: v_mfma_f32_32x32x16_bf16 + v_mfma_f32_32x32x8_bf16 per 32x32 pairs = 48 flop per pair
-            ex = 48.0 * B * N * M / dom_s / 1e12
+            ex = 2.0 * 48.0 * B * N * M / dom_s / 1e12
             roofline['matrix_pipe'] = {'instruction': 'v_mfma_f32_32x32x16_bf16 + v_mfma_f32_32x32x8_bf16 (fp32 coordinates split exactly into 3 bf16 pieces, 21 of 24 K slots used)',
                                        'executed_TFLOPs': round(ex, 1), 'dense_bf16_peak_TFLOPs': 2500.0,
                                        'frac': round(ex / 2500.0, 4)}

@@ -917,21 +917,34 @@ __device__ inline float min16(const f16v& v) {
     return vmin3(vmin3(a, b, c), g, g);
 }
 
+struct ScanJob {          // one direction of a Chamfer call
+    const float* qpts; const float* F; const unsigned short* H; const unsigned int* nmax;
+    int Nq, Nt, Ntp, gx, G;                       // G = gx * B workgroups
+    float* out_dist; int32_t* out_idx; int* undecided;
+};
+
+// Both directions of a Chamfer call in ONE launch: workgroups [0, j0.G) run job 0, the rest job 1.  Launched
+// back to back each direction had its own tail (at C3 4096 workgroups on 1280 resident slots = 3.2 rounds, then
+// 1024 = 0.8 rounds: 5 rounds of time); together they pack into 4.  The long job (more targets per query) goes
+// first so that its workgroups start early and the short ones fill in behind.
 template <int PREC>   // 0: fp32-input MFMA (shares the fp32 vector datapath), 1: bf16 3-piece split on the matrix pipe
-__global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_kernel(const float* __restrict__ qpts,
-                                                                   const float* __restrict__ tpts,
-                                                                   const float* __restrict__ F,
-                                                                   const unsigned short* __restrict__ H,
-                                                                   const unsigned int* __restrict__ nmax, int Nq,
-                                                                   int Nt, int Ntp, int gx, float* __restrict__ out_dist,
-                                                                   int32_t* __restrict__ out_idx, int* __restrict__ undecided,
-                                                                   int nsamples) {
-    // 1-D grid of gx * B workgroups.  Workgroups are dealt round-robin over the 8 XCDs (L2 is per XCD), so the
-    // linear id is remapped such that all workgroups of a sample land on ONE XCD and stream its target rows
-    // out of that XCD's L2 (speed only: any placement is correct).
-    int vid = blockIdx.x;
+__global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_kernel(const ScanJob j0, const ScanJob j1, int nsamples) {
+    const bool other = (int)blockIdx.x >= j0.G;
+    const float* __restrict__ qpts = other ? j1.qpts : j0.qpts;
+    const float* __restrict__ F = other ? j1.F : j0.F;
+    const unsigned short* __restrict__ H = other ? j1.H : j0.H;
+    const unsigned int* __restrict__ nmax = other ? j1.nmax : j0.nmax;
+    const int Nq = other ? j1.Nq : j0.Nq, Nt = other ? j1.Nt : j0.Nt, Ntp = other ? j1.Ntp : j0.Ntp;
+    const int gx = other ? j1.gx : j0.gx, G = other ? j1.G : j0.G;
+    float* __restrict__ out_dist = other ? j1.out_dist : j0.out_dist;
+    int32_t* __restrict__ out_idx = other ? j1.out_idx : j0.out_idx;
+    int* __restrict__ undecided = other ? j1.undecided : j0.undecided;
+    // Workgroups are dealt round-robin over the 8 XCDs (L2 is per XCD), so the id inside the job is remapped such
+    // that all workgroups of a sample land on ONE XCD and stream its target rows out of that XCD's L2 (speed only:
+    // any placement is correct; j0.G is a multiple of 8 whenever B is, so id & 7 is still the XCD).
+    int vid = (int)blockIdx.x - (other ? j0.G : 0);
     {
-        const int G = gridDim.x, per = G >> 3;
+        const int per = G >> 3;
         if (vid < (per << 3)) vid = (vid & 7) * per + (vid >> 3);
     }
     const int b = vid / gx, bx = vid - b * gx;
@@ -1549,20 +1562,17 @@ static int mfma_both(const float* p1, const float* p2, int B, int N, int M, floa
     VPN_LAUNCH(chamfer_feat_kernel, dim3(B * (f2.ysplit + f1.ysplit)), dim3(CFEAT_THREADS), 0, s, f2, f1, B);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    for (int dir = 0; dir < 2; ++dir) {
-        const float* q = dir ? p2 : p1;
-        const float* t = dir ? p1 : p2;
-        const int Nq = dir ? M : N, Nt = dir ? N : M;
-        const MfmaWs& w = dir ? w1 : w2;
-        float* d = dir ? d2 : d1;
-        int32_t* idx = dir ? i2 : i1;
-        const int gx = (Nq + 127) / 128;
+    {
+        const int gx1 = (N + 127) / 128, gx2 = (M + 127) / 128;
+        const ScanJob s1{p1, w2.F, w2.H, w2.nmax, N, M, w2.Ntp, gx1, gx1 * B, d1, i1, w2.undecided};     // p1 against p2
+        const ScanJob s2{p2, w1.F, w1.H, w1.nmax, M, N, w1.Ntp, gx2, gx2 * B, d2, i2, w1.undecided};     // p2 against p1
+        const bool long_first = (long long)N > (long long)M;       // direction 2 scans the N targets: more work per workgroup
+        const ScanJob& ja = long_first ? s2 : s1;
+        const ScanJob& jb = long_first ? s1 : s2;
         if (fp32_filter)
-            VPN_LAUNCH(chamfer_nn_mfma_kernel<0>, dim3(gx * B), dim3(CM_BLOCK), 0, s, q, t, w.F, w.H, w.nmax, Nq, Nt, w.Ntp, gx,
-                       d, idx, w.undecided, B);
+            VPN_LAUNCH(chamfer_nn_mfma_kernel<0>, dim3(ja.G + jb.G), dim3(CM_BLOCK), 0, s, ja, jb, B);
         else
-            VPN_LAUNCH(chamfer_nn_mfma_kernel<1>, dim3(gx * B), dim3(CM_BLOCK), 0, s, q, t, w.F, w.H, w.nmax, Nq, Nt, w.Ntp, gx,
-                       d, idx, w.undecided, B);
+            VPN_LAUNCH(chamfer_nn_mfma_kernel<1>, dim3(ja.G + jb.G), dim3(CM_BLOCK), 0, s, ja, jb, B);
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
     }
