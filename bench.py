@@ -211,10 +211,10 @@ def main():
 
     # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 cannot run inside bench.py)
     try:
-        tr = json.load(open(os.path.join(ROOT, 'profiles', 'r01i_traffic.json')))['kernels'].get(dom)
+        tr = json.load(open(os.path.join(ROOT, 'profiles', 'r01j_traffic.json')))['kernels'].get(dom)
         if tr and (B, K, n, M, H) == (64, 32, 256, 2048, 256):
             roofline['traffic'] = tr['traffic_bytes']
-            roofline['traffic_source'] = 'profiles/r01i_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same workload)'
+            roofline['traffic_source'] = 'profiles/r01j_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same workload)'
     except (OSError, ValueError, KeyError):
         pass
 
