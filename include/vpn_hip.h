@@ -203,6 +203,17 @@ int vpn_camera_transform_fwd(const float* points, const float* dists, const floa
 int vpn_camera_transform_bwd(const float* grad_out, const float* dists, const float* elevs, const float* azims,
                              const float* angles, int B, int N, int to_object, float* grad_points, void* stream);
 
+/* ---- primitive -> mesh vertices (row f2: modules/meshing/sphere.py:8-27, cuboid.py:8-26, meshing.py:27-46)
+ * verts [B, Ptot, 3]: verts[b][offsets[k] + p] = R(q_bk) (tpl[p] * v_bk) + t_bk, tpl = tpl_sphere [Ps,3] or
+ * tpl_cuboid [Pc,3] by kinds[k]; offsets [K+1] int32 (device): vertex offsets of the composed mesh, offsets[K] = Ptot.
+ * The reference parses the OBJ template from disk per (sample, primitive); here the templates are device arrays the
+ * caller keeps (a template of a kind that does not occur may be NULL). */
+int vpn_mesh_fwd(const float* params, const int32_t* kinds, const int32_t* offsets,
+                 const float* tpl_sphere, const float* tpl_cuboid, int B, int K, int Ptot, float* verts, void* stream);
+int vpn_mesh_bwd(const float* params, const int32_t* kinds, const int32_t* offsets,
+                 const float* tpl_sphere, const float* tpl_cuboid, int B, int K, int Ptot,
+                 const float* grad_verts, float* grad_params, void* stream);
+
 /* ---- head post-processing into packed primitive parameters (row f4)
  * restrict_range + split + restrict_volumes of the reference's model (modules/network/vpnet_one_resnet.py:34-41,
  * :67-85): volumes [B,3K], rotates [B,4K], translates [B,3K] (raw head outputs) -> params [B,K,10].

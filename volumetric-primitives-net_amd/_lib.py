@@ -43,6 +43,8 @@ SIGNATURES = {
                                  _i, _c_f]),
     'vpn_camera_transform_fwd': (_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _i, _i, _i, _c_f, _c_f]),
     'vpn_camera_transform_bwd': (_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _i, _i, _i, _c_f, _c_f]),
+    'vpn_mesh_fwd': (_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _i, _i, _i, _c_f, _c_f]),
+    'vpn_mesh_bwd': (_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _i, _i, _i, _c_f, _c_f, _c_f]),
     'vpn_head_pack_fwd': (_i, [_c_f, _c_f, _c_f, _i, _i, _i, _f, _f, _f, _f, _f, _c_f, _c_f]),
     'vpn_head_pack_bwd': (_i, [_c_f, _c_f, _c_f, _c_f, _i, _i, _i, _f, _f, _f, _f, _f, _c_f, _c_f, _c_f, _c_f]),
     'vpn_emd_workspace': (_sz, [_i, _i]),

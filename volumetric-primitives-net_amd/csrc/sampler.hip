@@ -347,6 +347,100 @@ __global__ __launch_bounds__(TR_BLOCK) void transform_bwd_kernel(
     }
 }
 
+// ---- primitive -> mesh vertices (row f2: modules/meshing/sphere.py:8-27, cuboid.py:8-26, meshing.py:27-46)
+// The reference parses an OBJ template from disk for every (sample, primitive), scales its vertices by v,
+// runs transform_points and concatenates the K meshes.  Here the templates sit on the device and one launch writes
+// verts[b][offsets[k] + p] = R(q_bk) (tpl_kind(k)[p] * v_bk) + t_bk for all (b, k).  offsets [K+1] are the vertex
+// offsets of the composed mesh (compose_meshes appends the primitives in order).
+constexpr int MESH_BLOCK = 256;
+
+__global__ __launch_bounds__(MESH_BLOCK) void mesh_fwd_kernel(const float* __restrict__ params,
+                                                              const int32_t* __restrict__ kinds,
+                                                              const int32_t* __restrict__ offsets,
+                                                              const float* __restrict__ tpl_sphere,
+                                                              const float* __restrict__ tpl_cuboid, int K, int Ptot,
+                                                              float* __restrict__ verts) {
+    __shared__ Pose S;
+    const int k = blockIdx.x, b = blockIdx.y;
+    const float* prm = params + ((size_t)b * K + k) * VPN_PARAM_STRIDE;
+    if (threadIdx.x == 0) S = make_pose(prm[3], prm[4], prm[5], prm[6]);
+    __syncthreads();
+    const Mat3& R = S.R;
+    const float* tpl = kinds[k] == VPN_SPHERE ? tpl_sphere : tpl_cuboid;
+    const int o = offsets[k], P = offsets[k + 1] - o;
+    const float v0 = prm[0], v1 = prm[1], v2 = prm[2], t0 = prm[7], t1 = prm[8], t2 = prm[9];
+    float* out = verts + ((size_t)b * Ptot + o) * 3;
+    for (int p = threadIdx.x; p < P; p += MESH_BLOCK) {
+        const float x = tpl[p * 3] * v0, y = tpl[p * 3 + 1] * v1, z = tpl[p * 3 + 2] * v2;     // sphere.py:15
+        out[p * 3 + 0] = (R.m[0][0] * x + R.m[0][1] * y + R.m[0][2] * z) + t0;
+        out[p * 3 + 1] = (R.m[1][0] * x + R.m[1][1] * y + R.m[1][2] * z) + t1;
+        out[p * 3 + 2] = (R.m[2][0] * x + R.m[2][1] * y + R.m[2][2] * z) + t2;
+    }
+}
+
+// backward: the same chain rule as the sampler's (the canonical coefficient of a vertex is its template coordinate)
+__global__ __launch_bounds__(MESH_BLOCK) void mesh_bwd_kernel(const float* __restrict__ params,
+                                                              const int32_t* __restrict__ kinds,
+                                                              const int32_t* __restrict__ offsets,
+                                                              const float* __restrict__ tpl_sphere,
+                                                              const float* __restrict__ tpl_cuboid, int K, int Ptot,
+                                                              const float* __restrict__ grad_verts,
+                                                              float* __restrict__ grad_params) {
+    __shared__ Pose S;
+    __shared__ float red[MESH_BLOCK / 64][12];
+    const int k = blockIdx.x, b = blockIdx.y;
+    const float* prm = params + ((size_t)b * K + k) * VPN_PARAM_STRIDE;
+    if (threadIdx.x == 0) S = make_pose(prm[3], prm[4], prm[5], prm[6]);
+    __syncthreads();
+    const float* tpl = kinds[k] == VPN_SPHERE ? tpl_sphere : tpl_cuboid;
+    const int o = offsets[k], P = offsets[k + 1] - o;
+    const float* gp = grad_verts + ((size_t)b * Ptot + o) * 3;
+    float acc[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc[i] = 0.0f;
+    for (int p = threadIdx.x; p < P; p += MESH_BLOCK) {
+        const float c[3] = {tpl[p * 3], tpl[p * 3 + 1], tpl[p * 3 + 2]};
+        const float g[3] = {gp[p * 3], gp[p * 3 + 1], gp[p * 3 + 2]};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) acc[r * 3 + a] += g[r] * c[a];
+            acc[9 + r] += g[r];
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        const float s = wave_sum(acc[i]);
+        if (lane == 0) red[wave][i] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float G[3][3], gt[3];
+        for (int r = 0; r < 3; ++r) {
+            for (int a = 0; a < 3; ++a) {
+                float s = 0.0f;
+                for (int w = 0; w < MESH_BLOCK / 64; ++w) s += red[w][r * 3 + a];
+                G[r][a] = s;
+            }
+            float s = 0.0f;
+            for (int w = 0; w < MESH_BLOCK / 64; ++w) s += red[w][9 + r];
+            gt[r] = s;
+        }
+        const Mat3& R = S.R;
+        float gR[3][3], gv[3], gq[4];
+        for (int a = 0; a < 3; ++a) {
+            gv[a] = R.m[0][a] * G[0][a] + R.m[1][a] * G[1][a] + R.m[2][a] * G[2][a];   // p = R (c*v) + t
+            for (int r = 0; r < 3; ++r) gR[r][a] = G[r][a] * prm[a];
+        }
+        pose_backward(S, prm[3], prm[4], prm[5], gR, gq);
+        float* og = grad_params + ((size_t)b * K + k) * VPN_PARAM_STRIDE;
+        og[0] = gv[0]; og[1] = gv[1]; og[2] = gv[2];
+        og[3] = gq[0]; og[4] = gq[1]; og[5] = gq[2]; og[6] = gq[3];
+        og[7] = gt[0]; og[8] = gt[1]; og[9] = gt[2];
+    }
+}
+
 // ---- fused camera transforms (modules/transform/transform.py:21-73): the reference chains 3-4 rotate_points
 // calls and a scale over the whole cloud; here the per-sample 3x3 is composed once and applied in one pass.
 //   to_object != 0  view_to_obj_points :21-47:  p * dist <- R(-z,-e) R(y',-a) R(x,-angle) p,  y' = R(-z,e) y
@@ -496,6 +590,38 @@ extern "C" int vpn_sample_chamfer_bwd(const float* params, const int32_t* kinds,
     if (lds > 60 * 1024) return VPN_E_TOOBIG;                           // 15 k GT points; beyond: vpn_chamfer_bwd + vpn_sample_bwd
     VPN_LAUNCH(sample_chamfer_bwd_kernel, dim3(K, B), dim3(SAMP_BLOCK), lds, (hipStream_t)stream, params, kinds, u, seed,
                sample_base, K, n, points, gt_points, M, dist1, idx1, dist2, idx2, grad_loss_b, w1, w2, grad_params);
+    VPN_LAUNCH_CHECK();
+    return 0;
+}
+
+static int mesh_check(const void* params, const void* kinds, const void* offsets, const void* ts, const void* tc,
+                      int B, int K, int Ptot) {
+    if (!params || !kinds || !offsets || (!ts && !tc)) return VPN_E_BADARG;
+    if (B <= 0 || K <= 0 || Ptot <= 0) return VPN_E_BADARG;
+    if (B > 65535 || (long long)B * Ptot * 3 > 0x7fffffffLL) return VPN_E_TOOBIG;
+    return 0;
+}
+
+extern "C" int vpn_mesh_fwd(const float* params, const int32_t* kinds, const int32_t* offsets,
+                            const float* tpl_sphere, const float* tpl_cuboid, int B, int K, int Ptot, float* verts,
+                            void* stream) {
+    int rc = mesh_check(params, kinds, offsets, tpl_sphere, tpl_cuboid, B, K, Ptot);
+    if (rc) return rc;
+    if (!verts) return VPN_E_BADARG;
+    VPN_LAUNCH(mesh_fwd_kernel, dim3(K, B), dim3(MESH_BLOCK), 0, (hipStream_t)stream, params, kinds, offsets, tpl_sphere,
+               tpl_cuboid, K, Ptot, verts);
+    VPN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vpn_mesh_bwd(const float* params, const int32_t* kinds, const int32_t* offsets,
+                            const float* tpl_sphere, const float* tpl_cuboid, int B, int K, int Ptot,
+                            const float* grad_verts, float* grad_params, void* stream) {
+    int rc = mesh_check(params, kinds, offsets, tpl_sphere, tpl_cuboid, B, K, Ptot);
+    if (rc) return rc;
+    if (!grad_verts || !grad_params) return VPN_E_BADARG;
+    VPN_LAUNCH(mesh_bwd_kernel, dim3(K, B), dim3(MESH_BLOCK), 0, (hipStream_t)stream, params, kinds, offsets, tpl_sphere,
+               tpl_cuboid, K, Ptot, grad_verts, grad_params);
     VPN_LAUNCH_CHECK();
     return 0;
 }

@@ -6,3 +6,4 @@ from .render import VertexRenderer
 from .transform import (transform_points, rotate_points, translate_points, view_to_obj_points,
                         obj_to_view_points, rotate_points_forward_x_axis)
 from .network import pack_head_outputs, split_primitives
+from .meshing import Meshing, TriangleMesh, load_obj

@@ -97,6 +97,37 @@ class TransformFunction(Function):
         return gp, gq, gt
 
 
+class MeshFunction(Function):
+    """Vertices of all K primitives of all B samples in one launch (modules/meshing of the reference):
+    params [B,K,10], templates [P,3] -> verts [B, sum_k P_kind(k), 3] in primitive order."""
+
+    @staticmethod
+    def forward(ctx, params, kinds, offsets, tpl_sphere, tpl_cuboid, ptot):
+        params = _f32c(params)
+        B, K, _ = params.shape
+        ts = _f32c(tpl_sphere) if tpl_sphere is not None else None
+        tc = _f32c(tpl_cuboid) if tpl_cuboid is not None else None
+        verts = torch.empty((B, int(ptot), 3), dtype=torch.float32, device=params.device)
+        _lib.call('vpn_mesh_fwd', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(offsets), _lib.ptr(ts), _lib.ptr(tc), B, K,
+                  int(ptot), _lib.ptr(verts), _lib.stream())
+        ctx.save_for_backward(params, kinds, offsets, *(x for x in (ts, tc) if x is not None))
+        ctx.which = (ts is not None, tc is not None, int(ptot))
+        return verts
+
+    @staticmethod
+    def backward(ctx, grad_verts):
+        params, kinds, offsets, *tpls = ctx.saved_tensors
+        has_s, has_c, ptot = ctx.which
+        ts = tpls[0] if has_s else None
+        tc = tpls[-1] if has_c else None
+        B, K, _ = params.shape
+        g = _f32c(grad_verts)
+        gp = torch.empty_like(params)
+        _lib.call('vpn_mesh_bwd', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(offsets), _lib.ptr(ts), _lib.ptr(tc), B, K, ptot,
+                  _lib.ptr(g), _lib.ptr(gp), _lib.stream())
+        return gp, None, None, None, None, None
+
+
 class HeadPackFunction(Function):
     """restrict_range + split + restrict_volumes of the reference's model (vpnet_one_resnet.py:34-41, :67-85) fused:
     raw head outputs volumes [B,3K], rotates [B,4K], translates [B,3K] -> packed params [B,K,10]."""
