@@ -70,3 +70,24 @@ def test_head_pack_vs_oracle(B, K, is_sigmoid):
     kinds = vpn_amd.kinds_tensor([0] * K, torch.device(DEV))
     pts = vpn_amd.Sampling.sample_primitives(out.detach(), kinds, 8, seed=3)
     assert pts.shape == (B, K * 8, 3) and bool(torch.isfinite(pts).all())
+
+
+def test_on_disk_formats():
+    """split.csv, rendering_metadata.txt and RGBA renderings (dataset.py:98-151), on hand-written samples."""
+    from vpn_amd.modules import dataset as D
+    csv = ('id,synsetId,subSynsetId,modelId,split\n'
+           '1,02691156,02691156,aaa111,train\n2,02691156,02690373,bbb222,val\n3,03001627,03001627,ccc333,test\n'
+           '4,03001627,03001627,ddd444,train\nbroken,line\n')
+    sp = D.parse_split_csv(csv)
+    assert sp['train'] == [('02691156', 'aaa111'), ('03001627', 'ddd444'), ('02691156', 'bbb222')]   # val after train
+    assert sp['test'] == [('03001627', 'ccc333')]
+    meta = '293.65 26.04 0 0.78 25\n118.4 29.9 0 0.91 25\nnot a camera line\n'
+    az, el, di = D.parse_rendering_metadata(meta)
+    assert az == [293.65, 118.4] and el == [26.04, 29.9]
+    assert abs(di[0] - 0.78 * 1.754) < 1e-12 and abs(di[1] - 0.91 * 1.754) < 1e-12                   # dataset.py:147
+    img = torch.rand(4, 8, 8)
+    rgb, sil = D.split_rgba(img)
+    assert torch.equal(rgb, img[:3]) and torch.equal(sil, img[3:4]) and sil.shape == (1, 8, 8)
+    rgbn, _ = D.split_rgba(img, normalize=True)
+    assert torch.allclose(rgbn[1], (img[1] - 0.456) / 0.224)
+    assert D.split_rgba(torch.rand(2, 4, 8, 8))[1].shape == (2, 1, 8, 8)

@@ -7,3 +7,4 @@ from .transform import (transform_points, rotate_points, translate_points, view_
                         obj_to_view_points, rotate_points_forward_x_axis)
 from .network import pack_head_outputs, split_primitives
 from .meshing import Meshing, TriangleMesh, load_obj
+from .dataset import parse_split_csv, parse_rendering_metadata, split_rgba
