@@ -95,13 +95,17 @@ def main():
     cd_fn = vpn_amd.ChamferDistanceLoss()
     sigma, gamma, z_far = vpn_amd.config.RASTER_SIGMA, vpn_amd.config.RASTER_GAMMA, vpn_amd.config.RASTER_Z_FAR
 
+    unit_total = torch.tensor([0.0, 0.0, 1.0], device=dev)
+
     def compute(i):
         # total = ChamferDistanceLoss(sample(params), gt) + SilhouetteLoss(L1) + L1 depth loss  (train.py:243-262),
         # one autograd node: sampler -> Chamfer scans -> raster with fused image losses, and the matching backward
         params.grad = None
         out = vpn_amd.HotPathLossFunction.apply(params, kinds, cam, gt_points, gt_sil, gt_depth, n, 1234 + i,
                                                 rank * B, H, W, sigma, gamma, z_far, 1.0, 1.0, 1.0)
-        out[2].backward()
+        # d(total)/d(params): the unit vector selects the total (index 2) of the three losses.  `out[2].backward()`
+        # is the same thing through three more ATen kernels (ones_like, and SelectBackward's zeros + copy).
+        out.backward(unit_total)
         return out[2]
 
     def step(i):
