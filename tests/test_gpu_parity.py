@@ -273,6 +273,31 @@ def test_chamfer_vs_oracle_ragged(vpn, B, N, M):
     _chamfer_exact(vpn, torch.rand(B, N, 3, generator=gen) - 0.5, torch.rand(B, M, 3, generator=gen) - 0.5)
 
 
+def test_chamfer_modes_agree_on_random_shapes(vpn):
+    """Every exact scan strategy against the brute-force scan on 24 random problems: sizes from 1 to ~3000 that are
+    not multiples of anything, batch sizes that are not multiples of 8 (the XCD-aware decodings fall back), uniform /
+    clustered / quantised (many exact ties, long undecided lists) / duplicated clouds."""
+    gen = torch.Generator().manual_seed(2024)
+    for case in range(24):
+        B = [1, 2, 3, 5, 8, 9][case % 6]
+        N = int(torch.randint(1, 3000, (1,), generator=gen))
+        M = int(torch.randint(1, 3000, (1,), generator=gen))
+        kind = case % 4
+        p1 = torch.rand(B, N, 3, generator=gen) - 0.5
+        p2 = torch.rand(B, M, 3, generator=gen) - 0.5
+        if kind == 1:                                        # clustered
+            p1 = 0.02 * p1 + (torch.rand(B, 1, 3, generator=gen) - 0.5)
+        elif kind == 2:                                      # quantised: exact ties everywhere
+            p1, p2 = torch.round(p1 * 8) / 8, torch.round(p2 * 8) / 8
+        elif kind == 3 and N > 1:                            # duplicated points inside a cloud
+            p1[:, N // 2:] = p1[:, :N - N // 2]
+        a1, b1, a2, b2 = vpn.chamfer_nn(g(p1), g(p2), mode='brute')
+        for mode in ('mfma', 'mfma32', 'sorted', 'pruned'):
+            d1, i1, d2, i2 = vpn.chamfer_nn(g(p1), g(p2), mode=mode)
+            ok = torch.equal(d1, a1) and torch.equal(i1, b1) and torch.equal(d2, a2) and torch.equal(i2, b2)
+            assert ok, 'case %d (B=%d N=%d M=%d kind=%d): %s differs from brute force' % (case, B, N, M, kind, mode)
+
+
 def test_chamfer_lattice_ties(vpn):
     """Points on a coarse lattice: masses of exactly equal distances -> lowest index must win."""
     gen = torch.Generator().manual_seed(5)
