@@ -370,6 +370,7 @@ class RasterLossFunction(Function):
 
 
 _PATTERNS = {}
+FUSED_BWD_MAX_GT = 15360      # vpn_sample_chamfer_bwd keeps per-wave match lists of the GT points in LDS (include/vpn_hip.h)
 _SIDE = {}
 # optionally run the raster branch of HotPathLossFunction on a second HIP stream (VPN_CONCURRENT=1)
 CONCURRENT_BRANCHES = os.environ.get('VPN_CONCURRENT', '0') == '1'   # measured: no gain at C3 (each kernel already fills the GPU)
@@ -481,9 +482,16 @@ class HotPathLossFunction(Function):
                           _lib.stream())
         # Chamfer backward and sampler backward in one launch: the [B,N,3] point gradient never exists
         grad_params = torch.empty_like(params)
-        _lib.call('vpn_sample_chamfer_bwd', _lib.ptr(params), _lib.ptr(kinds), None, seed, base, B, K, n, _lib.ptr(points),
-                  _lib.ptr(gt_points), M, _lib.ptr(d1), _lib.ptr(i1), _lib.ptr(d2), _lib.ptr(i2), _lib.ptr(gvec), 1.0, 1.0,
-                  _lib.ptr(grad_params), s)
+        if M <= FUSED_BWD_MAX_GT:
+            _lib.call('vpn_sample_chamfer_bwd', _lib.ptr(params), _lib.ptr(kinds), None, seed, base, B, K, n,
+                      _lib.ptr(points), _lib.ptr(gt_points), M, _lib.ptr(d1), _lib.ptr(i1), _lib.ptr(d2), _lib.ptr(i2),
+                      _lib.ptr(gvec), 1.0, 1.0, _lib.ptr(grad_params), s)
+        else:                                                   # GT clouds beyond the fused kernel's LDS match lists
+            grad_points = torch.empty_like(points)
+            _lib.call('vpn_chamfer_bwd', _lib.ptr(points), _lib.ptr(gt_points), _lib.ptr(d1), _lib.ptr(i1), _lib.ptr(d2),
+                      _lib.ptr(i2), _lib.ptr(gvec), B, N, M, 1.0, 1.0, _lib.ptr(grad_points), None, s)
+            _lib.call('vpn_sample_bwd', _lib.ptr(params), _lib.ptr(kinds), None, seed, base, B, K, n,
+                      _lib.ptr(grad_points), _lib.ptr(grad_params), s)
         if side is not None:
             main.wait_stream(side)
             grad_params += grad_raster
