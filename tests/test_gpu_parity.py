@@ -604,6 +604,28 @@ def test_hot_path_loss_single_node(vpn):
     assert rel_err(pg.grad.cpu(), pm.grad.cpu()) <= 1e-5
 
 
+def test_hot_path_large_gt_cloud_falls_back(vpn):
+    """GT clouds beyond the fused backward's LDS match lists (M > 15360) take the two-kernel backward: same result
+    as the module composition."""
+    gen = torch.Generator().manual_seed(34)
+    B, K, n, M, H, W = 1, 4, 64, 16000, 32, 32
+    params = rand_params(gen, B, K)
+    kt = vpn.kinds_tensor([0] * K, torch.device(DEV))
+    gt_pts = g(torch.rand(B, M, 3, generator=gen) - 0.5)
+    gt_sil = g((torch.rand(B, 1, H, W, generator=gen) > 0.5).float())
+    cam = g(torch.tensor([[1.0, 0.0, 0.0]]))
+    pg = g(params).requires_grad_(True)
+    out = vpn.HotPathLossFunction.apply(pg, kt, cam, gt_pts, gt_sil, None, n, 5, 0, H, W, 0.05, 0.1, 2.0, 1.0, 1.0, 0.0)
+    out[2].backward()
+    pm = g(params).requires_grad_(True)
+    pts = vpn.Sampling.sample_primitives(pm, kt, n, seed=5)
+    img = vpn.RasterLossFunction.apply(pm, kt, cam, gt_sil, None, H, W, 0.05, 0.1, 2.0, False)
+    tot = vpn.ChamferDistanceLoss()(pts, gt_pts) + img[0]
+    tot.backward()
+    assert rel_err(out[2].detach().cpu(), tot.detach().cpu()) <= 1e-5
+    assert rel_err(pg.grad.cpu(), pm.grad.cpu()) <= 1e-5
+
+
 def test_raster_full_size_properties(vpn):
     """Config 3 raster (B=64, K=32, 256x256): too big for the dense oracle, so: oracle on two
     images, plus linearity of the backward in the incoming gradient and determinism."""
