@@ -136,10 +136,13 @@ __global__ __launch_bounds__(EMD_THREADS) void emd_auction_kernel(const float* _
             const int tpad = (tn + 64 * EMD_UNROLL - 1) / (64 * EMD_UNROLL) * (64 * EMD_UNROLL);
             const bool final_tile = t0 + EMD_TILE >= n;
             if (t0 > 0) __syncthreads();
-            for (int j = tid; j < tpad; j += EMD_THREADS) {
+            const bool coords = n > EMD_TILE || it == 0;        // a one-tile problem keeps its coordinates in LDS: only
+            for (int j = tid; j < tpad; j += EMD_THREADS) {     // the prices change from round to round
                 if (j < tn) {
-                    const float* c = p2 + (size_t)(t0 + j) * 3;
-                    tx[j] = c[0]; ty[j] = c[1]; tz[j] = c[2];
+                    if (coords) {
+                        const float* c = p2 + (size_t)(t0 + j) * 3;
+                        tx[j] = c[0]; ty[j] = c[1]; tz[j] = c[2];
+                    }
                     tp[j] = emd_ld(price + t0 + j);
                 } else {                                        // padding never wins: value = -inf
                     tx[j] = 0.0f; ty[j] = 0.0f; tz[j] = 0.0f; tp[j] = __builtin_inff();
@@ -195,13 +198,14 @@ __global__ __launch_bounds__(EMD_THREADS) void emd_auction_kernel(const float* _
             if (u >= U) continue;
             const int i = ulist[u], t = bid[i];
             if (last) { emd_st(assign + i, t); continue; }      // prices and owners are not read again
-            const unsigned long long key = emd_ld(top + t);
+            const unsigned long long key = emd_ld(top + t);     // the three loads depend only on t: issued together,
+            const int prev = emd_ld(assign_inv + t);            // one L2 round trip instead of a chain of three
+            const float pt = emd_ld(price + t);
             if (0x7fffffff - (int)(unsigned)key != i) continue;
-            const int prev = emd_ld(assign_inv + t);
             if (prev != -1) emd_st(assign + prev, -1);
             emd_st(assign_inv + t, i);
             emd_st(assign + i, t);
-            emd_st(price + t, emd_ld(price + t) + inc[i]);
+            emd_st(price + t, pt + inc[i]);
             emd_st(top + t, 0ull);                              // :212
         }
         emd_group_sync(counter, passed, G);
