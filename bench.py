@@ -1,18 +1,23 @@
 """bench.py — render + Chamfer forward+backward images/s on MI355X (BASELINE.json metric).
 
 A step = one pass of the hot path over one batch of synthetic input already resident in HBM:
-  sampler fwd (Philox in-kernel) -> Chamfer(pred, gt) fwd -> raster fwd (silhouette+depth)
-  -> L1(sil) + L1(depth) -> backward of all of it to d/d(v,q,t) [-> RCCL all-gather of the per-rank gradient slices if N>1].
-Workload (config.workload): BASELINE configs[2] = C3: B=64 per GPU, K=32 sphere primitives,
-256x256, n=256 points per primitive (N=8192) vs M=2048 GT points.
+  sampler fwd (Philox in-kernel, fresh draws every step) -> Chamfer(pred, gt) fwd -> raster fwd (silhouette+depth)
+  -> L1(sil) + L1(depth) -> backward of all of it to d/d(v,q,t) [-> one RCCL collective on the gradients if N>1].
+Workloads (config.workload):
+  c3 (default, the headline): BASELINE configs[2]: B=64 per GPU, K=32 sphere primitives, 256x256, n=256 points per
+     primitive (N=8192) vs M=2048 GT points.  With --global-batch G the batch is split G/N per rank (BASELINE
+     configs[3] = C4: G=256, strong scaling) instead of 64 per rank (weak scaling).
+  c2: BASELINE configs[1]: K=16, 128x128 silhouette+depth, B=32, raster fwd/bwd only.  The default
+     run also measures it and reports it under the key "c2" next to the C3 headline.
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W] [--workload c2] [--global-batch 256] [--collective allreduce]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline`.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -23,7 +28,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-VALU_PEAK_TFLOPS = 157.3     # fp32 vector peak (packed FMA)
+FP32_PEAK_TFLOPS = 157.3     # fp32 vector peak = fp32-input MFMA peak (MI355X_MICROARCH.md chip table)
+BF16_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA
+N_SIMD = 1024                # 256 CUs x 4 SIMD-32
+PMC_FILE = os.path.join(ROOT, 'profiles', 'r02_pmc.json')     # written by tools/pmc_collect.py from rocprofv3 passes
 
 
 def synth_inputs(B, K, M, seed, device):
@@ -36,22 +44,154 @@ def synth_inputs(B, K, M, seed, device):
     return torch.cat([v, q, t], 2).to(device), gt_points.to(device)
 
 
+def event_windows(run, steps, windows):
+    """Median / min / max over `windows` windows of `steps` calls each, timed with a HIP event pair on the current
+    stream (the stream the step is launched on).  Returns milliseconds per step."""
+    out = []
+    for _ in range(windows):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for i in range(steps):
+            run(i)
+        b.record()
+        b.synchronize()
+        out.append(a.elapsed_time(b) / steps)
+    return {'median': statistics.median(out), 'min': min(out), 'max': max(out), 'windows': windows, 'steps': steps}
+
+
+def load_pmc(workload_key):
+    """Counter summaries of the same command collected with rocprofv3 (tools/pmc_collect.py -> profiles/r02_pmc.json):
+    {kernel: {counter: mean per dispatch}} for this workload, or {}."""
+    try:
+        return json.load(open(PMC_FILE)).get(workload_key, {})
+    except (OSError, ValueError):
+        return {}
+
+
+def valu_issue_roofline(name, pmc, launch_us):
+    """Executed-work roofline of a VALU-bound kernel: wave-instructions actually issued (PMC) x their issue cost
+    (2 cycles per wave64 instruction on a SIMD-32, 4 for the quarter-rate transcendentals: MI355X_MICROARCH.md
+    'vector-instruction ISSUE cost' halves of the one-wave figures) / (launch time x SIMDs x clock)."""
+    k = pmc.get(name)
+    if not k or 'SQ_INSTS_VALU' not in k:
+        return None
+    valu = k['SQ_INSTS_VALU']
+    trans = k.get('SQ_INSTS_VALU_TRANS', 0.0)
+    cycles = 2.0 * (valu - trans) + 4.0 * trans
+    clock = 2.4e9
+    frac = cycles / (launch_us * 1e-6 * clock * N_SIMD)
+    out = {'valu_wave_insts': valu, 'trans_wave_insts': trans, 'issue_cycles': cycles,
+           'frac_of_valu_issue_peak_at_2.4GHz': round(frac, 4)}
+    if 'GRBM_GUI_ACTIVE' in k:      # sum over the 8 XCDs of active cycles -> the clock the launch actually ran at
+        eff = k['GRBM_GUI_ACTIVE'] / 8.0 / (launch_us * 1e-6)
+        out['effective_clock_GHz'] = round(eff / 1e9, 3)
+        out['frac_of_valu_issue_peak_at_effective_clock'] = round(cycles / (launch_us * 1e-6 * eff * N_SIMD), 4)
+    for c in ('SQ_INSTS_SALU', 'SQ_WAVES', 'SQ_WAIT_INST_ANY', 'SQ_WAVE_CYCLES', 'SQ_BUSY_CYCLES'):
+        if c in k:
+            out[c] = k[c]
+    return out
+
+
+def traffic_of(name, pmc):
+    """HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes (KB), corrected as the guide prescribes: FETCH_SIZE
+    doubled for kernels whose reads are 16-B-per-lane coalesced streams (flagged per kernel by tools/pmc_collect.py)."""
+    k = pmc.get(name)
+    if not k or 'FETCH_SIZE' not in k or 'WRITE_SIZE' not in k:
+        return None
+    mul = 2.0 if k.get('fetch_doubled') else 1.0
+    return int((k['FETCH_SIZE'] * mul + k['WRITE_SIZE']) * 1024)
+
+
+def raster_only(vpn_amd, _lib, dev, B, K, H, steps, warmup, windows, pmc_key, use_graph=True):
+    """C2: vpn_raster_loss_fwd + vpn_raster_loss_bwd alone (render, L1 silhouette + L1 depth, gradient to (v,q,t)),
+    HIP-graph replay, hipEvent timing; per-kernel times from the library's launch profiler."""
+    W = H
+    kinds = vpn_amd.kinds_tensor([vpn_amd.SPHERE] * K, dev)
+    params, _ = synth_inputs(B, K, 8, 1234, dev)
+    params.requires_grad_(True)
+    cam = torch.tensor([[1.0, 0.0, 0.0]], device=dev).expand(B, 3).contiguous()
+    p2, _ = synth_inputs(B, K, 8, 4321, dev)
+    sigma, gamma, z_far = vpn_amd.config.RASTER_SIGMA, vpn_amd.config.RASTER_GAMMA, vpn_amd.config.RASTER_Z_FAR
+    with torch.no_grad():
+        a2, d2 = vpn_amd.RasterFunction.apply(p2, kinds, cam, H, W, sigma, gamma, z_far)
+    gt_sil, gt_depth = (a2 > 0.5).float(), d2.clone()
+    ones = torch.ones(2, device=dev)
+
+    def compute(_i=0):
+        params.grad = None
+        out = vpn_amd.RasterLossFunction.apply(params, kinds, cam, gt_sil, gt_depth, H, W, sigma, gamma, z_far, False)
+        out.backward(ones)
+        return out
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            compute()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    run = compute
+    if use_graph:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            compute()
+        run = lambda i=0: graph.replay()
+    for _ in range(warmup):
+        run()
+    torch.cuda.synchronize()
+    ev = event_windows(run, steps, windows)
+    ksteps = 20
+    with _lib.KernelProfile() as kp:
+        for _ in range(ksteps):
+            compute()
+    kern = kp.summary()
+    kernel_us = {k: {'calls_per_step': round(v[0] / ksteps, 2), 'avg_us': round(v[1] * 1e3, 2)} for k, v in kern.items()}
+    fwd_b, bwd_b = B * (40 * K + 8 * H * W), B * (8 * H * W + 80 * K)          # SURVEY.md 8d
+    pmc = load_pmc(pmc_key)
+    roof = {}
+    for name, alg in (('raster_fwd_kernel<1>', fwd_b), ('raster_bwd_kernel<1>', bwd_b)):
+        if name not in kern:
+            continue
+        us = kern[name][1] * 1e3
+        gbs = alg / (us * 1e-6) / 1e9
+        roof[name] = {'avg_launch_us': round(us, 2), 'algorithmic_bytes_per_launch': alg,
+                      'hbm': {'bound': 'hbm', 'achieved': round(gbs, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                              'frac': round(gbs / HBM_PEAK_GBS, 5), 'traffic': traffic_of(name, pmc)},
+                      'executed_work': valu_issue_roofline(name, pmc, us)}
+    ms = ev['median']
+    return {'workload': 'C2: B=%d, K=%d sphere primitives, %dx%d silhouette+depth, raster fwd+bwd only '
+                        '(vpn_raster_loss_fwd/bwd: render + L1(sil) + L1(depth) + gradient)' % (B, K, H, W),
+            'images_per_s': round(B / ms * 1e3, 1), 'ms_per_step': round(ms, 5), 'timing': ev,
+            'algorithmic_bytes_per_image': (fwd_b + bwd_b) // B, 'kernel_us': kernel_us, 'roofline': roof,
+            'pmc_source': os.path.relpath(PMC_FILE, ROOT) if pmc else None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--batch', type=int, default=64, help='samples per GPU')
-    ap.add_argument('--prims', type=int, default=32)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--workload', choices=['c3', 'c2'], default='c3')
+    ap.add_argument('--batch', type=int, default=None, help='samples per GPU (default 64 for c3, 32 for c2)')
+    ap.add_argument('--global-batch', type=int, default=None,
+                    help='fixed GLOBAL batch split evenly over the ranks (C4: 256): strong scaling')
+    ap.add_argument('--prims', type=int, default=None)
     ap.add_argument('--points', type=int, default=256, help='sampled points per primitive')
     ap.add_argument('--gt-points', type=int, default=2048)
-    ap.add_argument('--size', type=int, default=256)
+    ap.add_argument('--size', type=int, default=None)
+    ap.add_argument('--collective', choices=['allreduce', 'allgather'], default='allreduce',
+                    help='the one gradient exchange per step when N>1 (north_star: RCCL all-reduce)')
+    ap.add_argument('--windows', type=int, default=5, help='hipEvent windows of --steps replays each (median reported)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-c2', action='store_true', help='skip the C2 raster-only measurement of the default run')
+    ap.add_argument('--no-extras', action='store_true', help='skip C2, EMD and the CPU baseline (profiling runs)')
     ap.add_argument('--no-graph', action='store_true', help='launch every step eagerly instead of replaying a HIP graph')
     ap.add_argument('--dist-selftest', action='store_true',
-                    help='run the multi-rank code path (RCCL group, gradient all-gather) even with one rank')
+                    help='run the multi-rank code path (RCCL group, gradient collective) even with one rank')
     ap.add_argument('--cpu-sample', type=int, default=32, help='images in the CPU baseline sample')
     args = ap.parse_args()
+    if args.no_extras:
+        args.no_cpu_baseline = args.no_c2 = True
 
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -72,46 +212,86 @@ def main():
 
     import vpn_amd
     from vpn_amd import _lib
-    from vpn_amd.dist import GradAllGather
+    from vpn_amd.dist import GradAllGather, GradAllReduce
     _lib.lib()
 
-    B, K, n, M, H = args.batch, args.prims, args.points, args.gt_points, args.size
+    if args.workload == 'c2':
+        B = args.batch or 32
+        res = raster_only(vpn_amd, _lib, dev, B, args.prims or 16, args.size or 128, args.steps, args.warmup,
+                          args.windows, 'c2', not args.no_graph)
+        if rank == 0:
+            fwd = res['roofline'].get('raster_fwd_kernel<1>', {})
+            bwd = res['roofline'].get('raster_bwd_kernel<1>', {})
+            dom = bwd if bwd.get('avg_launch_us', 0) >= fwd.get('avg_launch_us', 0) else fwd
+            out = {'metric': 'raster fwd+bwd images/sec (BASELINE config C2)', 'value': res['images_per_s'],
+                   'unit': 'images/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
+                   'ms_per_step': res['ms_per_step'], 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+                   'dtype': 'f32', 'data': 'synthetic', 'launch': 'eager' if args.no_graph else 'hip-graph replay',
+                   'config': {'workload': res['workload'], 'global_batch': B, 'parallelism': 'dp1'},
+                   'roofline': dict(dom.get('hbm', {}), kernel='raster_bwd_kernel<1>' if dom is bwd else 'raster_fwd_kernel<1>',
+                                    executed_work=dom.get('executed_work')),
+                   'c2': res}
+            print(json.dumps(out), flush=True)
+        if multi:
+            dist.destroy_process_group()
+        return
+
+    K, n, M, H = args.prims or 32, args.points, args.gt_points, args.size or 256
     W = H
+    if args.global_batch:
+        assert args.global_batch % world == 0, '--global-batch must divide evenly over the ranks'
+        B = args.global_batch // world
+        scaling = 'strong'
+    else:
+        B = args.batch or 64
+        scaling = 'weak'
+    Bg = B * world
     kinds = vpn_amd.kinds_tensor([vpn_amd.SPHERE] * K, dev)      # reference default: all spheres (config.py:33-34)
-    # each rank owns global samples [rank*B, (rank+1)*B): weak scaling, per-GPU work fixed
-    params_all, gt_all = synth_inputs(B * world, K, M, 1234, dev)
+    # rank r owns global samples [r*B, (r+1)*B)
+    params_all, gt_all = synth_inputs(Bg, K, M, 1234, dev)
     params = params_all[rank * B:(rank + 1) * B].clone().requires_grad_(True)
     gt_points = gt_all[rank * B:(rank + 1) * B].contiguous()
     cam = torch.tensor([[1.0, 0.0, 0.0]], device=dev).expand(B, 3).contiguous()    # train.py:172-174
-    # GT silhouette / depth: render of a second primitive set (seed 4321), silhouette thresholded at 0.5
-    p2, _ = synth_inputs(B * world, K, M, 4321, dev)
+    # GT silhouette / depth of the timed run: render of a second primitive set (seed 4321), silhouette thresholded
+    # at 0.5.  (The parity leg below builds its GT with the CPU oracle instead, so that it does not depend on the
+    # kernel under test.)
+    p2_all, _ = synth_inputs(Bg, K, M, 4321, dev)
+    sigma, gamma, z_far = vpn_amd.config.RASTER_SIGMA, vpn_amd.config.RASTER_GAMMA, vpn_amd.config.RASTER_Z_FAR
     with torch.no_grad():
-        a2, d2 = vpn_amd.RasterFunction.apply(p2[rank * B:(rank + 1) * B].contiguous(), kinds, cam, H, W,
-                                              vpn_amd.config.RASTER_SIGMA, vpn_amd.config.RASTER_GAMMA,
-                                              vpn_amd.config.RASTER_Z_FAR)
+        a2, d2 = vpn_amd.RasterFunction.apply(p2_all[rank * B:(rank + 1) * B].contiguous(), kinds, cam, H, W, sigma, gamma,
+                                              z_far)
     gt_sil = (a2 > 0.5).float()
     gt_depth = d2.clone()
-    reducer = GradAllGather(B * world, K, dev, rank, world) if multi else None
-    cd_fn = vpn_amd.ChamferDistanceLoss()
-    sigma, gamma, z_far = vpn_amd.config.RASTER_SIGMA, vpn_amd.config.RASTER_GAMMA, vpn_amd.config.RASTER_Z_FAR
+    reducer = None
+    if multi:
+        reducer = (GradAllReduce if args.collective == 'allreduce' else GradAllGather)(Bg, K, dev, rank, world)
+    one = torch.ones((), device=dev)
+    # Philox key of the step: a device counter bumped on the stream at the start of every step, read by the sampler
+    # kernels, so every replay of the captured graph draws fresh surface points (the reference resamples each step)
+    seed_buf = torch.full((1,), 1234, dtype=torch.int64, device=dev)
 
-    unit_total = torch.tensor([0.0, 0.0, 1.0], device=dev)
-
-    def compute(i):
+    def compute(_i=0):
         # total = ChamferDistanceLoss(sample(params), gt) + SilhouetteLoss(L1) + L1 depth loss  (train.py:243-262),
         # one autograd node: sampler -> Chamfer scans -> raster with fused image losses, and the matching backward
         params.grad = None
-        out = vpn_amd.HotPathLossFunction.apply(params, kinds, cam, gt_points, gt_sil, gt_depth, n, 1234 + i,
-                                                rank * B, H, W, sigma, gamma, z_far, 1.0, 1.0, 1.0)
-        # d(total)/d(params): the unit vector selects the total (index 2) of the three losses.  `out[2].backward()`
-        # is the same thing through three more ATen kernels (ones_like, and SelectBackward's zeros + copy).
-        out.backward(unit_total)
+        seed_buf.add_(1)
+        out = vpn_amd.HotPathLossFunction.apply(params, kinds, cam, gt_points, gt_sil, gt_depth, n, seed_buf, rank * B,
+                                                H, W, sigma, gamma, z_far, 1.0, 1.0, 1.0)
+        out[2].backward(one)
         return out[2]
 
-    def step(i):
+    def comm():
+        if isinstance(reducer, GradAllReduce):
+            reducer.allreduce()
+        else:
+            reducer.gather()
+
+    def step(i=0):
         loss = compute(i)
         if reducer is not None:
-            return reducer.reduce(params.grad, loss)
+            reducer.pack(params.grad, loss)
+            comm()
+            return reducer.views()
         return params.grad, loss
 
     def sync():
@@ -119,8 +299,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # The step is launch-bound on the host when issued eagerly (about 20 launches of 5-200 us), so the
-    # compute part is captured once into a HIP graph and replayed; the RCCL all-gather stays outside.
+    # Issued eagerly the step is launch-bound on the host (about 15 launches of 5-130 us), so the compute part is
+    # captured once into a HIP graph and replayed; the collective stays outside the graph.
     use_graph = not args.no_graph
     run_step = step
     if use_graph:
@@ -139,13 +319,14 @@ def main():
                 reducer.pack(params.grad, g_loss)          # scaled copy into the send buffer: part of the graph
         g_grad = params.grad
 
-        def run_step(i):
+        def run_step(i=0):
             graph.replay()
             if reducer is not None:
-                reducer.gather()                           # the one collective of the step, outside the graph
-                return reducer.views()                     # (overlapping it with the next step through a second
-            return g_grad, g_loss                          #  graph + communication stream measured slower at 1 rank)
+                comm()                                     # the one collective of the step, outside the graph
+                return reducer.views()
+            return g_grad, g_loss
 
+    # ---- the contract's timed region: W warm-up steps, then exactly K steps between barrier + synchronize
     for i in range(args.warmup):
         run_step(i)
     sync()
@@ -159,11 +340,18 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
     ms_per_step = dt / args.steps * 1e3
-    value = B * world * args.steps / dt
+    value = Bg * args.steps / dt
+    # ---- the same steps again under a HIP event pair on the launch stream: median of `windows` windows
+    ev = event_windows(run_step, args.steps, args.windows)
+    if multi:
+        t = torch.tensor([ev['median'], ev['min'], ev['max']], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ev['median'], ev['min'], ev['max'] = (float(x) for x in t)
+    seed_after = int(seed_buf.item())
 
     # ---- device time per C-ABI entry point and per KERNEL (HIP events on the launch stream, recorded by the
     # binding / by the library around every launch), same steps again, eagerly
-    ksteps = max(5, min(args.steps, 20))
+    ksteps = 20
     with _lib.KernelTimer() as kt, _lib.KernelProfile() as kp:
         for i in range(ksteps):
             step(i)
@@ -185,6 +373,8 @@ def main():
         'chamfer_bwd_lds_kernel': B * (12 * (N + M) + 8 * (N + M) + 12 * N),
         'sample_chamfer_bwd_kernel': B * (12 * (N + M) + 8 * (N + M) + 80 * K),
     }
+    is_c3 = (B, K, n, M, H) == (64, 32, 256, 2048, 256)
+    pmc = load_pmc('c3') if is_c3 else {}
     pair_flops = 8.0 * B * N * M                      # 8 flop per point pair (3 sub, 3 mul, 2 add  ==  K=4 MAC on the matrix pipe)
     dom = max((k for k in kern if k in alg_bytes), key=lambda k: kern[k][0] * kern[k][1])
     dom_s = kern[dom][1] * 1e-3
@@ -192,57 +382,73 @@ def main():
     if dom.startswith('chamfer_nn_mfma_kernel'):      # the exact scan with the matrix-pipe filter, both directions per launch
         pair_flops *= 2.0
         tf = pair_flops / dom_s / 1e12
-        bf16 = dom.endswith('<1>')
-        roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': round(tf, 2), 'peak': VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(tf / VALU_PEAK_TFLOPS, 4), 'traffic': None,
+        roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': round(tf, 2), 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': round(tf / FP32_PEAK_TFLOPS, 4), 'traffic': traffic_of(dom, pmc),
+                    'basis': 'ALGORITHMIC fp32 flops (8 per point pair: 3 sub, 3 mul, 2 add) / launch time, priced at the '
+                             'fp32 peak of MI355X (157.3 TFLOP/s: vector = fp32-input MFMA, MI355X_MICROARCH.md).  The '
+                             'kernel EXECUTES on the bf16 matrix pipe (exact 3-way bf16 split as a conservative filter, '
+                             'exact fp32 finish): see `executed`',
                     'algorithmic_flops_per_launch': pair_flops, 'avg_launch_us': round(dom_s * 1e6, 2),
-                    'peak_note': 'algorithmic work = 8 fp32 flop per point pair, priced against the fp32 rate of MI355X '
-                                 '(157.3 TFLOP/s, vector = fp32-input MFMA; MI355X_MICROARCH.md)',
                     'hbm_view': {'algorithmic_bytes_per_launch': alg_bytes[dom], 'achieved_GBps': round(hbm_gbs, 2),
                                  'frac_of_8TBps': round(hbm_gbs / HBM_PEAK_GBS, 5)}}
-        if bf16:    # executed on the bf16 matrix pipe: v_mfma_f32_32x32x16_bf16 + v_mfma_f32_32x32x8_bf16 per 32x32 pairs = 48 flop per pair
+        if dom.endswith('<1>'):    # v_mfma_f32_32x32x16_bf16 + v_mfma_f32_32x32x8_bf16 per 32x32 pairs = 48 flop per pair
             ex = 2.0 * 48.0 * B * N * M / dom_s / 1e12
-            roofline['matrix_pipe'] = {'instruction': 'v_mfma_f32_32x32x16_bf16 + v_mfma_f32_32x32x8_bf16 (fp32 coordinates split exactly into 3 bf16 pieces, 21 of 24 K slots used)',
-                                       'executed_TFLOPs': round(ex, 1), 'dense_bf16_peak_TFLOPs': 2500.0,
-                                       'frac': round(ex / 2500.0, 4)}
+            roofline['executed'] = {'unit': 'bf16 MFMA', 'instruction': 'v_mfma_f32_32x32x16_bf16 + v_mfma_f32_32x32x8_bf16 '
+                                    '(fp32 coordinates split exactly into 3 bf16 pieces, 21 of 24 K slots used)',
+                                    'achieved_TFLOPs': round(ex, 1), 'peak_TFLOPs': BF16_PEAK_TFLOPS,
+                                    'frac': round(ex / BF16_PEAK_TFLOPS, 4)}
     else:
         roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': round(hbm_gbs, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': round(hbm_gbs / HBM_PEAK_GBS, 5), 'traffic': None,
+                    'frac': round(hbm_gbs / HBM_PEAK_GBS, 5), 'traffic': traffic_of(dom, pmc),
                     'algorithmic_bytes_per_launch': alg_bytes[dom], 'avg_launch_us': round(dom_s * 1e6, 2)}
         if dom.startswith('chamfer_nn'):
             roofline['valu_tflops'] = round(pair_flops / dom_s / 1e12, 2)
-            roofline['valu_frac_of_fp32_peak'] = round(pair_flops / dom_s / 1e12 / VALU_PEAK_TFLOPS, 4)
-
-    # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 cannot run inside bench.py)
-    try:
-        tr = json.load(open(os.path.join(ROOT, 'profiles', 'r01j_traffic.json')))['kernels'].get(dom)
-        if tr and (B, K, n, M, H) == (64, 32, 256, 2048, 256):
-            roofline['traffic'] = tr['traffic_bytes']
-            roofline['traffic_source'] = 'profiles/r01j_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same workload)'
-    except (OSError, ValueError, KeyError):
-        pass
+            roofline['valu_frac_of_fp32_peak'] = round(pair_flops / dom_s / 1e12 / FP32_PEAK_TFLOPS, 4)
+    if pmc:
+        roofline['traffic_source'] = os.path.relpath(PMC_FILE, ROOT) + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same workload)'
+    # the raster pair: HBM view (algorithmic bytes) and the executed-work view (VALU issue) per kernel
+    raster_roof = {}
+    for name in ('raster_fwd_kernel<1>', 'raster_bwd_kernel<1>'):
+        if name in kern:
+            us = kern[name][1] * 1e3
+            gbs = alg_bytes[name] / (us * 1e-6) / 1e9
+            raster_roof[name] = {'avg_launch_us': round(us, 2), 'algorithmic_bytes_per_launch': alg_bytes[name],
+                                 'hbm_GBps': round(gbs, 2), 'hbm_frac': round(gbs / HBM_PEAK_GBS, 5),
+                                 'traffic': traffic_of(name, pmc), 'executed_work': valu_issue_roofline(name, pmc, us)}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(params_all[:args.cpu_sample].detach().cpu(), gt_all[:args.cpu_sample].cpu(),
-                           gt_sil[:args.cpu_sample].cpu(), gt_depth[:args.cpu_sample].cpu(), K, n, H, W,
-                           sigma, gamma, z_far, params, kinds, cam, gt_points, gt_sil, gt_depth, vpn_amd)
+                           p2_all[:args.cpu_sample].detach().cpu(), K, n, H, W, sigma, gamma, z_far, kinds, cam, vpn_amd)
+
+    c2 = None
+    if rank == 0 and world == 1 and not args.no_c2:
+        c2 = raster_only(vpn_amd, _lib, dev, 32, 16, 128, args.steps, args.warmup, args.windows, 'c2')
 
     if rank == 0:
+        coll = 'none'
+        if multi:
+            nbytes = (Bg * K * 10 + 1) * 4 if args.collective == 'allreduce' else (B * K * 10 + 4) * 4
+            coll = 'rccl %s, %d B per rank per step' % ('all-reduce (sum) of the global gradient buffer'
+                                                       if args.collective == 'allreduce' else 'all-gather', nbytes)
+        name = 'C3' if not args.global_batch else ('C4' if (Bg, K, H) == (256, 32, 256) else 'C3-shape')
         out = {
             'metric': 'render+Chamfer fwd+bwd images/sec', 'value': round(value, 1), 'unit': 'images/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'launch': 'hip-graph replay' if use_graph else 'eager',
-            'config': {'workload': 'C3: B=%d/GPU, K=%d sphere primitives, %dx%d silhouette+depth, n=%d pts/prim '
-                                   '(N=%d) vs M=%d GT points, Chamfer+L1 fwd+bwd' % (B, K, H, W, n, N, M),
-                       'global_batch': B * world, 'parallelism': 'dp%d' % world,
-                       'collective': 'rccl all-gather %d B/rank/step' % ((B * K * 10 + 4) * 4) if multi else 'none'},
-            'roofline': roofline, 'kernel_us': kernel_us, 'entry_us': entry_us,
+            'config': {'workload': '%s: B=%d/GPU (global %d), K=%d sphere primitives, %dx%d silhouette+depth, n=%d pts/prim '
+                                   '(N=%d) vs M=%d GT points, Chamfer+L1 fwd+bwd' % (name, B, Bg, K, H, W, n, N, M),
+                       'global_batch': Bg, 'parallelism': 'dp%d' % world, 'collective': coll,
+                       'sampling': 'fresh Philox draws every step (device step counter, %d steps drawn)' % (seed_after - 1234)},
+            'hip_event_ms_per_step': {k: (round(v, 5) if isinstance(v, float) else v) for k, v in ev.items()},
+            'roofline': roofline, 'raster_roofline': raster_roof, 'kernel_us': kernel_us, 'entry_us': entry_us,
         }
         if cpu is not None:
             out['cpu_baseline'] = cpu
-        if world == 1:      # row f1, outside the metric: the auction EMD loss the reference adds to the same step
+        if c2 is not None:
+            out['c2'] = c2
+        if world == 1 and not args.no_extras:      # row f1, outside the metric: the auction EMD loss of the same step
             out['emd'] = emd_extra(B, M, dev, vpn_amd, cpu is not None)
         print(json.dumps(out), flush=True)
     if multi:
@@ -283,18 +489,27 @@ def emd_extra(B, n, dev, vpn_amd, with_cpu):
     return out
 
 
-def cpu_baseline(params, gt_points, gt_sil, gt_depth, K, n, H, W, sigma, gamma, z_far,
-                 gpu_params, kinds, cam, gpu_gt_points, gpu_gt_sil, gpu_gt_depth, vpn_amd):
-    """The oracle (CPU PyTorch restatement of the reference path, dense B*N*M Chamfer) timed on
-    the host cores on a bounded sample of the same workload, and compared with the HIP path on
-    exactly those samples."""
+def cpu_baseline(params, gt_points, params2, K, n, H, W, sigma, gamma, z_far, kinds, cam, vpn_amd):
+    """The oracle (CPU PyTorch restatement of the reference path, dense B*N*M Chamfer) timed on the host cores on a
+    bounded sample of the same workload (median of 3 passes after a warm-up pass on one image), and the HIP path
+    compared with it on exactly those samples.  The GT silhouette / depth of this leg is rendered by the ORACLE
+    (second primitive set, thresholded at 0.5) so the comparison does not depend on the kernel being checked."""
     from oracle import vpn_oracle as O
-    cores = min(16, os.cpu_count() or 1)      # the 1-GPU box's CPU share is 16 cores
-    torch.set_num_threads(cores)
+    host_cores = os.cpu_count() or 1
+    threads = min(host_cores, 16)            # the 1-GPU box's CPU share is 16 cores; more threads than that only thrash
+    torch.set_num_threads(threads)
     S = params.shape[0]
-    u = O.philox_uniforms(1234, 0, S, K, n)
+    seed = 1234
+    u = O.philox_uniforms(seed, 0, S, K, n)
     kl = [0] * K
     camc = torch.tensor([[1.0, 0.0, 0.0]]).expand(S, 3).contiguous()
+    with torch.no_grad():
+        gs, gd = [], []
+        for b in range(0, S, 4):
+            a2, d2 = O.raster(params2[b:b + 4], kl, camc[b:b + 4], H, W, sigma, gamma, z_far)
+            gs.append((a2 > 0.5).float())
+            gd.append(d2)
+        gt_sil, gt_depth = torch.cat(gs), torch.cat(gd)
 
     def run(S=S):
         p = params.clone().requires_grad_(True)
@@ -310,21 +525,26 @@ def cpu_baseline(params, gt_points, gt_sil, gt_depth, K, n, H, W, sigma, gamma, 
         return total, p.grad
 
     run(1)                                               # warm-up on one image
-    t0 = time.perf_counter()
-    loss_c, grad_c = run()
-    dt = time.perf_counter() - t0
-    # same samples on the GPU (explicit uniforms = the Philox draws the kernel makes itself)
-    pg = gpu_params[:S].detach().clone().requires_grad_(True)
-    loss_g = vpn_amd.HotPathLossFunction.apply(pg, kinds, cam[:S].contiguous(), gpu_gt_points[:S].contiguous(),
-                                               gpu_gt_sil[:S].contiguous(), gpu_gt_depth[:S].contiguous(), n, 1234, 0,
-                                               H, W, sigma, gamma, z_far, 1.0, 1.0, 1.0)[2]
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        loss_c, grad_c = run()
+        times.append(time.perf_counter() - t0)
+    dt = statistics.median(times)
+    # same samples on the GPU (host seed = the Philox key the oracle's draws were generated with)
+    dev = cam.device
+    pg = params.to(dev).requires_grad_(True)
+    loss_g = vpn_amd.HotPathLossFunction.apply(pg, kinds, cam[:S].contiguous(), gt_points.to(dev), gt_sil.to(dev),
+                                               gt_depth.to(dev), n, seed, 0, H, W, sigma, gamma, z_far, 1.0, 1.0, 1.0)[2]
     loss_g.backward()
     gerr = float((pg.grad.cpu() - grad_c).abs().max() / grad_c.abs().max())
     lerr = abs(float(loss_g.detach()) - loss_c) / abs(loss_c)
-    return {'value': round(S / dt, 3), 'unit': 'images/s', 'cores': cores, 'kind': 'port',
-            'sample': '%d images of the same workload (1-image warm-up + 1 timed pass of %.1f s), torch CPU fp32, '
-                      'dense B*N*M Chamfer as chamfer_distance.py:14-23' % (S, dt),
-            'parity_vs_gpu': {'loss_rel': float('%.3g' % lerr), 'grad_rel': float('%.3g' % gerr)}}
+    return {'value': round(S / dt, 3), 'unit': 'images/s', 'cores': threads, 'host_cores': host_cores, 'kind': 'port',
+            'sample': '%d images of the same workload; 1-image warm-up, then the median of 3 timed passes (%s s), torch CPU '
+                      'fp32 with %d threads on a host with %d cores, dense B*N*M Chamfer as chamfer_distance.py:14-23'
+                      % (S, '/'.join('%.1f' % t for t in times), threads, host_cores),
+            'parity_vs_gpu': {'loss_rel': float('%.3g' % lerr), 'grad_rel': float('%.3g' % gerr),
+                              'gt_images': 'rendered by the CPU oracle'}}
 
 
 if __name__ == '__main__':

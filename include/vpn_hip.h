@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VPN_ABI_VERSION 1
+#define VPN_ABI_VERSION 2
 
 /* primitive kinds (reference: train.py:106-116 cuboids first, then spheres, cones are stubs) */
 #define VPN_SPHERE 0
@@ -66,13 +66,16 @@ int vpn_profile_read(char* names, int names_len, float* mean_ms, int* calls, int
  *      sphere.py:26-27; cuboid: the three draws of cuboid.py:66), or NULL to
  *      generate them in-kernel with Philox4x32-10 keyed by (seed, sample_base+b,
  *      k, point) so the result does not depend on how the batch is sharded.
+ *   seed_dev: NULL, or a DEVICE uint64 read when the kernel runs and added to `seed`: a step counter the
+ *      caller bumps on the stream, so that a captured HIP graph replayed N times draws N different point
+ *      sets like the reference's per-step torch.rand (sphere.py:26-27) instead of freezing the seed at capture.
  */
 int vpn_sample_fwd(const float* params, const int32_t* kinds, const float* u,
-                   uint64_t seed, uint64_t sample_base, int B, int K, int n,
+                   uint64_t seed, const uint64_t* seed_dev, uint64_t sample_base, int B, int K, int n,
                    float* points, void* stream);
-/* grad_params [B,K,10] is WRITTEN (not accumulated). */
+/* grad_params [B,K,10] is WRITTEN (not accumulated).  (seed, *seed_dev) must be what the forward saw. */
 int vpn_sample_bwd(const float* params, const int32_t* kinds, const float* u,
-                   uint64_t seed, uint64_t sample_base, int B, int K, int n,
+                   uint64_t seed, const uint64_t* seed_dev, uint64_t sample_base, int B, int K, int n,
                    const float* grad_points, float* grad_params, void* stream);
 /* Backward of ChamferDistanceLoss(sample(params), gt_points) straight to grad_params [B,K,10], for the pair of
  * calls train.py:117-120 + :160-161 makes: equals vpn_chamfer_bwd (gradient of the predicted cloud only, GT gets
@@ -81,7 +84,7 @@ int vpn_sample_bwd(const float* params, const int32_t* kinds, const float* u,
  * dist/idx from vpn_chamfer_fwd*(points, gt_points); grad_loss_b [B] as in vpn_chamfer_bwd.
  * M <= 15360 (VPN_E_TOOBIG beyond: use the two separate calls). */
 int vpn_sample_chamfer_bwd(const float* params, const int32_t* kinds, const float* u,
-                           uint64_t seed, uint64_t sample_base, int B, int K, int n,
+                           uint64_t seed, const uint64_t* seed_dev, uint64_t sample_base, int B, int K, int n,
                            const float* points, const float* gt_points, int M,
                            const float* dist1, const int32_t* idx1, const float* dist2, const int32_t* idx2,
                            const float* grad_loss_b, float w1, float w2, float* grad_params, void* stream);
@@ -121,9 +124,12 @@ int vpn_chamfer_nn(const float* queries, const float* targets, int B, int Nq, in
  *   mode 4  the same filter with fp32-input MFMA;
  *   mode 0  automatic (mode 3 for large clouds when a workspace is given, else mode 1). */
 size_t vpn_chamfer_workspace(int B, int N, int M);
+/* workspace_bytes: size of `workspace`; VPN_E_BADARG if a mode that uses it is given fewer than
+ * vpn_chamfer_workspace(B,N,M) bytes or a pointer that is not 16-byte aligned (the filtered scans fetch row
+ * tiles without bounds checks inside it). */
 int vpn_chamfer_fwd_ws(const float* p1, const float* p2, int B, int N, int M,
                        float* dist1, int32_t* idx1, float* dist2, int32_t* idx2,
-                       void* workspace, int mode, void* stream);
+                       void* workspace, size_t workspace_bytes, int mode, void* stream);
 /* loss_b[b] = w1*mean_i dist1[b,i] + w2*mean_j dist2[b,j]   (chamfer_distance.py:25-28) */
 int vpn_chamfer_loss(const float* dist1, const float* dist2, int B, int N, int M,
                      float w1, float w2, float* loss_b, void* stream);

@@ -32,3 +32,12 @@ def rel_err(a, b):
     a, b = a.double(), b.double()
     den = b.abs().max().clamp_min(1e-30)
     return float((a - b).abs().max() / den)
+
+
+def elem_rel_err(a, b, floor=1e-2):
+    """Element-wise relative error with an absolute floor: max |a-b| / (|b| + floor * max|b|).  Unlike `rel_err`
+    it holds small components to (nearly) their own scale: a component 100x below the largest is still checked
+    to twice the stated tolerance of its own size."""
+    a, b = a.double(), b.double()
+    den = b.abs() + floor * b.abs().max().clamp_min(1e-30)
+    return float(((a - b).abs() / den).max())

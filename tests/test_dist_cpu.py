@@ -40,9 +40,9 @@ def _worker(rank, world, port, out):
     assert torch.equal(u_local, u[lo:hi])
     loss, grad = _loss_and_grad(params[lo:hi], gt[lo:hi], kinds, u_local)
     red = GradAllReduce(Bg, K, torch.device('cpu'), rank, world)
-    # local mean is over B/world samples: scale so the sum over ranks is the global-batch mean
-    ggrad, gloss = red.reduce(grad / world, loss)
-    # the all-gather formulation (what bench.py runs over RCCL) must give the same global gradient and loss
+    # both reducers take the gradient of the LOCAL mean loss and scale by 1/world themselves (same contract)
+    ggrad, gloss = red.reduce(grad, loss)
+    # the all-gather formulation must give the same global gradient and loss from the same inputs
     gat = GradAllGather(Bg, K, torch.device('cpu'), rank, world)
     ggrad2, gloss2 = gat.reduce(grad, loss)
     assert torch.allclose(ggrad2, ggrad, rtol=1e-6, atol=1e-9) and torch.allclose(gloss2, gloss, rtol=1e-6)

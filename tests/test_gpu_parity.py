@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, rel_err
+from conftest import elem_rel_err, load_golden, rel_err
 from oracle import vpn_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -206,12 +206,12 @@ def test_fused_chamfer_sampler_backward(vpn):
         _lib.call('vpn_chamfer_bwd', _lib.ptr(pts), _lib.ptr(gt), _lib.ptr(d1), _lib.ptr(i1), _lib.ptr(d2), _lib.ptr(i2),
                   _lib.ptr(gl), B, N, M, 0.7, 1.3, _lib.ptr(gp), None, _lib.stream())
         ref = torch.empty_like(params)
-        _lib.call('vpn_sample_bwd', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(u), seed, 0, B, K, n, _lib.ptr(gp),
+        _lib.call('vpn_sample_bwd', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(u), seed, None, 0, B, K, n, _lib.ptr(gp),
                   _lib.ptr(ref), _lib.stream())
         outs = []
         for _ in range(2):
             out = torch.empty_like(params)
-            _lib.call('vpn_sample_chamfer_bwd', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(u), seed, 0, B, K, n,
+            _lib.call('vpn_sample_chamfer_bwd', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(u), seed, None, 0, B, K, n,
                       _lib.ptr(pts), _lib.ptr(gt), M, _lib.ptr(d1), _lib.ptr(i1), _lib.ptr(d2), _lib.ptr(i2), _lib.ptr(gl),
                       0.7, 1.3, _lib.ptr(out), _lib.stream())
             outs.append(out)
@@ -422,6 +422,10 @@ def test_chamfer_full_size_properties(vpn):
 
 
 # ----------------------------------------------------------------------------- raster
+ESCAPES = []          # (seed, slice, e_gpu, e_cpu) of every use of the fp64 clause in _raster_case
+ELEM_TOL = 1e-3
+
+
 def _raster_case(vpn, B, K, H, W, kinds, cam, seed, sigma=0.05, gamma=0.1, z_far=2.0, scale=1.0):
     gen = torch.Generator().manual_seed(seed)
     params = rand_params(gen, B, K)
@@ -446,8 +450,16 @@ def _raster_case(vpn, B, K, H, W, kinds, cam, seed, sigma=0.05, gamma=0.1, z_far
         mine, ref32, ref64 = pg.grad.cpu()[..., sl], pc.grad[..., sl], p64.grad[..., sl]
         e_gpu = rel_err(mine, ref64)
         e_cpu = rel_err(ref32, ref64)
-        # within 1e-4 of the fp32 oracle, or at least as close to the fp64 truth as the fp32 oracle is
-        assert rel_err(mine, ref32) <= RTOL or e_gpu <= max(RTOL, 2 * e_cpu), (sl, e_gpu, e_cpu, rel_err(mine, ref32))
+        # within 1e-4 of the fp32 oracle.  Only where the fp32 ORACLE itself is further than 5e-5 from the fp64
+        # truth (its own rounding noise eats half the budget) the kernel may instead be as close to the truth as
+        # the oracle is; every use of that clause is recorded in ESCAPES and reported by test_raster_escape_report
+        if rel_err(mine, ref32) > RTOL:
+            assert e_cpu > 5e-5 and e_gpu <= 2 * e_cpu, (sl, e_gpu, e_cpu, rel_err(mine, ref32))
+            ESCAPES.append((seed, sl.start, e_gpu, e_cpu))
+        # small components too: element-wise, relative to |ref| + 1 % of the largest component, against the fp64
+        # truth; the kernel may not be worse than 1e-3 there nor (beyond noise) than 4x the fp32 oracle
+        ee_gpu, ee_cpu = elem_rel_err(mine, ref64), elem_rel_err(ref32, ref64)
+        assert ee_gpu <= max(ELEM_TOL, 4 * ee_cpu), (sl, ee_gpu, ee_cpu)
     return a.detach()
 
 
@@ -646,3 +658,119 @@ def test_raster_full_size_properties(vpn):
     assert torch.equal(g2, 2 * g1), 'backward is not linear in the incoming gradient'
     assert bool(torch.isfinite(g1).all())
     assert 0.02 < float(a.mean()) < 0.9
+
+
+# ----------------------------------------------------------------------------- BASELINE configs C2 and C5
+def _oracle_raster_losses_chunked(params, kinds, cam, gt_sil, gt_dep, H, W, chunk=4):
+    """Oracle silhouette (L1) + depth (L1) means and their gradient, images processed `chunk` at a time."""
+    B = params.shape[0]
+    p = params.clone().requires_grad_(True)
+    tot = torch.zeros(2)
+    for s in range(0, B, chunk):
+        a, d = O.raster(p[s:s + chunk], kinds, cam[s:s + chunk], H, W, 0.05, 0.1, 2.0)
+        ls = (a - gt_sil[s:s + chunk]).abs().sum() / (B * H * W)
+        ld = (d - gt_dep[s:s + chunk]).abs().sum() / (B * H * W)
+        (ls + ld).backward()
+        tot += torch.stack([ls.detach(), ld.detach()])
+    return tot, p.grad
+
+
+def test_raster_config2_workload(vpn):
+    """BASELINE config C2: 16 primitives, 128x128 silhouette + depth, batch 32, raster fwd/bwd only
+    (vertex_renderer.py:7,14-26 renders at exactly 128x128; silhouette.py:16-22).  The dense oracle fits at this
+    size: all 32 images, images and fused losses, forward and gradient."""
+    gen = torch.Generator().manual_seed(1234)
+    B, K, H, W = 32, 16, 128, 128
+    params = rand_params(gen, B, K)
+    kinds = [0] * K                                          # config.py:33-34: all spheres
+    cam = torch.tensor([[1.0, 0.0, 0.0]]).expand(B, 3).contiguous()
+    gt_sil = (O.raster(rand_params(gen, B, K), kinds, cam, H, W, 0.05, 0.1, 2.0)[0] > 0.5).float()
+    gt_dep = 2.0 - torch.rand(B, H, W, generator=gen)
+    ref, gref = _oracle_raster_losses_chunked(params, kinds, cam, gt_sil, gt_dep, H, W)
+    kt = vpn.kinds_tensor(kinds, torch.device(DEV))
+    pg = g(params).requires_grad_(True)
+    out = vpn.RasterLossFunction.apply(pg, kt, g(cam), g(gt_sil), g(gt_dep), H, W, 0.05, 0.1, 2.0, False)
+    out.sum().backward()
+    assert rel_err(out.detach().cpu(), ref) <= RTOL
+    assert rel_err(pg.grad.cpu(), gref) <= RTOL
+    assert elem_rel_err(pg.grad.cpu(), gref) <= ELEM_TOL
+    # image mode on all 32 images
+    a, d = vpn.RasterFunction.apply(g(params), kt, g(cam), H, W, 0.05, 0.1, 2.0)
+    for s in range(0, B, 8):
+        a_ref, d_ref = O.raster(params[s:s + 8], kinds, cam[s:s + 8], H, W, 0.05, 0.1, 2.0)
+        assert rel_err(a[s:s + 8].cpu(), a_ref) <= RTOL and rel_err(d[s:s + 8].cpu(), d_ref) <= RTOL
+    # SilhouetteLoss module surface at the reference's render size
+    loss = vpn.SilhouetteLoss()(vpn.PrimitivePack(g(params), kinds), g(gt_sil)[:, None], g(cam[:, 0]), g(cam[:, 1]),
+                                g(cam[:, 2]))
+    assert rel_err(loss.cpu(), ref[0]) <= RTOL
+
+
+@pytest.mark.parametrize('kinds_name', ['spheres', 'mixed'])
+def test_raster_config5_shape(vpn, kinds_name):
+    """BASELINE config C5 shape: 64 primitives, 256x256 (train.py loop).  B=8 on the GPU; the oracle on two images
+    (forward + gradient of the fused losses), linearity and determinism of the backward on all of them."""
+    gen = torch.Generator().manual_seed(55)
+    B, K, H, W = 8, 64, 256, 256
+    kinds = [0] * K if kinds_name == 'spheres' else [1] * 16 + [0] * 48      # cuboids first (train.py:112-116)
+    params = rand_params(gen, B, K)
+    cam = torch.tensor([[1.0, 0.0, 0.0]]).expand(B, 3).contiguous()
+    gt_sil = (torch.rand(B, H, W, generator=gen) > 0.5).float()
+    gt_dep = 2.0 - torch.rand(B, H, W, generator=gen)
+    kt = vpn.kinds_tensor(kinds, torch.device(DEV))
+    S = 2
+    ref, gref = _oracle_raster_losses_chunked(params[:S], kinds, cam[:S], gt_sil[:S], gt_dep[:S], H, W, chunk=1)
+    pg = g(params[:S]).requires_grad_(True)
+    out = vpn.RasterLossFunction.apply(pg, kt, g(cam[:S]), g(gt_sil[:S]), g(gt_dep[:S]), H, W, 0.05, 0.1, 2.0, False)
+    out.sum().backward()
+    assert rel_err(out.detach().cpu(), ref) <= RTOL
+    assert rel_err(pg.grad.cpu(), gref) <= RTOL
+    assert elem_rel_err(pg.grad.cpu(), gref) <= ELEM_TOL
+    pb = g(params).requires_grad_(True)
+    a, d = vpn.RasterFunction.apply(pb, kt, g(cam), H, W, 0.05, 0.1, 2.0)
+    Wa, Wd = torch.randn(B, H, W, device=DEV), torch.randn(B, H, W, device=DEV)
+    g1, = torch.autograd.grad([a, d], [pb], [Wa, Wd], retain_graph=True)
+    g1b, = torch.autograd.grad([a, d], [pb], [Wa, Wd], retain_graph=True)
+    g2, = torch.autograd.grad([a, d], [pb], [2 * Wa, 2 * Wd], retain_graph=True)
+    assert torch.equal(g1, g1b) and torch.equal(g2, 2 * g1) and bool(torch.isfinite(g1).all())
+    # a shard rendered alone equals the same rows of the batch
+    a2, d2 = vpn.RasterFunction.apply(g(params[3:5]), kt, g(cam[3:5]), H, W, 0.05, 0.1, 2.0)
+    assert torch.equal(a2, a[3:5].detach()) and torch.equal(d2, d[3:5].detach())
+
+
+def test_hot_path_config5_shape(vpn):
+    """C5 shape through the single-node step: K=64 primitives x 128 points (config.py:8: SAMPLE_NUM) = 8192 points
+    vs 2048 GT points, 256x256; oracle on both samples."""
+    gen = torch.Generator().manual_seed(56)
+    B, K, n, M, H, W = 2, 64, 128, 2048, 256, 256
+    params = rand_params(gen, B, K)
+    kinds = [0] * K
+    gt_pts = torch.rand(B, M, 3, generator=gen) - 0.5
+    gt_sil = (torch.rand(B, 1, H, W, generator=gen) > 0.5).float()
+    gt_dep = 2.0 - torch.rand(B, H, W, generator=gen)
+    cam = torch.tensor([[1.0, 0.0, 0.0]]).expand(B, 3).contiguous()
+    seed = 99
+    u = O.philox_uniforms(seed, 0, B, K, n)
+    pc = params.clone().requires_grad_(True)
+    tot = 0.0
+    for b in range(B):
+        pts = O.sample_primitives(pc[b:b + 1], kinds, u[b:b + 1])
+        a, d = O.raster(pc[b:b + 1], kinds, cam[b:b + 1], H, W, 0.05, 0.1, 2.0)
+        lb = (O.chamfer_loss(pts, gt_pts[b:b + 1]) / B + (a[:, None] - gt_sil[b:b + 1]).abs().sum() / (B * H * W)
+              + (d - gt_dep[b:b + 1]).abs().sum() / (B * H * W))
+        lb.backward()
+        tot += float(lb.detach())
+    kt = vpn.kinds_tensor(kinds, torch.device(DEV))
+    pg = g(params).requires_grad_(True)
+    out = vpn.HotPathLossFunction.apply(pg, kt, g(cam), g(gt_pts), g(gt_sil), g(gt_dep), n, seed, 0, H, W, 0.05, 0.1,
+                                        2.0, 1.0, 1.0, 1.0)
+    out[2].backward()
+    assert abs(float(out[2]) - tot) / abs(tot) <= RTOL
+    assert rel_err(pg.grad.cpu(), pc.grad) <= RTOL
+
+
+def test_raster_escape_report():
+    """Runs last in this file: how often the fp64 clause of _raster_case was needed (it must stay rare, and only
+    where the fp32 oracle itself is noisy)."""
+    for e in ESCAPES:
+        print('fp64 clause used: seed %d, slice %d, e_gpu %.2e, e_cpu %.2e' % e)
+    assert len(ESCAPES) <= 2, ESCAPES

@@ -18,7 +18,7 @@ def run(q, t, tag):
     d = torch.empty(Bq, Nq, device=dev); i = torch.empty(Bq, Nq, dtype=torch.int32, device=dev)
     d2 = torch.empty(Bq, Nt, device=dev); i2 = torch.empty(Bq, Nt, dtype=torch.int32, device=dev)
     ws = torch.empty(L.vpn_chamfer_workspace(Bq, Nq, Nt) // 4, device=dev)
-    _lib.call('vpn_chamfer_fwd_ws', _lib.ptr(q), _lib.ptr(t), Bq, Nq, Nt, _lib.ptr(d), _lib.ptr(i), _lib.ptr(d2), _lib.ptr(i2), _lib.ptr(ws), 2, _lib.stream())
+    _lib.call('vpn_chamfer_fwd_ws', _lib.ptr(q), _lib.ptr(t), Bq, Nq, Nt, _lib.ptr(d), _lib.ptr(i), _lib.ptr(d2), _lib.ptr(i2), _lib.ptr(ws), ws.numel() * 4, 2, _lib.stream())
     b = rd()
     waves1, waves2 = Bq * ((Nq + 63) // 64), Bq * ((Nt + 63) // 64)
     c1, c2 = (Nt + 63) // 64, (Nq + 63) // 64

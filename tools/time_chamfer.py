@@ -24,7 +24,7 @@ ws = torch.empty((_lib.lib().vpn_chamfer_workspace(B, N, M) // 4,), dtype=torch.
 d1 = torch.empty(B, N, device=dev); d2 = torch.empty(B, M, device=dev)
 i1 = torch.empty(B, N, dtype=torch.int32, device=dev); i2 = torch.empty(B, M, dtype=torch.int32, device=dev)
 _lib.call('vpn_chamfer_fwd_ws', _lib.ptr(pts), _lib.ptr(gt), B, N, M, _lib.ptr(d1), _lib.ptr(i1), _lib.ptr(d2), _lib.ptr(i2),
-          _lib.ptr(ws), 3, _lib.stream())
+          _lib.ptr(ws), ws.numel() * 4, 3, _lib.stream())
 torch.cuda.synchronize()
 pad = lambda n: (n + 63) & ~63
 p4 = lambda n: (n + 3) & ~3

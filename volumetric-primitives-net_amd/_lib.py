@@ -9,7 +9,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libvpn_hip.so')
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _c_f = ctypes.c_void_p      # device pointers travel as void*
 _i, _f, _u64, _sz = ctypes.c_int, ctypes.c_float, ctypes.c_uint64, ctypes.c_size_t
@@ -19,16 +19,16 @@ SIGNATURES = {
     'vpn_error_string': (ctypes.c_char_p, [_i]),
     'vpn_profile_enable': (_i, [_i]),
     'vpn_profile_read': (_i, [ctypes.c_char_p, _i, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int), _i]),
-    'vpn_sample_fwd': (_i, [_c_f, _c_f, _c_f, _u64, _u64, _i, _i, _i, _c_f, _c_f]),
-    'vpn_sample_bwd': (_i, [_c_f, _c_f, _c_f, _u64, _u64, _i, _i, _i, _c_f, _c_f, _c_f]),
-    'vpn_sample_chamfer_bwd': (_i, [_c_f, _c_f, _c_f, _u64, _u64, _i, _i, _i, _c_f, _c_f, _i, _c_f, _c_f, _c_f, _c_f, _c_f,
+    'vpn_sample_fwd': (_i, [_c_f, _c_f, _c_f, _u64, _c_f, _u64, _i, _i, _i, _c_f, _c_f]),
+    'vpn_sample_bwd': (_i, [_c_f, _c_f, _c_f, _u64, _c_f, _u64, _i, _i, _i, _c_f, _c_f, _c_f]),
+    'vpn_sample_chamfer_bwd': (_i, [_c_f, _c_f, _c_f, _u64, _c_f, _u64, _i, _i, _i, _c_f, _c_f, _i, _c_f, _c_f, _c_f, _c_f, _c_f,
                                     _f, _f, _c_f, _c_f]),
     'vpn_transform_fwd': (_i, [_c_f, _c_f, _c_f, _i, _i, _c_f, _c_f]),
     'vpn_transform_bwd': (_i, [_c_f, _c_f, _c_f, _i, _i, _c_f, _c_f, _c_f, _c_f]),
     'vpn_chamfer_fwd': (_i, [_c_f, _c_f, _i, _i, _i, _c_f, _c_f, _c_f, _c_f, _c_f]),
     'vpn_chamfer_nn': (_i, [_c_f, _c_f, _i, _i, _i, _c_f, _c_f, _c_f]),
     'vpn_chamfer_workspace': (_sz, [_i, _i, _i]),
-    'vpn_chamfer_fwd_ws': (_i, [_c_f, _c_f, _i, _i, _i, _c_f, _c_f, _c_f, _c_f, _c_f, _i, _c_f]),
+    'vpn_chamfer_fwd_ws': (_i, [_c_f, _c_f, _i, _i, _i, _c_f, _c_f, _c_f, _c_f, _c_f, _sz, _i, _c_f]),
     'vpn_chamfer_loss': (_i, [_c_f, _c_f, _i, _i, _i, _f, _f, _c_f, _c_f]),
     'vpn_chamfer_bwd': (_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i, _i, _i, _f, _f, _c_f, _c_f, _c_f]),
     'vpn_raster_records_size': (_sz, [_i, _i]),

@@ -1724,10 +1724,15 @@ extern "C" size_t vpn_chamfer_workspace(int B, int N, int M) {
 // pruned.  mode: 0 automatic, 1 brute force, 2 box-pruned, 3 bf16 matrix-pipe filter, 4 fp32-MFMA filter
 // (all bit-identical).
 extern "C" int vpn_chamfer_fwd_ws(const float* p1, const float* p2, int B, int N, int M, float* dist1, int32_t* idx1,
-                                  float* dist2, int32_t* idx2, void* workspace, int mode, void* stream) {
+                                  float* dist2, int32_t* idx2, void* workspace, size_t workspace_bytes, int mode,
+                                  void* stream) {
     if (!p1 || !p2 || !dist1 || !idx1 || !dist2 || !idx2) return VPN_E_BADARG;
     if (B <= 0 || N <= 0 || M <= 0) return VPN_E_BADARG;
     if (B > 65535 || (long long)B * N > 0x7fffffffLL || (long long)B * M > 0x7fffffffLL) return VPN_E_TOOBIG;
+    // the filtered scans trust the workspace layout (unguarded tile fetches into its slack): a short or misaligned
+    // workspace is rejected here instead of faulting on the device
+    if (workspace && (workspace_bytes < vpn_chamfer_workspace(B, N, M) || ((uintptr_t)workspace & 15) != 0))
+        return VPN_E_BADARG;
     if (mode == 0) mode = chamfer_mode();
     // automatic: the MFMA-filtered scan for large clouds (measured 1.3x the brute-force scan at C3), brute force
     // for small ones or without a workspace; the box-pruned scan stays opt-in

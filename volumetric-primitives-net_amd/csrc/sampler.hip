@@ -68,14 +68,18 @@ __device__ inline void canonical_coeff(const PrimLds& P, int p, const float u[3]
 __device__ inline void load_prim(PrimLds& P, const float* prm, int kind, int n) {
     P.pose = make_pose(prm[3], prm[4], prm[5], prm[6]);
     P.v[0] = prm[0]; P.v[1] = prm[1]; P.v[2] = prm[2];
-    P.kind = kind;
-    if (kind == VPN_CUBOID) cuboid_quota(P.v, n, P.cum);
+    // the host binding rejects unknown kinds; device code treats anything that is not a sphere as a cuboid so that
+    // no lane ever reads uninitialised quotas
+    P.kind = kind == VPN_SPHERE ? VPN_SPHERE : VPN_CUBOID;
+    if (P.kind == VPN_CUBOID) cuboid_quota(P.v, n, P.cum);
 }
 
 __global__ __launch_bounds__(SAMP_BLOCK) void sample_fwd_kernel(
     const float* __restrict__ params, const int32_t* __restrict__ kinds, const float* __restrict__ u,
-    uint64_t seed, uint64_t sample_base, int K, int n, float* __restrict__ points) {
+    uint64_t seed, const uint64_t* __restrict__ seed_dev, uint64_t sample_base, int K, int n,
+    float* __restrict__ points) {
     __shared__ PrimLds P;
+    if (seed_dev) seed += *seed_dev;
     const int k = blockIdx.x, b = blockIdx.y;
     const float* prm = params + ((size_t)b * K + k) * VPN_PARAM_STRIDE;
     if (threadIdx.x == 0) load_prim(P, prm, kinds[k], n);
@@ -99,9 +103,10 @@ __global__ __launch_bounds__(SAMP_BLOCK) void sample_fwd_kernel(
 
 __global__ __launch_bounds__(SAMP_BLOCK) void sample_bwd_kernel(
     const float* __restrict__ params, const int32_t* __restrict__ kinds, const float* __restrict__ u,
-    uint64_t seed, uint64_t sample_base, int K, int n, const float* __restrict__ grad_points,
-    float* __restrict__ grad_params) {
+    uint64_t seed, const uint64_t* __restrict__ seed_dev, uint64_t sample_base, int K, int n,
+    const float* __restrict__ grad_points, float* __restrict__ grad_params) {
     __shared__ PrimLds P;
+    if (seed_dev) seed += *seed_dev;
     __shared__ float red[SAMP_BLOCK / 64][12];
     const int k = blockIdx.x, b = blockIdx.y;
     const float* prm = params + ((size_t)b * K + k) * VPN_PARAM_STRIDE;
@@ -170,12 +175,13 @@ __global__ __launch_bounds__(SAMP_BLOCK) void sample_bwd_kernel(
 // per sample) plus sample_bwd_kernel and the [B,N,3] gradient between them.
 __global__ __launch_bounds__(SAMP_BLOCK) void sample_chamfer_bwd_kernel(
     const float* __restrict__ params, const int32_t* __restrict__ kinds, const float* __restrict__ u,
-    uint64_t seed, uint64_t sample_base, int K, int n, const float* __restrict__ points,
-    const float* __restrict__ gt, int M, const float* __restrict__ dist1, const int32_t* __restrict__ idx1,
+    uint64_t seed, const uint64_t* __restrict__ seed_dev, uint64_t sample_base, int K, int n,
+    const float* __restrict__ points, const float* __restrict__ gt, int M, const float* __restrict__ dist1, const int32_t* __restrict__ idx1,
     const float* __restrict__ dist2, const int32_t* __restrict__ idx2, const float* __restrict__ grad_loss_b,
     float w1, float w2, float* __restrict__ grad_params) {
     __shared__ PrimLds P;
     __shared__ float red[SAMP_BLOCK / 64][12];
+    if (seed_dev) seed += *seed_dev;
     const int k = blockIdx.x, b = blockIdx.y, N = K * n;
     const float* prm = params + ((size_t)b * K + k) * VPN_PARAM_STRIDE;
     if (threadIdx.x == 0) load_prim(P, prm, kinds[k], n);
@@ -506,24 +512,25 @@ __global__ __launch_bounds__(TR_BLOCK) void camera_transform_kernel(
 using namespace vpn;
 
 extern "C" int vpn_sample_fwd(const float* params, const int32_t* kinds, const float* u, uint64_t seed,
-                              uint64_t sample_base, int B, int K, int n, float* points, void* stream) {
+                              const uint64_t* seed_dev, uint64_t sample_base, int B, int K, int n, float* points,
+                              void* stream) {
     if (!params || !kinds || !points) return VPN_E_BADARG;
     if (B <= 0 || K <= 0 || n <= 0) return VPN_E_BADARG;
     if (B > 65535) return VPN_E_TOOBIG;
     VPN_LAUNCH(sample_fwd_kernel, dim3(K, B), dim3(SAMP_BLOCK), 0, (hipStream_t)stream, params, kinds, u,
-                       seed, sample_base, K, n, points);
+                       seed, seed_dev, sample_base, K, n, points);
     VPN_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int vpn_sample_bwd(const float* params, const int32_t* kinds, const float* u, uint64_t seed,
-                              uint64_t sample_base, int B, int K, int n, const float* grad_points,
+                              const uint64_t* seed_dev, uint64_t sample_base, int B, int K, int n, const float* grad_points,
                               float* grad_params, void* stream) {
     if (!params || !kinds || !grad_points || !grad_params) return VPN_E_BADARG;
     if (B <= 0 || K <= 0 || n <= 0) return VPN_E_BADARG;
     if (B > 65535) return VPN_E_TOOBIG;
     VPN_LAUNCH(sample_bwd_kernel, dim3(K, B), dim3(SAMP_BLOCK), 0, (hipStream_t)stream, params, kinds, u,
-                       seed, sample_base, K, n, grad_points, grad_params);
+                       seed, seed_dev, sample_base, K, n, grad_points, grad_params);
     VPN_LAUNCH_CHECK();
     return 0;
 }
@@ -578,7 +585,7 @@ extern "C" int vpn_camera_transform_bwd(const float* grad_out, const float* dist
 }
 
 extern "C" int vpn_sample_chamfer_bwd(const float* params, const int32_t* kinds, const float* u, uint64_t seed,
-                                      uint64_t sample_base, int B, int K, int n, const float* points,
+                                      const uint64_t* seed_dev, uint64_t sample_base, int B, int K, int n, const float* points,
                                       const float* gt_points, int M, const float* dist1, const int32_t* idx1,
                                       const float* dist2, const int32_t* idx2, const float* grad_loss_b, float w1,
                                       float w2, float* grad_params, void* stream) {
@@ -589,7 +596,7 @@ extern "C" int vpn_sample_chamfer_bwd(const float* params, const int32_t* kinds,
     const size_t lds = (size_t)((M + SAMP_BLOCK - 1) / SAMP_BLOCK) * 64 * (SAMP_BLOCK / 64) * sizeof(int);   // = M rounded up
     if (lds > 60 * 1024) return VPN_E_TOOBIG;                           // 15 k GT points; beyond: vpn_chamfer_bwd + vpn_sample_bwd
     VPN_LAUNCH(sample_chamfer_bwd_kernel, dim3(K, B), dim3(SAMP_BLOCK), lds, (hipStream_t)stream, params, kinds, u, seed,
-               sample_base, K, n, points, gt_points, M, dist1, idx1, dist2, idx2, grad_loss_b, w1, w2, grad_params);
+               seed_dev, sample_base, K, n, points, gt_points, M, dist1, idx1, dist2, idx2, grad_loss_b, w1, w2, grad_params);
     VPN_LAUNCH_CHECK();
     return 0;
 }

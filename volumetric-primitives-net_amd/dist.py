@@ -22,7 +22,9 @@ def shard_bounds(global_batch, rank, world):
 class GradAllReduce:
     """Persistent flat buffer [B_global*K*10 + 1]; `reduce(local_grad, local_loss)` returns
     (global grad [B_global,K,10], mean loss).  Backend 'nccl' is RCCL over xGMI on ROCm;
-    'gloo' is used by the CPU tests."""
+    'gloo' is used by the CPU tests.  Same contract as GradAllGather: `local_grad` is the gradient of the rank's
+    LOCAL mean loss; both scale it by 1/world so the result is the gradient of the global-batch mean.
+    `pack` (capturable: only enqueues kernels on the current stream) / `allreduce` (the collective) / `views`."""
 
     def __init__(self, global_batch, K, device, rank=None, world=None):
         self.rank = dist.get_rank() if rank is None else rank
@@ -32,13 +34,24 @@ class GradAllReduce:
         self.buf = torch.zeros(global_batch * K * 10 + 1, dtype=torch.float32, device=device)
         self.grad = self.buf[:-1].view(self.shape)
 
-    def reduce(self, local_grad, local_loss):
+    def pack(self, local_grad, local_loss):
         self.buf.zero_()
-        self.grad[self.lo:self.hi].copy_(local_grad)
-        self.buf[-1] = local_loss.detach() / self.world
-        if self.world > 1 or dist.is_initialized():
+        torch.mul(local_grad, 1.0 / self.world, out=self.grad[self.lo:self.hi])
+        torch.mul(local_loss.detach().reshape(1), 1.0 / self.world, out=self.buf[-1:])
+
+    def allreduce(self):
+        if dist.is_initialized():
             dist.all_reduce(self.buf, op=dist.ReduceOp.SUM)
+        elif self.world > 1:
+            raise RuntimeError('GradAllReduce with world=%d needs an initialised process group' % self.world)
+
+    def views(self):
         return self.grad, self.buf[-1]
+
+    def reduce(self, local_grad, local_loss):
+        self.pack(local_grad, local_loss)
+        self.allreduce()
+        return self.views()
 
 
 class GradAllGather:
@@ -67,6 +80,8 @@ class GradAllGather:
                 dist.all_gather([self.all[r] for r in range(self.world)], self.local)
             else:
                 dist.all_gather_into_tensor(self.all.view(-1), self.local)
+        elif self.world > 1:
+            raise RuntimeError('GradAllGather with world=%d needs an initialised process group' % self.world)
         else:
             self.all[0].copy_(self.local)
 

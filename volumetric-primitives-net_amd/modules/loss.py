@@ -64,11 +64,11 @@ class SilhouetteLoss(nn.Module):
 
     def forward(self, predict_meshes, gt_silhouettes: torch.Tensor,
                 dists: torch.Tensor, elevs: torch.Tensor, azims: torch.Tensor) -> torch.Tensor:
-        """silhouette.py:13-23.  `predict_meshes` is a PrimitivePack for the batch (or a list of
-        per-sample packs, the shape of the reference's list of meshes); the B sequential
+        """silhouette.py:13-23.  `predict_meshes` is the reference's list of B composed meshes (train.py:146-149,
+        made by Meshing: each carries its primitives), a list of per-sample packs, or one PrimitivePack for the
+        batch; the B sequential
         renders of silhouette.py:16-18 become one launch at the GT silhouette's resolution."""
-        if isinstance(predict_meshes, (list, tuple)):
-            predict_meshes = PrimitivePack.stack(list(predict_meshes))
+        predict_meshes = PrimitivePack.of(predict_meshes)
         H, W = gt_silhouettes.shape[-2:]
         B = len(predict_meshes)
         dev = predict_meshes.params.device

@@ -11,17 +11,22 @@ import math
 import torch
 
 from ..ops import SPHERE, CUBOID, MeshFunction, kinds_tensor
+from ..primitives import PrimitivePack
 
 
 class TriangleMesh:
-    """The two attributes of kaolin.rep.TriangleMesh that the reference touches (meshing.py:35-43)."""
+    """The two attributes of kaolin.rep.TriangleMesh that the reference touches (meshing.py:35-43), plus
+    `primitives`: the PrimitivePack (one sample, [1,K,10] + kinds) the mesh was generated from, attached by
+    Meshing.*_meshing and carried through compose_meshes.  The raster consumes primitives, not triangles, so a mesh
+    that carries them renders through SilhouetteLoss / VertexRenderer exactly as train.py:122-149,176 builds and
+    passes it; a mesh without them (e.g. loaded from an OBJ) cannot be rendered."""
 
-    def __init__(self, vertices: torch.Tensor, faces: torch.Tensor):
-        self.vertices, self.faces = vertices, faces
+    def __init__(self, vertices: torch.Tensor, faces: torch.Tensor, primitives=None):
+        self.vertices, self.faces, self.primitives = vertices, faces, primitives
 
     @classmethod
-    def from_tensors(cls, vertices, faces):
-        return cls(vertices, faces)
+    def from_tensors(cls, vertices, faces, primitives=None):
+        return cls(vertices, faces, primitives)
 
     @classmethod
     def from_obj(cls, path):
@@ -151,7 +156,9 @@ class Meshing:
         cls.check_parameters(v, q, t)
         params = torch.cat([v, q, t], 1)[:, None, :]
         verts, faces = cls.mesh_primitives(params, [kind])
-        return [TriangleMesh(verts[b], faces) for b in range(v.size(0))]     # a list over the batch (sphere.py:24-27)
+        kt = kinds_tensor([kind], params.device)
+        # a list over the batch (sphere.py:24-27); each mesh remembers the primitive it came from
+        return [TriangleMesh(verts[b], faces, PrimitivePack(params[b], kt)) for b in range(v.size(0))]
 
     @classmethod
     def cuboid_meshing(cls, v: torch.Tensor, q: torch.Tensor, t: torch.Tensor) -> list:
@@ -174,7 +181,11 @@ class Meshing:
             vertices.append(m.vertices)
             faces.append(m.faces + n)
             n += m.vertices.size(0)
-        return TriangleMesh.from_tensors(vertices=torch.cat(vertices), faces=torch.cat(faces))
+        packs = [getattr(m, 'primitives', None) for m in meshes]
+        prims = None
+        if all(p is not None for p in packs):                   # K single-primitive packs -> one [1,K,10] pack
+            prims = PrimitivePack(torch.cat([p.params for p in packs], 1), torch.cat([p.kinds for p in packs]))
+        return TriangleMesh.from_tensors(vertices=torch.cat(vertices), faces=torch.cat(faces), primitives=prims)
 
     @staticmethod
     def check_parameters(v: torch.Tensor, q: torch.Tensor, t: torch.Tensor):

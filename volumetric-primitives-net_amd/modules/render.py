@@ -15,7 +15,8 @@ def _as_batch(x, B, device):
 
 class VertexRenderer:
     """Same entry point as the reference (vertex_renderer.py:10-26).  Differences, all forced
-    by the reference rendering through kaolin (absent): `mesh` is a PrimitivePack, a whole
+    by the reference rendering through kaolin (absent): `mesh` is a PrimitivePack or a mesh that
+    carries one (what Meshing.*_meshing / compose_meshes return, so train.py:122-149,176 runs as written), a whole
     batch renders in one call, the camera travels with the call instead of mutating a
     module-global renderer (vertex_renderer.py:7,18), the image size is an argument instead of
     the hard-wired 128x128 (vertex_renderer.py:7), and the third output is the soft-min depth
@@ -30,9 +31,7 @@ class VertexRenderer:
 
     @classmethod
     def render(cls, mesh, dist, elev, azim, colors=None, image_size=None):
-        if not isinstance(mesh, PrimitivePack):
-            raise TypeError('VertexRenderer.render takes a PrimitivePack (primitive parameters); triangle meshes '
-                            'are the reference-side adapter (SURVEY.md 8f, row f2)')
+        mesh = PrimitivePack.of(mesh)        # a pack, a Meshing-made mesh (train.py:122-149), or a list of them
         B = len(mesh)
         dev = mesh.params.device
         cam = torch.stack([_as_batch(dist, B, dev), _as_batch(elev, B, dev), _as_batch(azim, B, dev)], 1)

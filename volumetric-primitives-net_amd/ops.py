@@ -23,18 +23,46 @@ def _f32c(t):
     return t.contiguous().float()          # emd_module.py:41-42 does the same to its inputs
 
 
-def kinds_tensor(kinds, device):
-    """int32 device tensor of primitive kinds; rejects cones (sampling.py:39-45 is `pass`)."""
-    if isinstance(kinds, torch.Tensor):
-        host = kinds.detach().cpu().tolist() if kinds.device.type != device.type else None
-        if host is None:
-            return kinds.to(torch.int32).contiguous()
-        kinds = host
-    kinds = [int(k) for k in kinds]
+_KINDS_OK = set()      # (data_ptr, version, numel) of device kind tensors whose contents have been validated
+
+
+def _check_kinds(kinds):
     if any(k not in (SPHERE, CUBOID) for k in kinds):
         raise ValueError('unknown primitive kind in %r (0 = sphere, 1 = cuboid; cones are not implemented '
                          'in the reference either)' % (kinds,))
-    return torch.tensor(kinds, dtype=torch.int32, device=device)
+
+
+def kinds_tensor(kinds, device):
+    """int32 device tensor of primitive kinds; rejects cones (sampling.py:39-45 is `pass`).  A tensor already on
+    the device is validated once (one host copy the first time that storage / version is seen: kind tensors are
+    made once per run) so that an unknown kind never reaches a kernel."""
+    device = torch.device(device)
+    if isinstance(kinds, torch.Tensor):
+        if kinds.device.type == device.type and kinds.dtype == torch.int32 and kinds.is_contiguous():
+            key = (kinds.data_ptr(), kinds._version, kinds.numel())
+            if key not in _KINDS_OK:
+                _check_kinds(kinds.detach().cpu().tolist())
+                if len(_KINDS_OK) > 4096:
+                    _KINDS_OK.clear()
+                _KINDS_OK.add(key)
+            return kinds
+        kinds = kinds.detach().cpu().tolist()
+    kinds = [int(k) for k in kinds]
+    _check_kinds(kinds)
+    t = torch.tensor(kinds, dtype=torch.int32, device=device)
+    if t.is_cuda:
+        _KINDS_OK.add((t.data_ptr(), t._version, t.numel()))
+    return t
+
+
+def _seed_args(seed):
+    """(host seed, device seed pointer) of the sampler entry points: `seed` is an int, or a device int64 tensor of
+    one element (a step counter bumped on the stream: read by the kernel, so HIP-graph replays draw fresh points)."""
+    if isinstance(seed, torch.Tensor):
+        if not (seed.is_cuda and seed.dtype == torch.int64 and seed.numel() == 1):
+            raise ValueError('a device seed must be a CUDA int64 tensor with one element')
+        return 0, _lib.ptr(seed)
+    return int(seed), None
 
 
 class SampleFunction(Function):
@@ -45,12 +73,13 @@ class SampleFunction(Function):
     def forward(ctx, params, kinds, u, seed, sample_base, n):
         params = _f32c(params)
         B, K, S = params.shape
+        kinds = kinds_tensor(kinds, params.device)
         assert S == PARAM_STRIDE and kinds.numel() == K
         if u is not None:
             u = _f32c(u)
             assert u.shape == (B, K, n, 3)
         points = torch.empty((B, K * n, 3), dtype=torch.float32, device=params.device)
-        _lib.call('vpn_sample_fwd', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(u), int(seed), int(sample_base),
+        _lib.call('vpn_sample_fwd', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(u), int(seed), None, int(sample_base),
                                     B, K, n, _lib.ptr(points), _lib.stream())
         ctx.save_for_backward(params, kinds, u if u is not None else torch.empty(0, device=params.device))
         ctx.has_u = u is not None
@@ -63,7 +92,7 @@ class SampleFunction(Function):
         seed, base, B, K, n = ctx.meta
         grad_points = _f32c(grad_points)
         grad_params = torch.empty_like(params)
-        _lib.call('vpn_sample_bwd', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(u) if ctx.has_u else None, seed,
+        _lib.call('vpn_sample_bwd', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(u) if ctx.has_u else None, seed, None,
                                     base, B, K, n, _lib.ptr(grad_points), _lib.ptr(grad_params), _lib.stream())
         return grad_params, None, None, None, None, None
 
@@ -105,6 +134,7 @@ class MeshFunction(Function):
     def forward(ctx, params, kinds, offsets, tpl_sphere, tpl_cuboid, ptot):
         params = _f32c(params)
         B, K, _ = params.shape
+        kinds = kinds_tensor(kinds, params.device)
         ts = _f32c(tpl_sphere) if tpl_sphere is not None else None
         tc = _f32c(tpl_cuboid) if tpl_cuboid is not None else None
         verts = torch.empty((B, int(ptot), 3), dtype=torch.float32, device=params.device)
@@ -213,7 +243,7 @@ class ChamferFunction(Function):
         s = _lib.stream()
         ws = torch.empty((_lib.lib().vpn_chamfer_workspace(B, N, M) // 4,), dtype=torch.float32, device=dev)
         _lib.call('vpn_chamfer_fwd_ws', _lib.ptr(p1), _lib.ptr(p2), B, N, M, _lib.ptr(d1), _lib.ptr(i1), _lib.ptr(d2),
-                  _lib.ptr(i2), _lib.ptr(ws), 0, s)
+                  _lib.ptr(i2), _lib.ptr(ws), ws.numel() * 4, 0, s)
         _lib.call('vpn_chamfer_loss', _lib.ptr(d1), _lib.ptr(d2), B, N, M, float(w1), float(w2), _lib.ptr(loss_b), s)
         ctx.save_for_backward(p1, p2, d1, i1, d2, i2)
         ctx.w = (float(w1), float(w2))
@@ -251,7 +281,7 @@ def chamfer_nn(p1, p2, mode='auto'):
     i2 = torch.empty((B, M), dtype=torch.int32, device=dev)
     ws = torch.empty((_lib.lib().vpn_chamfer_workspace(B, N, M) // 4,), dtype=torch.float32, device=dev)
     _lib.call('vpn_chamfer_fwd_ws', _lib.ptr(p1), _lib.ptr(p2), B, N, M, _lib.ptr(d1), _lib.ptr(i1), _lib.ptr(d2),
-              _lib.ptr(i2), _lib.ptr(ws), CHAMFER_MODES[mode], _lib.stream())
+              _lib.ptr(i2), _lib.ptr(ws), ws.numel() * 4, CHAMFER_MODES[mode], _lib.stream())
     return d1, i1, d2, i2
 
 
@@ -296,6 +326,7 @@ class RasterFunction(Function):
     def forward(ctx, params, kinds, cam, H, W, sigma, gamma, z_far):
         params, cam = _f32c(params), _f32c(cam)
         B, K, S = params.shape
+        kinds = kinds_tensor(kinds, params.device)
         assert S == PARAM_STRIDE and kinds.numel() == K and cam.shape == (B, 3)
         dev = params.device
         alpha = torch.empty((B, H, W), dtype=torch.float32, device=dev)
@@ -332,6 +363,7 @@ class RasterLossFunction(Function):
     def forward(ctx, params, kinds, cam, gt_sil, gt_depth, H, W, sigma, gamma, z_far, sil_mse):
         params, cam = _f32c(params), _f32c(cam)
         B, K, S = params.shape
+        kinds = kinds_tensor(kinds, params.device)
         assert S == PARAM_STRIDE and kinds.numel() == K and cam.shape == (B, 3)
         if gt_sil is not None:
             gt_sil = _f32c(gt_sil).reshape(B, H, W)
@@ -395,77 +427,90 @@ def _grad_pattern(B, w_cd, w_sil, w_depth, dev):
 
 class HotPathLossFunction(Function):
     """One training-step loss of the reference's hot path in a single autograd node (train.py:243-262):
-        total = w_cd * ChamferDistanceLoss(sample(params), gt_points) + w_sil * SilhouetteLoss + w_depth * L1(depth)
+        total = w_cd * ChamferDistanceLoss(sample(params), gt_points; cd_w1, cd_w2) + w_sil * SilhouetteLoss
+                + w_depth * L1(depth)
     Forward: sampler -> Chamfer scans -> per-sample loss -> raster with fused image losses (which also
     assembles the total).  Backward: Chamfer backward -> sampler backward (writes d/dparams) -> raster
-    backward (adds to it).  No intermediate ever goes through an ATen kernel.  Returns [3] =
-    (silhouette loss, depth loss, total); differentiate the total."""
+    backward (adds to it).  No intermediate ever goes through an ATen kernel.  Returns three scalars
+    (silhouette loss, depth loss, total); only the total is differentiable (the first two are reported values:
+    they are marked non-differentiable, so `out[0].backward()` raises instead of returning a wrong gradient).
+    `seed`: int, or a device int64 tensor of one element read by the kernels (see _seed_args).
+    cd_w1 / cd_w2 = config.CD_W1 / CD_W2 (chamfer_distance.py:10), sil_mse = SILHOUETTE_LOSS_FUNC != 'L1'."""
 
     @staticmethod
     def forward(ctx, params, kinds, cam, gt_points, gt_sil, gt_depth, n, seed, sample_base, H, W, sigma, gamma,
-                z_far, w_cd, w_sil, w_depth):
+                z_far, w_cd, w_sil, w_depth, cd_w1=1.0, cd_w2=1.0, sil_mse=False):
         params, cam, gt_points = _f32c(params), _f32c(cam), _f32c(gt_points)
         B, K, _ = params.shape
         M = gt_points.shape[1]
         N = K * n
         dev = params.device
+        kinds = kinds_tensor(kinds, dev)
+        assert kinds.numel() == K and cam.shape == (B, 3) and gt_points.shape[0] == B
         L = _lib.lib()
         s = _lib.stream()
+        seed_host, seed_dev = _seed_args(seed)
+        cd_w1, cd_w2, sil_mse = float(cd_w1), float(cd_w2), int(bool(sil_mse))
         gt_sil = _f32c(gt_sil).reshape(B, H, W) if gt_sil is not None else None
         gt_depth = _f32c(gt_depth).reshape(B, H, W) if gt_depth is not None else None
-        # The raster branch (VALU-bound) is independent of the sampler + Chamfer branch (matrix-pipe filter) until
-        # the total: it runs on a side stream so the two overlap (fork / join is captured into HIP graphs as such).
         aux = torch.empty((B, 3, H, W), dtype=torch.float32, device=dev)
         rec = torch.empty((L.vpn_raster_records_size(B, K) // 4,), dtype=torch.float32, device=dev)
         lws = torch.empty((L.vpn_raster_loss_workspace(B, H, W) // 4,), dtype=torch.float32, device=dev)
         losses = torch.empty((3,), dtype=torch.float32, device=dev)
         main = torch.cuda.current_stream()
+        # optionally the raster branch (independent of the sampler + Chamfer branch until the total) runs on a side
+        # stream; fork / join is captured into HIP graphs as such
         side = _side_stream(dev) if CONCURRENT_BRANCHES else None
         if side is not None:
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 _lib.call('vpn_raster_loss_fwd', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(cam), B, K, H, W,
-                          float(sigma), float(gamma), float(z_far), _lib.ptr(gt_sil), _lib.ptr(gt_depth), 0,
+                          float(sigma), float(gamma), float(z_far), _lib.ptr(gt_sil), _lib.ptr(gt_depth), sil_mse,
                           _lib.ptr(aux), _lib.ptr(rec), _lib.ptr(lws), _lib.ptr(losses), None, 0, 0.0, 0.0, 0.0,
                           _lib.stream())
         points = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
-        _lib.call('vpn_sample_fwd', _lib.ptr(params), _lib.ptr(kinds), None, int(seed), int(sample_base), B, K, n,
-                  _lib.ptr(points), s)
+        _lib.call('vpn_sample_fwd', _lib.ptr(params), _lib.ptr(kinds), None, seed_host, seed_dev, int(sample_base), B, K,
+                  n, _lib.ptr(points), s)
         d1 = torch.empty((B, N), dtype=torch.float32, device=dev)
         d2 = torch.empty((B, M), dtype=torch.float32, device=dev)
         i1 = torch.empty((B, N), dtype=torch.int32, device=dev)
         i2 = torch.empty((B, M), dtype=torch.int32, device=dev)
         cws = torch.empty((L.vpn_chamfer_workspace(B, N, M) // 4,), dtype=torch.float32, device=dev)
         _lib.call('vpn_chamfer_fwd_ws', _lib.ptr(points), _lib.ptr(gt_points), B, N, M, _lib.ptr(d1), _lib.ptr(i1),
-                  _lib.ptr(d2), _lib.ptr(i2), _lib.ptr(cws), 0, s)
+                  _lib.ptr(d2), _lib.ptr(i2), _lib.ptr(cws), cws.numel() * 4, 0, s)
         loss_b = torch.empty((B,), dtype=torch.float32, device=dev)
-        _lib.call('vpn_chamfer_loss', _lib.ptr(d1), _lib.ptr(d2), B, N, M, 1.0, 1.0, _lib.ptr(loss_b), s)
+        _lib.call('vpn_chamfer_loss', _lib.ptr(d1), _lib.ptr(d2), B, N, M, cd_w1, cd_w2, _lib.ptr(loss_b), s)
         if side is not None:
             main.wait_stream(side)
             _lib.call('vpn_total_loss', _lib.ptr(loss_b), B, float(w_cd), float(w_sil), float(w_depth),
                       _lib.ptr(losses), s)
         else:
             _lib.call('vpn_raster_loss_fwd', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(cam), B, K, H, W,
-                      float(sigma), float(gamma), float(z_far), _lib.ptr(gt_sil), _lib.ptr(gt_depth), 0, _lib.ptr(aux),
-                      _lib.ptr(rec), _lib.ptr(lws), _lib.ptr(losses), _lib.ptr(loss_b), B, float(w_cd), float(w_sil),
-                      float(w_depth), s)
+                      float(sigma), float(gamma), float(z_far), _lib.ptr(gt_sil), _lib.ptr(gt_depth), sil_mse,
+                      _lib.ptr(aux), _lib.ptr(rec), _lib.ptr(lws), _lib.ptr(losses), _lib.ptr(loss_b), B, float(w_cd),
+                      float(w_sil), float(w_depth), s)
         pattern = _grad_pattern(B, w_cd, w_sil, w_depth, dev)
         empty = torch.empty(0, device=dev)
+        seed_t = seed if isinstance(seed, torch.Tensor) else empty
         ctx.save_for_backward(params, kinds, cam, gt_points, points, d1, i1, d2, i2, aux, rec,
                               gt_sil if gt_sil is not None else empty, gt_depth if gt_depth is not None else empty,
-                              pattern)
-        ctx.meta = (B, K, n, M, H, W, int(seed), int(sample_base), float(sigma), float(gamma), float(z_far),
-                    gt_sil is not None, gt_depth is not None)
-        return losses
+                              pattern, seed_t)
+        ctx.meta = (B, K, n, M, H, W, seed_host, seed_dev is not None, int(sample_base), float(sigma), float(gamma),
+                    float(z_far), gt_sil is not None, gt_depth is not None, cd_w1, cd_w2, sil_mse)
+        sil, dep, tot = losses.unbind(0)
+        ctx.mark_non_differentiable(sil, dep)
+        return sil, dep, tot
 
     @staticmethod
-    def backward(ctx, grad_losses):
-        (params, kinds, cam, gt_points, points, d1, i1, d2, i2, aux, rec, gt_sil, gt_depth, pattern) = ctx.saved_tensors
-        B, K, n, M, H, W, seed, base, sigma, gamma, z_far, has_sil, has_depth = ctx.meta
+    def backward(ctx, _g_sil, _g_dep, grad_total):
+        (params, kinds, cam, gt_points, points, d1, i1, d2, i2, aux, rec, gt_sil, gt_depth, pattern,
+         seed_t) = ctx.saved_tensors
+        (B, K, n, M, H, W, seed, has_seed_dev, base, sigma, gamma, z_far, has_sil, has_depth, cd_w1, cd_w2,
+         sil_mse) = ctx.meta
         N = K * n
         s = _lib.stream()
-        # only the total (index 2) is meant to be differentiated
-        gvec = (pattern * grad_losses[2]).contiguous()          # one small kernel: [B] for Chamfer, [2] for the raster
+        seed_dev = _lib.ptr(seed_t) if has_seed_dev else None
+        gvec = (pattern * grad_total).contiguous()              # one small kernel: [B] for Chamfer, [2] for the raster
         g2 = ctypes.c_void_p(gvec.data_ptr() + 4 * B)           # the last two entries: (sil, depth) gradients
         ws = torch.empty((_lib.lib().vpn_raster_bwd_workspace(B, K, H, W) // 4,), dtype=torch.float32,
                          device=params.device)
@@ -478,19 +523,20 @@ class HotPathLossFunction(Function):
             with torch.cuda.stream(side):
                 _lib.call('vpn_raster_loss_bwd', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(cam), B, K, H, W, sigma,
                           gamma, z_far, _lib.ptr(aux), _lib.ptr(rec), _lib.ptr(gt_sil) if has_sil else None,
-                          _lib.ptr(gt_depth) if has_depth else None, 0, g2, _lib.ptr(ws), _lib.ptr(grad_raster), 0,
+                          _lib.ptr(gt_depth) if has_depth else None, sil_mse, g2, _lib.ptr(ws), _lib.ptr(grad_raster), 0,
                           _lib.stream())
+                gvec.record_stream(side)
         # Chamfer backward and sampler backward in one launch: the [B,N,3] point gradient never exists
         grad_params = torch.empty_like(params)
         if M <= FUSED_BWD_MAX_GT:
-            _lib.call('vpn_sample_chamfer_bwd', _lib.ptr(params), _lib.ptr(kinds), None, seed, base, B, K, n,
+            _lib.call('vpn_sample_chamfer_bwd', _lib.ptr(params), _lib.ptr(kinds), None, seed, seed_dev, base, B, K, n,
                       _lib.ptr(points), _lib.ptr(gt_points), M, _lib.ptr(d1), _lib.ptr(i1), _lib.ptr(d2), _lib.ptr(i2),
-                      _lib.ptr(gvec), 1.0, 1.0, _lib.ptr(grad_params), s)
+                      _lib.ptr(gvec), cd_w1, cd_w2, _lib.ptr(grad_params), s)
         else:                                                   # GT clouds beyond the fused kernel's LDS match lists
             grad_points = torch.empty_like(points)
             _lib.call('vpn_chamfer_bwd', _lib.ptr(points), _lib.ptr(gt_points), _lib.ptr(d1), _lib.ptr(i1), _lib.ptr(d2),
-                      _lib.ptr(i2), _lib.ptr(gvec), B, N, M, 1.0, 1.0, _lib.ptr(grad_points), None, s)
-            _lib.call('vpn_sample_bwd', _lib.ptr(params), _lib.ptr(kinds), None, seed, base, B, K, n,
+                      _lib.ptr(i2), _lib.ptr(gvec), B, N, M, cd_w1, cd_w2, _lib.ptr(grad_points), None, s)
+            _lib.call('vpn_sample_bwd', _lib.ptr(params), _lib.ptr(kinds), None, seed, seed_dev, base, B, K, n,
                       _lib.ptr(grad_points), _lib.ptr(grad_params), s)
         if side is not None:
             main.wait_stream(side)
@@ -498,6 +544,5 @@ class HotPathLossFunction(Function):
         else:
             _lib.call('vpn_raster_loss_bwd', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(cam), B, K, H, W, sigma,
                       gamma, z_far, _lib.ptr(aux), _lib.ptr(rec), _lib.ptr(gt_sil) if has_sil else None,
-                      _lib.ptr(gt_depth) if has_depth else None, 0, g2, _lib.ptr(ws), _lib.ptr(grad_params), 1, s)
-        return (grad_params,) + (None,) * 16
-
+                      _lib.ptr(gt_depth) if has_depth else None, sil_mse, g2, _lib.ptr(ws), _lib.ptr(grad_params), 1, s)
+        return (grad_params,) + (None,) * 19

@@ -47,4 +47,25 @@ class PrimitivePack:
 
     @staticmethod
     def stack(packs):
+        for p in packs[1:]:
+            if not torch.equal(p.kinds, packs[0].kinds):
+                raise ValueError('all samples of a batch must hold the same primitive kinds in the same order')
         return PrimitivePack(torch.cat([p.params for p in packs], 0), packs[0].kinds)
+
+    @staticmethod
+    def of(obj):
+        """PrimitivePack behind `obj`: a pack itself, a mesh produced by Meshing.*_meshing / compose_meshes (its
+        `.primitives`), or a list of either, one entry per sample (the list train.py:122-149 builds and train.py:176
+        hands to SilhouetteLoss).  Anything else - e.g. a triangle mesh without primitives - raises TypeError."""
+        if isinstance(obj, PrimitivePack):
+            return obj
+        if isinstance(obj, (list, tuple)):
+            if not obj:
+                raise TypeError('empty list of meshes')
+            return PrimitivePack.stack([PrimitivePack.of(o) for o in obj])
+        prims = getattr(obj, 'primitives', None)
+        if isinstance(prims, PrimitivePack):
+            return prims
+        raise TypeError('the primitive raster renders primitive parameters: pass a PrimitivePack or a mesh made by '
+                        'Meshing.sphere_meshing / cuboid_meshing / compose_meshes (which carries its primitives); '
+                        'got %s without primitives' % type(obj).__name__)
