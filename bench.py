@@ -115,12 +115,13 @@ def raster_only(vpn_amd, _lib, dev, B, K, H, steps, warmup, windows, pmc_key, us
     with torch.no_grad():
         a2, d2 = vpn_amd.RasterFunction.apply(p2, kinds, cam, H, W, sigma, gamma, z_far)
     gt_sil, gt_depth = (a2 > 0.5).float(), d2.clone()
-    ones = torch.ones(2, device=dev)
+    one = torch.ones((), device=dev)
 
     def compute(_i=0):
+        # total_img = SilhouetteLoss(L1) + L1 depth loss and its gradient to (v,q,t): the raster part of the C3 step
         params.grad = None
-        out = vpn_amd.RasterLossFunction.apply(params, kinds, cam, gt_sil, gt_depth, H, W, sigma, gamma, z_far, False)
-        out.backward(ones)
+        out = vpn_amd.RasterTotalFunction.apply(params, kinds, cam, gt_sil, gt_depth, H, W, sigma, gamma, z_far, False, 1.0, 1.0)
+        out[2].backward(one)
         return out
 
     side = torch.cuda.Stream()
@@ -149,7 +150,7 @@ def raster_only(vpn_amd, _lib, dev, B, K, H, steps, warmup, windows, pmc_key, us
     fwd_b, bwd_b = B * (40 * K + 8 * H * W), B * (8 * H * W + 80 * K)
     pmc = load_pmc(pmc_key)
     roof = {}
-    for name, alg in (('raster_fwd_kernel<1>', fwd_b), ('raster_bwd_kernel<1>', bwd_b)):
+    for name, alg in (('raster_total_kernel', fwd_b + bwd_b), ('raster_fwd_kernel<1>', fwd_b), ('raster_bwd_kernel<1>', bwd_b)):
         if name not in kern:
             continue
         us = kern[name][1] * 1e3
@@ -160,7 +161,7 @@ def raster_only(vpn_amd, _lib, dev, B, K, H, steps, warmup, windows, pmc_key, us
                       'executed_work': valu_issue_roofline(name, pmc, us)}
     ms = ev['median']
     return {'workload': 'C2: B=%d, K=%d sphere primitives, %dx%d silhouette+depth, raster fwd+bwd only '
-                        '(vpn_raster_loss_fwd/bwd: render + L1(sil) + L1(depth) + gradient)' % (B, K, H, W),
+                        '(vpn_raster_total_fwd/bwd: render + L1(sil) + L1(depth) + gradient to (v,q,t))' % (B, K, H, W),
             'images_per_s': round(B / ms * 1e3, 1), 'ms_per_step': round(ms, 5), 'timing': ev,
             'algorithmic_bytes_per_image': (fwd_b + bwd_b) // B, 'kernel_us': kernel_us, 'roofline': roof,
             'pmc_source': os.path.relpath(PMC_FILE, ROOT) if pmc else None}
@@ -220,16 +221,14 @@ def main():
         res = raster_only(vpn_amd, _lib, dev, B, args.prims or 16, args.size or 128, args.steps, args.warmup,
                           args.windows, 'c2', not args.no_graph)
         if rank == 0:
-            fwd = res['roofline'].get('raster_fwd_kernel<1>', {})
-            bwd = res['roofline'].get('raster_bwd_kernel<1>', {})
-            dom = bwd if bwd.get('avg_launch_us', 0) >= fwd.get('avg_launch_us', 0) else fwd
+            domk = max(res['roofline'], key=lambda k: res['roofline'][k]['avg_launch_us'])
+            dom = res['roofline'][domk]
             out = {'metric': 'raster fwd+bwd images/sec (BASELINE config C2)', 'value': res['images_per_s'],
                    'unit': 'images/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
                    'ms_per_step': res['ms_per_step'], 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
                    'dtype': 'f32', 'data': 'synthetic', 'launch': 'eager' if args.no_graph else 'hip-graph replay',
                    'config': {'workload': res['workload'], 'global_batch': B, 'parallelism': 'dp1'},
-                   'roofline': dict(dom.get('hbm', {}), kernel='raster_bwd_kernel<1>' if dom is bwd else 'raster_fwd_kernel<1>',
-                                    executed_work=dom.get('executed_work')),
+                   'roofline': dict(dom.get('hbm', {}), kernel=domk, executed_work=dom.get('executed_work')),
                    'c2': res}
             print(json.dumps(out), flush=True)
         if multi:
@@ -369,6 +368,7 @@ def main():
         'chamfer_nn_pruned_kernel<1>': nn_bytes,
         'raster_fwd_kernel<0>': B * (40 * K + 8 * H * W), 'raster_fwd_kernel<1>': B * (40 * K + 8 * H * W),
         'raster_bwd_kernel<0>': B * (8 * H * W + 80 * K), 'raster_bwd_kernel<1>': B * (8 * H * W + 80 * K),
+        'raster_total_kernel': B * (40 * K + 8 * H * W) + B * (8 * H * W + 80 * K),      # forward + backward in one launch
         'sample_fwd_kernel': B * (40 * K + 12 * N), 'sample_bwd_kernel': B * (12 * N + 80 * K),
         'chamfer_bwd_lds_kernel': B * (12 * (N + M) + 8 * (N + M) + 12 * N),
         'sample_chamfer_bwd_kernel': B * (12 * (N + M) + 8 * (N + M) + 80 * K),
@@ -408,7 +408,7 @@ def main():
         roofline['traffic_source'] = os.path.relpath(PMC_FILE, ROOT) + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same workload)'
     # the raster pair: HBM view (algorithmic bytes) and the executed-work view (VALU issue) per kernel
     raster_roof = {}
-    for name in ('raster_fwd_kernel<1>', 'raster_bwd_kernel<1>'):
+    for name in ('raster_total_kernel', 'raster_fwd_kernel<1>', 'raster_bwd_kernel<1>'):
         if name in kern:
             us = kern[name][1] * 1e3
             gbs = alg_bytes[name] / (us * 1e-6) / 1e9
@@ -510,6 +510,15 @@ def cpu_baseline(params, gt_points, params2, K, n, H, W, sigma, gamma, z_far, ki
             gs.append((a2 > 0.5).float())
             gd.append(d2)
         gt_sil, gt_depth = torch.cat(gs), torch.cat(gd)
+        # The L1 depth loss differentiates through sign(D - gt_depth), which fp32 cannot decide where the predicted and
+        # the GT surface cross within rounding noise; ONE flipped pixel moves the gradient by ~1e-3 relative (it carries
+        # 2/(S*H*W) of weight against ~1e3 edge pixels per primitive), and a 32-image sample holds about one such pixel
+        # (Finding 6).  Those pixels get their GT moved by 1e-3 so that the comparison is decidable.
+        dp = torch.cat([O.raster(params[b:b + 4], kl, camc[b:b + 4], H, W, sigma, gamma, z_far)[1] for b in range(0, S, 4)])
+        diff = dp - gt_depth
+        near = (diff != 0) & (diff.abs() < 1e-5)
+        gt_depth = torch.where(near, gt_depth - torch.where(diff >= 0, 1e-3, -1e-3), gt_depth)
+        n_near = int(near.sum())
 
     def run(S=S):
         p = params.clone().requires_grad_(True)
@@ -544,7 +553,9 @@ def cpu_baseline(params, gt_points, params2, K, n, H, W, sigma, gamma, z_far, ki
                       'fp32 with %d threads on a host with %d cores, dense B*N*M Chamfer as chamfer_distance.py:14-23'
                       % (S, '/'.join('%.1f' % t for t in times), threads, host_cores),
             'parity_vs_gpu': {'loss_rel': float('%.3g' % lerr), 'grad_rel': float('%.3g' % gerr),
-                              'gt_images': 'rendered by the CPU oracle'}}
+                              'gt_images': 'rendered by the CPU oracle; %d pixels whose predicted depth lies within '
+                                           '1e-5 of the GT depth (sign of the L1 term undecidable in fp32) had '
+                                           'their GT moved by 1e-3' % n_near}}
 
 
 if __name__ == '__main__':

@@ -150,11 +150,11 @@ int vpn_chamfer_bwd(const float* p1, const float* p2,
  * rasterises the mesh with kaolin's DIBRenderer, which is not in its tree).
  *   cam [B,3] = (dist, elev_deg, azim_deg)   (vertex_renderer.py:18)
  *   alpha, depth [B,H,W]; aux [B,3,H,W] = (prod(1-a), zbar, sum w) saved for bwd;
- *   records: vpn_raster_records_size(B,K) bytes, 16-byte aligned, written by fwd (the
- *   per-primitive camera-space ray coefficients + pixel bounding boxes) and read
- *   again by bwd — keep it alive with aux.
+ *   records: vpn_raster_records_size(B,K,H,W) bytes, 16-byte aligned, written by fwd (the
+ *   per-primitive camera-space ray coefficients and culling conics, then the per-tile
+ *   visibility masks) and read again by bwd — keep it alive with aux.
  */
-size_t vpn_raster_records_size(int B, int K);
+size_t vpn_raster_records_size(int B, int K, int H, int W);
 int vpn_raster_fwd(const float* params, const int32_t* kinds, const float* cam,
                    int B, int K, int H, int W, float sigma, float gamma, float z_far,
                    float* alpha, float* depth, float* aux, void* records, void* stream);
@@ -173,21 +173,14 @@ int vpn_raster_bwd(const float* params, const int32_t* kinds, const float* cam,
  * against the GT silhouette) in one pass, optionally with an L1 depth loss: the losses are
  * evaluated where the pixel is produced, so alpha/depth and their gradients never travel through HBM.
  *   gt_sil, gt_depth [B,H,W] (either may be NULL -> that loss is 0); sil_mse: 0 = L1, 1 = MSE;
- *   losses [3] = (mean silhouette loss, mean |depth - gt_depth|, total); the total is written only when
- *   extra_loss_b [nb] is given: total = w_extra * mean(extra_loss_b) + w_sil * losses[0] + w_dep * losses[1]
- *   (the weighted sum of train.py:243-262 with the per-sample Chamfer losses as `extra`);
- *   loss_ws: vpn_raster_loss_workspace(B,H,W) bytes of scratch; aux/records as for vpn_raster_fwd.
+ *   losses [4] = (mean silhouette loss, mean |depth - gt_depth|, their sum, 0);
+ *   loss_ws: vpn_raster_loss_workspace(B,H,W) bytes of scratch (16-byte aligned); aux/records as for vpn_raster_fwd.
  */
 size_t vpn_raster_loss_workspace(int B, int H, int W);
 int vpn_raster_loss_fwd(const float* params, const int32_t* kinds, const float* cam,
                         int B, int K, int H, int W, float sigma, float gamma, float z_far,
                         const float* gt_sil, const float* gt_depth, int sil_mse,
-                        float* aux, void* records, void* loss_ws, float* losses,
-                        const float* extra_loss_b, int nb, float w_extra, float w_sil, float w_dep,
-                        void* stream);
-/* losses[2] = w_extra * mean(loss_b[0..nb)) + w_sil * losses[0] + w_dep * losses[1]: the total when the raster
- * and the Chamfer branches ran concurrently on two streams and meet here. */
-int vpn_total_loss(const float* loss_b, int nb, float w_extra, float w_sil, float w_dep, float* losses, void* stream);
+                        float* aux, void* records, void* loss_ws, float* losses, void* stream);
 /* grad_losses [2] (device): upstream gradients of the two scalar losses; workspace as for
  * vpn_raster_bwd; grad_params [B,K,10] is written, or added to when accumulate != 0 (so the gradient of
  * the sampler + Chamfer branch and of the raster branch meet without an extra pass). */
@@ -197,6 +190,29 @@ int vpn_raster_loss_bwd(const float* params, const int32_t* kinds, const float* 
                         const float* gt_sil, const float* gt_depth, int sil_mse,
                         const float* grad_losses, void* workspace, float* grad_params, int accumulate,
                         void* stream);
+
+/* ---- the training step's image losses, forward and backward in ONE pass (train.py:243-262, :176)
+ *   total_img = w_sil * SilhouetteLoss(render(params), gt_sil) + w_dep * mean |depth - gt_depth|
+ * vpn_raster_total_fwd renders, evaluates both losses and, in the same kernel, the gradient of total_img w.r.t. the
+ * ray coefficients (for an upstream gradient of 1; the result is linear in it): per-tile loss sums go to loss_ws,
+ * gradient partials to `workspace` (vpn_raster_bwd_workspace bytes); no aux tensor exists.
+ * vpn_loss_finalize turns the per-tile sums (and, when dist1/dist2 [B,N]/[B,M] are given, the per-sample Chamfer
+ * loss cd_b = cd_w1 mean_i dist1 + cd_w2 mean_j dist2, chamfer_distance.py:25-28) into
+ *   losses[4] = (silhouette loss, depth loss, w_cd * mean_b cd_b + w_sil * [0] + w_dep * [1], mean_b cd_b)
+ * in a fixed summation order; loss_b [B] (optional) receives cd_b.  H = W = 0: no image losses (Chamfer only; loss_ws
+ * then needs 16 + 16 B bytes, zeroed once by the caller).
+ * vpn_raster_total_bwd (when backward runs): grad_params (+)= (*grad_total) * d total_img / d params from the
+ * partials; grad_total is a DEVICE scalar (NULL = 1). */
+int vpn_raster_total_fwd(const float* params, const int32_t* kinds, const float* cam,
+                         int B, int K, int H, int W, float sigma, float gamma, float z_far,
+                         const float* gt_sil, const float* gt_depth, int sil_mse, float w_sil, float w_dep,
+                         void* records, void* loss_ws, void* workspace, void* stream);
+int vpn_loss_finalize(void* loss_ws, int B, int H, int W, const float* dist1, const float* dist2, int N, int M,
+                      float cd_w1, float cd_w2, float w_cd, float w_sil, float w_dep, float* losses, float* loss_b,
+                      void* stream);
+int vpn_raster_total_bwd(const float* params, const float* cam, int B, int K, int H, int W,
+                         const void* records, const void* workspace, const float* grad_total,
+                         float* grad_params, int accumulate, void* stream);
 
 /* ---- fused camera transforms (row f3): view_to_obj_points / obj_to_view_points
  * (modules/transform/transform.py:21-47, :50-73; called on train.py:158 every step).

@@ -31,14 +31,15 @@ SIGNATURES = {
     'vpn_chamfer_fwd_ws': (_i, [_c_f, _c_f, _i, _i, _i, _c_f, _c_f, _c_f, _c_f, _c_f, _sz, _i, _c_f]),
     'vpn_chamfer_loss': (_i, [_c_f, _c_f, _i, _i, _i, _f, _f, _c_f, _c_f]),
     'vpn_chamfer_bwd': (_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i, _i, _i, _f, _f, _c_f, _c_f, _c_f]),
-    'vpn_raster_records_size': (_sz, [_i, _i]),
+    'vpn_raster_records_size': (_sz, [_i, _i, _i, _i]),
     'vpn_raster_fwd': (_i, [_c_f, _c_f, _c_f, _i, _i, _i, _i, _f, _f, _f, _c_f, _c_f, _c_f, _c_f, _c_f]),
     'vpn_raster_bwd_workspace': (_sz, [_i, _i, _i, _i]),
     'vpn_raster_bwd': (_i, [_c_f, _c_f, _c_f, _i, _i, _i, _i, _f, _f, _f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f]),
     'vpn_raster_loss_workspace': (_sz, [_i, _i, _i]),
-    'vpn_raster_loss_fwd': (_i, [_c_f, _c_f, _c_f, _i, _i, _i, _i, _f, _f, _f, _c_f, _c_f, _i, _c_f, _c_f, _c_f, _c_f,
-                                 _c_f, _i, _f, _f, _f, _c_f]),
-    'vpn_total_loss': (_i, [_c_f, _i, _f, _f, _f, _c_f, _c_f]),
+    'vpn_raster_loss_fwd': (_i, [_c_f, _c_f, _c_f, _i, _i, _i, _i, _f, _f, _f, _c_f, _c_f, _i, _c_f, _c_f, _c_f, _c_f, _c_f]),
+    'vpn_raster_total_fwd': (_i, [_c_f, _c_f, _c_f, _i, _i, _i, _i, _f, _f, _f, _c_f, _c_f, _i, _f, _f, _c_f, _c_f, _c_f, _c_f]),
+    'vpn_loss_finalize': (_i, [_c_f, _i, _i, _i, _c_f, _c_f, _i, _i, _f, _f, _f, _f, _f, _c_f, _c_f, _c_f]),
+    'vpn_raster_total_bwd': (_i, [_c_f, _c_f, _i, _i, _i, _i, _c_f, _c_f, _c_f, _c_f, _i, _c_f]),
     'vpn_raster_loss_bwd': (_i, [_c_f, _c_f, _c_f, _i, _i, _i, _i, _f, _f, _f, _c_f, _c_f, _c_f, _c_f, _i, _c_f, _c_f, _c_f,
                                  _i, _c_f]),
     'vpn_camera_transform_fwd': (_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _i, _i, _i, _c_f, _c_f]),

@@ -6,29 +6,31 @@
 // per-sample loop of SilhouetteLoss.forward (modules/loss/silhouette.py:16-20).  The
 // reference meshes each primitive (modules/meshing/sphere.py:8-27) and hands the mesh
 // to kaolin's DIBRenderer, which is not part of its tree: this operator is new and its
-// specification is oracle/vpn_oracle.py::raster (parity unpinned w.r.t. kaolin).
+// specification is oracle/vpn_oracle.py::raster (parity unpinned w.r.t. kaolin; geometry
+// pinned to reference-derived data by tests/test_raster_geometry.py).
 //
 // Work decomposition (CDNA4):
-//   * prep kernel: one lane per (image, primitive): pose from q, camera-space ray coefficients
-//     (o~, Mr, Mu, Mf), the exact culling conic of the primitive and its tight pixel box -> a
-//     7 x float4 record [B,K,7] in HBM (3.5 KB per image at K=32), reused by forward and backward;
-//   * raster kernels: ONE WAVEFRONT PER 16x16 PIXEL TILE (workgroup = 64 threads); the ray
-//     coefficients and pixel boxes of the image's K primitives are staged into LDS; inside the
-//     per-primitive loop every LDS read is a wave-uniform broadcast.  Lane l owns column l&15 and
-//     rows (l>>4)+4s, s=0..3: backward accumulates its 4 pixels in registers before the cross-lane
-//     reduction;
-//   * culling: each lane tests one primitive against the tile (pixel box, then exact
-//     conic-vs-rectangle) and a 64-bit ballot drives the loop.  A primitive is skipped only where
-//     its coverage logit is below -X_CUT (coverage < 1.3e-14): the result matches the dense
-//     specification to ~1e-6;
-//   * MODE 1 fuses SilhouetteLoss (L1/MSE) and an L1 depth loss: the images and their gradients
-//     never go through HBM;
+//   * binning kernel (once per call): per (image, primitive) the pose from q, the camera-space ray
+//     coefficients (o~, Mr, Mu, Mf), the exact culling conic and its pixel box -> a 7 x float4 record
+//     [B,K,7]; then per (image, 16x16 tile) a bit mask of the primitives that can touch the tile (pixel box,
+//     then exact conic-vs-rectangle; a primitive is dropped only where its coverage logit is below -X_CUT:
+//     coverage < 1.2e-7).  Forward, backward and the finishing kernel share the masks;
+//   * tile kernels: ONE WAVEFRONT PER 16x16 PIXEL TILE, four independent waves per workgroup (a 32x32 pixel
+//     block: no LDS, no barrier).  The tile's primitive list is the mask (scalar control flow); the ray
+//     coefficients are read with wave-uniform addresses.  Lane l owns column l&15 and rows (l>>4)+4s,
+//     s=0..3: backward accumulates its 4 pixels in registers before the cross-lane reduction;
+//   * raster_total_kernel: forward AND backward of the training step's image losses in one pass (state in
+//     registers, no `aux`, GT read once); raster_fwd / raster_bwd kernels: the general two-call form (images or
+//     two separately weighted losses), with the per-pixel state saved in `aux`;
 //   * backward: the per-pixel gradients w.r.t. the 12 ray coefficients of a primitive are summed
 //     over the lane's pixels, reduced over the wave with a transposing butterfly (17 shuffles for
-//     12 values), parked in LDS and written once per tile as partials [B,tiles,K,12] with plain
-//     coalesced stores; a finishing kernel sums the partials in a fixed order and applies the
-//     chain rule to (v,q,t).  No atomics anywhere: the gradient is bitwise reproducible.
+//     12 values) and written as 48 contiguous bytes of partial[b][k][tile] for the pairs of the mask only;
+//     a finishing kernel sums them in a fixed order and applies the chain rule to (v,q,t).  No atomics in the
+//     gradient: bitwise reproducible;
+//   * loss_finalize_kernel: per-sample sums of the tile losses (and of the Chamfer minima) and the batch
+//     totals by the last-arriving workgroup, in a fixed order.
 #include "vpn_common.h"
+#include <type_traits>
 
 #define R_EXP(x) __expf(x)   // v_exp_f32 based; the raster is a 1e-4 contract
 // a / b as a * v_rcp_f32(b): the compiler's fp32 division is a ~8-instruction sequence (range scaling for huge and
@@ -47,7 +49,7 @@ constexpr float R_X_CUT = 16.0f;     // primitives whose coverage logit is below
 constexpr int R_TW = 16, R_TH = 16;  // pixel tile per wave
 constexpr int R_PPL = 4;             // pixels per lane (row groups of 4 rows)
 constexpr int R_REC = 7;             // float4 per primitive record in HBM
-constexpr int R_LREC = 5;            // float4 per primitive staged in LDS (ray coefficients + pixel bbox)
+constexpr int R_CULL = 3;            // float4 per primitive staged in LDS by the binning kernel (pixel box + conic)
 
 struct Camera {
     float eye[3], right[3], up[3], fwd[3];
@@ -90,23 +92,16 @@ __device__ inline void prim_geometry(const Camera& C, const Mat3& R, const float
     }
 }
 
-// rec[(b*K+k)*5 + 0..3] = (o~|kind, Mr, Mu, Mf), rec[..+4] = pixel bbox (jmin, jmax, imin, imax as int bits)
-__global__ __launch_bounds__(256) void raster_prep_kernel(const float* __restrict__ params,
-                                                          const int32_t* __restrict__ kinds,
-                                                          const float* __restrict__ cam, int BK, int K, int H, int W,
-                                                          float sigma, float4* __restrict__ rec) {
-    const int bk = blockIdx.x * 256 + threadIdx.x;
-    if (bk >= BK) return;
-    const int b = bk / K, k = bk - b * K;
+// Record of one primitive for one camera: out[0..3] = (o~|kind, Mr, Mu, Mf) so that d~ = Mf + px Mr + py Mu;
+// out[4] = pixel bounding box of the culling ellipse (jmin, jmax, imin, imax as int bits); out[5..6] = its conic.
+__device__ inline void make_record(const float* __restrict__ prm, int kind, const float* __restrict__ cam, int b, int H,
+                                   int W, float sigma, float4 out[R_REC]) {
     const Camera C = make_camera(cam + b * 3);
-    const float* prm = params + (size_t)bk * VPN_PARAM_STRIDE;
     float v[3] = {prm[0], prm[1], prm[2]};
     float t[3] = {prm[7], prm[8], prm[9]};
     Pose P = make_pose(prm[3], prm[4], prm[5], prm[6]);
     PrimGeo G;
     prim_geometry(C, P.R, v, t, G);
-    const int kind = kinds[k];
-    float4* out = rec + (size_t)bk * R_REC;
     out[0] = make_float4(G.o[0], G.o[1], G.o[2], __int_as_float(kind));
     out[1] = make_float4(G.Mr[0], G.Mr[1], G.Mr[2], 0.f);
     out[2] = make_float4(G.Mu[0], G.Mu[1], G.Mu[2], 0.f);
@@ -197,14 +192,15 @@ struct PixPrim {
     int sel, zi;
 };
 
+template <int KIND>   // compile-time kind: the caller branches once per primitive (wave-uniform), not once per pixel
 __device__ inline void eval_prim(const float4 r0, const float4 r1, const float4 r2, const float4 r3, float px,
                                  float py, float inv_sigma, float inv_gamma, float zref, PixPrim& q) {
     const float o[3] = {r0.x, r0.y, r0.z};
-    const int kind = __float_as_int(r0.w);
+    constexpr int kind = KIND;
     q.d[0] = r3.x + px * r1.x + py * r2.x;
     q.d[1] = r3.y + px * r1.y + py * r2.y;
     q.d[2] = r3.z + px * r1.z + py * r2.z;
-    if (kind == VPN_SPHERE) {
+    if constexpr (kind == VPN_SPHERE) {
         q.A = q.d[0] * q.d[0] + q.d[1] * q.d[1] + q.d[2] * q.d[2];
         q.Bq = o[0] * q.d[0] + o[1] * q.d[1] + o[2] * q.d[2];
         q.invA = R_RCP(q.A);
@@ -240,27 +236,30 @@ __device__ inline void eval_prim(const float4 r0, const float4 r1, const float4 
         q.dsafe = q.zi == 0 ? ds[0] : (q.zi == 1 ? ds[1] : ds[2]);
         q.m2 = q.lam * q.lam;
     }
-    float xr = (1.0f - q.m2) * inv_sigma;
-    q.xin = (xr >= -R_X_CLAMP) && (xr <= R_X_CLAMP);
-    float x = fminf(fmaxf(xr, -R_X_CLAMP), R_X_CLAMP);
-    float ex = R_EXP(-fabsf(x));
-    float dn = R_RCP(1.0f + ex);
-    float big = dn, small = ex * dn;
-    q.a = x >= 0.0f ? big : small;
-    q.c = x >= 0.0f ? small : big;
-    float er = (zref - q.z) * inv_gamma;
-    q.ein = (er >= -R_E_CLAMP) && (er <= R_E_CLAMP);
-    float e = fminf(fmaxf(er, -R_E_CLAMP), R_E_CLAMP);
+    // coverage a = sigmoid(x), c = 1 - a = sigmoid(-x): with x clamped to +-80 exp(-x) stays finite in fp32, so one
+    // exp and one rcp give both without a sign split (a = 1/(1+e), c = e a: no cancellation on either side).
+    // Slow-class instructions (v_cmp / v_cndmask / v_min / v_max / v_med3: 1.7x a v_fma on gfx950) are
+    // kept to a minimum here: one clamp and one compare per logit.
+    const float xr = (1.0f - q.m2) * inv_sigma;
+    q.xin = fabsf(xr) <= R_X_CLAMP;
+    const float x = __builtin_amdgcn_fmed3f(xr, -R_X_CLAMP, R_X_CLAMP);
+    const float en = R_EXP(-x);
+    q.a = R_RCP(1.0f + en);
+    q.c = en * q.a;
+    const float er = (zref - q.z) * inv_gamma;
+    q.ein = fabsf(er) <= R_E_CLAMP;
+    const float e = __builtin_amdgcn_fmed3f(er, -R_E_CLAMP, R_E_CLAMP);
     q.E = R_EXP(e);
     q.wgt = q.a * q.E;
 }
 
 // gradient of the loss w.r.t. the primitive's ray coefficients through one pixel:
 // go = dL/do~ (3), gd = dL/dd~ (3), given gz = dL/dz and gm2 = dL/dm2 of this pixel x primitive
+template <int KIND>
 __device__ inline void prim_backward(const float4 r0, const PixPrim& q, float gz, float gm2, float go[3],
                                      float gd[3]) {
     const float o[3] = {r0.x, r0.y, r0.z};
-    if (__float_as_int(r0.w) == VPN_SPHERE) {
+    if constexpr (KIND == VPN_SPHERE) {
         const float gchord = -gz;                       // z = s - chord, chord = sqrt(h * invA)
         // d chord/d u = (0.5/chord) invA dh/du with dh/du = h/r  ->  0.5 chord / r ;  u = 1 - m2
         gm2 -= gchord * 0.5f * q.chord * R_RCP(q.rr);
@@ -314,161 +313,190 @@ __device__ inline void prim_backward(const float4 r0, const PixPrim& q, float gz
     }
 }
 
-// stage the ray coefficients + pixel box of the image's K primitives into LDS
-__device__ inline void stage_records(const float4* __restrict__ rec_b, int K, float4* lds) {
-    for (int i = threadIdx.x; i < K * R_LREC; i += 64) {
-        const int k = i / R_LREC, f = i - k * R_LREC;
-        lds[i] = rec_b[k * R_REC + f];
-    }
-    __syncthreads();
-}
 
-// does primitive (pixel box bb, conic qa/qb) touch the 16x16 tile at (c0, r0)?  Pixel box first, then the exact
-// conic-vs-tile test.  NOT inlined on purpose: raster_bwd_kernel writes a partial for exactly the (primitive,
-// tile) pairs this returns true for and raster_bwd_finish_kernel reads exactly those, so both must run the very
-// same instructions (two inlined copies could be contracted into FMAs differently).
-__device__ __attribute__((noinline)) bool prim_hits_tile(const float4 bb, const float4* __restrict__ rec_k, int c0,
-                                                         int r0, int H, int W) {
+// ---------------------------------------------------------------------------------------------------------------
+// Binning: records + the visibility mask of every (tile, primitive) pair, computed ONCE per call and shared by the
+// forward, backward and finishing kernels (each of them used to repeat the conic-vs-tile test per wave).
+//   masks[(b * ntile + tile) * words + w] bit j  <=>  primitive 64 w + j may touch the 16x16 tile
+// (pixel box first, then the exact conic-vs-rectangle test: a primitive is dropped only where its coverage logit is
+// below -X_CUT on the whole tile).
+
+// does primitive (pixel box bb, conic qa/qb) touch the 16x16 tile at (c0, r0)?
+__device__ inline bool prim_hits_tile(const float4 bb, const float4 qa, const float4 qb, int c0, int r0, int H, int W) {
     const int jmin = __float_as_int(bb.x), jmax = __float_as_int(bb.y);
     const int imin = __float_as_int(bb.z), imax = __float_as_int(bb.w);
     bool vis = (jmin <= c0 + R_TW - 1) && (jmax >= c0) && (imin <= r0 + R_TH - 1) && (imax >= r0);
-    if (vis) {
-        const float4 qa = rec_k[5];
-        if (qa.w != 0.0f) {
-            const float4 qb = rec_k[6];
-            // tile rectangle in slope units, half a pixel of margin on every side
-            const float sx = 2.0f * (R_TAN_HALF_FOV * (float)W / (float)H) / (float)W, sy = 2.0f * R_TAN_HALF_FOV / (float)H;
-            const float x0 = ((float)c0 - 0.5f * (float)W) * sx, x1 = ((float)(c0 + R_TW) - 0.5f * (float)W) * sx;
-            const float y1 = (0.5f * (float)H - (float)r0) * sy, y0 = (0.5f * (float)H - (float)(r0 + R_TH)) * sy;
-            vis = conic_hits_rect(qa, qb, x0, x1, y0, y1);
-        }
+    if (vis && qa.w != 0.0f) {
+        // tile rectangle in slope units, half a pixel of margin on every side
+        const float sx = 2.0f * (R_TAN_HALF_FOV * (float)W / (float)H) / (float)W, sy = 2.0f * R_TAN_HALF_FOV / (float)H;
+        const float x0 = ((float)c0 - 0.5f * (float)W) * sx, x1 = ((float)(c0 + R_TW) - 0.5f * (float)W) * sx;
+        const float y1 = (0.5f * (float)H - (float)r0) * sy, y0 = (0.5f * (float)H - (float)(r0 + R_TH)) * sy;
+        vis = conic_hits_rect(qa, qb, x0, x1, y0, y1);
     }
     return vis;
 }
 
-// visibility mask of primitives [k0, k0+64) for this wave's 16x16 tile (one primitive per lane)
-__device__ inline unsigned long long tile_mask(const float4* lds, const float4* __restrict__ rec_b, int k0, int K,
-                                               int c0, int r0, int H, int W) {
-    const int lane = threadIdx.x & 63;
-    bool vis = false;
-    if (k0 + lane < K) vis = prim_hits_tile(lds[(k0 + lane) * R_LREC + 4], rec_b + (size_t)(k0 + lane) * R_REC, c0, r0, H, W);
-    return __ballot(vis);
+constexpr int R_BIN_TILES = 64;      // tiles per binning workgroup (4 waves x 16 tiles)
+
+// grid (ceil(ntile / 64), B), 256 threads, dynamic LDS = K * 3 float4.  Every workgroup of an image computes the K
+// records (the first one writes them), then its waves test their tiles, one primitive per lane, and ballot.
+__global__ __launch_bounds__(256) void raster_bin_kernel(const float* __restrict__ params,
+                                                         const int32_t* __restrict__ kinds,
+                                                         const float* __restrict__ cam, int K, int H, int W,
+                                                         float sigma, int tiles_x, int ntile, int words,
+                                                         float4* __restrict__ rec,
+                                                         unsigned long long* __restrict__ masks,
+                                                         int* __restrict__ zero_me) {
+    extern __shared__ __attribute__((aligned(16))) float4 cull[];   // [K][3]: pixel box, conic A, conic b
+    const int b = blockIdx.y;
+    if (zero_me && blockIdx.x == 0 && b == 0 && threadIdx.x < 4) zero_me[threadIdx.x] = 0;   // arrival counters of later kernels
+    for (int k = threadIdx.x; k < K; k += 256) {
+        float4 r[R_REC];
+        make_record(params + ((size_t)b * K + k) * VPN_PARAM_STRIDE, kinds[k] == VPN_SPHERE ? VPN_SPHERE : VPN_CUBOID, cam, b,
+                    H, W, sigma, r);
+        if (blockIdx.x == 0) {
+            float4* out = rec + ((size_t)b * K + k) * R_REC;
+#pragma unroll
+            for (int i = 0; i < R_REC; ++i) out[i] = r[i];
+        }
+        cull[k * R_CULL + 0] = r[4]; cull[k * R_CULL + 1] = r[5]; cull[k * R_CULL + 2] = r[6];
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int t0 = blockIdx.x * R_BIN_TILES + wave * (R_BIN_TILES / 4);
+    for (int w = 0; w < words; ++w) {
+        const int k = w * 64 + lane;
+        const bool live = k < K;
+        const float4 bb = cull[(live ? k : 0) * R_CULL], qa = cull[(live ? k : 0) * R_CULL + 1], qb = cull[(live ? k : 0) * R_CULL + 2];
+        // 4 tiles per iteration: the tests are independent, their latencies overlap (one wave per SIMD here)
+        for (int tb = t0; tb < t0 + R_BIN_TILES / 4; tb += 4) {
+            bool vis[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = min(tb + u, ntile - 1);
+                const int ty = t / tiles_x, tx = t - ty * tiles_x;
+                vis[u] = live && prim_hits_tile(bb, qa, qb, tx * R_TW, ty * R_TH, H, W);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned long long m = __ballot(vis[u]);
+                if (lane == 0 && tb + u < ntile) masks[((size_t)b * ntile + tb + u) * words + w] = m;
+            }
+        }
+    }
 }
 
-// Fused image losses (MODE 1 of the raster kernels): SilhouetteLoss (L1 / MSE mean against the GT
-// silhouette, modules/loss/silhouette.py:11,22) and an L1 depth loss are evaluated where the pixel is
-// produced, so alpha / depth and their gradients never travel through HBM.
+// ---------------------------------------------------------------------------------------------------------------
+// Tile kernels.  ONE WAVEFRONT (= one workgroup) PER 16x16 PIXEL TILE.  Lane l owns column l & 15 and rows (l >> 4) + 4 s, s = 0..3.  The visible primitives of the
+// tile come from the binning mask (wave-uniform: the loop is scalar control flow) and their ray coefficients are
+// read straight from the record array with wave-uniform addresses.
+
+struct Tile {
+    int b, tile, c0, r0, col, rbase;
+    float px, py[R_PPL];
+    bool valid;
+};
+
+// One wave (= one workgroup) per tile, 1-D grid of ntile * B workgroups: id = p * B + b with p running over the tiles
+// CENTRE FIRST (rows and columns in the order n/2, n/2 - 1, n/2 + 1, ...: a bijection of [0, n) for every n).  The
+// primitives crowd the image centre, a tile's cost is proportional to its primitive count (0 to ~10 at C3) and a
+// heavy tile started late runs on alone at the end of the launch: heavy-first order shortens that tail; one-wave
+// workgroups because a 4-wave workgroup holds its 4 slots until its slowest tile is done; id % 8 = b % 8 keeps every
+// XCD on whole images with the same mix of tiles (speed only: any order is correct).
+__device__ inline Tile make_tile(int H, int W, int tiles_x, int tiles_y, int B) {
+    Tile T;
+    const int lane = threadIdx.x & 63;
+    const int id = blockIdx.x;
+    const int pt = id / B;
+    T.b = id - pt * B;
+    const int iy = pt / tiles_x, ix = pt - iy * tiles_x;
+    auto co = [](int i, int n) { const int c = n >> 1, h = (i + 1) >> 1; return (i & 1) ? c - h : c + h; };
+    const int tx = co(ix, tiles_x), ty = co(iy, tiles_y);
+    T.valid = true;
+    T.tile = ty * tiles_x + tx;
+    T.c0 = tx * R_TW; T.r0 = ty * R_TH;
+    T.col = T.c0 + (lane & 15); T.rbase = T.r0 + (lane >> 4);
+    T.px = ((2.0f * ((float)T.col + 0.5f) / (float)W) - 1.0f) * (R_TAN_HALF_FOV * (float)W / (float)H);
+#pragma unroll
+    for (int s = 0; s < R_PPL; ++s)
+        T.py[s] = (1.0f - (2.0f * ((float)(T.rbase + 4 * s) + 0.5f) / (float)H)) * R_TAN_HALF_FOV;
+    return T;
+}
+
+// A VALU instruction with an SGPR source issues at 0.6x the rate of one with VGPR sources on gfx950 (1.77 vs 1.07 ns
+// per wave-instruction, tools/ubench/valu_rates2.hip), and every use of a ray coefficient would be one; a vector load
+// at the top of each primitive's iteration exposes its L1/L2 latency instead.  So each wave first copies the
+// records of its tile's visible primitives into a private LDS array (lane i of a mask word fetches primitive i if
+// its bit is set and stores it at slot = number of set bits below i), and the loops read them from LDS with
+// wave-uniform addresses (broadcast) into VGPRs.  `vzero()` is a zero the compiler cannot see through (keeps
+// uniform scalars of the pixel loops in VGPRs).
+__device__ inline int vzero() {
+    int z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    return z;
+}
+
+__device__ inline unsigned long long uniform64(unsigned long long v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+constexpr int R_SLOT = 4;            // float4 per staged primitive: (o~|kind, Mr|k, Mu, Mf)
+
+// stage the visible primitives of mask word w; returns their number.  srec: this wave's 64 x R_SLOT float4.
+__device__ inline int stage_word(const float4* __restrict__ rec_b, unsigned long long m, int w, int K, float4* srec) {
+    const int lane = threadIdx.x & 63;
+    if ((m >> lane) & 1ull) {
+        const int slot = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        const int k = w * 64 + lane;
+        const float4* rk = rec_b + (size_t)k * R_REC;
+        float4 a = rk[0], b = rk[1], c = rk[2], d = rk[3];
+        b.w = __int_as_float(k);
+        srec[slot * R_SLOT + 0] = a; srec[slot * R_SLOT + 1] = b; srec[slot * R_SLOT + 2] = c; srec[slot * R_SLOT + 3] = d;
+    }
+    __builtin_amdgcn_wave_barrier();
+    return __builtin_popcountll(m);
+}
+
+// Fused image losses: SilhouetteLoss (L1 / MSE mean against the GT silhouette, modules/loss/silhouette.py:11,22) and
+// an L1 depth loss are evaluated where the pixel is produced, so alpha / depth and their gradients never travel
+// through HBM.
 struct LossArgs {
     const float* gt_sil;      // [B,H,W] or null
     const float* gt_depth;    // [B,H,W] or null
     int sil_mse;              // 0: L1Loss, 1: MSELoss
     float inv_count;          // 1 / (B*H*W): both losses are means
     float* tile_loss;         // fwd out: [B*tiles][2] per-tile sums
-    const float* grad_loss;   // bwd in: [2] upstream gradients of the two scalar losses (device)
+    const float* grad_loss;   // bwd in: [2] upstream gradients of the two scalar losses (device); fused kernel: null
+    float w_sil, w_dep;       // fused kernel: weights of the two losses in the total
 };
 
 __device__ inline float sign0(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }   // torch.sign
 
-template <int MODE>   // 0: write alpha/depth images, 1: fused losses
-__global__ __launch_bounds__(64) void raster_fwd_kernel(const float4* __restrict__ rec, const float* __restrict__ cam,
-                                                        int K, int H, int W, float sigma, float gamma, float z_far,
-                                                        float* __restrict__ alpha, float* __restrict__ depth,
-                                                        float* __restrict__ aux, LossArgs la) {
-    extern __shared__ __attribute__((aligned(16))) float4 lds[];   // [K*5]: ray coefficients + pixel box
-    const int b = blockIdx.z;
-    stage_records(rec + (size_t)b * K * R_REC, K, lds);
-    const int lane = threadIdx.x;
-    const int c0 = blockIdx.x * R_TW, r0 = blockIdx.y * R_TH;
-    const int col = c0 + (lane & 15), rbase = r0 + (lane >> 4);
-    const float px = ((2.0f * ((float)col + 0.5f) / (float)W) - 1.0f) * (R_TAN_HALF_FOV * (float)W / (float)H);
-    float py[R_PPL];
-#pragma unroll
-    for (int s = 0; s < R_PPL; ++s)
-        py[s] = (1.0f - (2.0f * ((float)(rbase + 4 * s) + 0.5f) / (float)H)) * R_TAN_HALF_FOV;
-    const float inv_sigma = 1.0f / sigma, inv_gamma = 1.0f / gamma, zref = cam[b * 3];
-
-    float P[R_PPL], S0[R_PPL], S1[R_PPL];
+// forward composite of the tile's visible primitives: P = prod(1 - a), S0 = sum w, S1 = sum w z
+__device__ inline void tile_forward(const Tile& T, const float4* __restrict__ rec_b, const unsigned long long* __restrict__ mrow,
+                                    int words, int K, float4* srec, float inv_sigma, float inv_gamma, float zref,
+                                    float P[R_PPL], float S0[R_PPL], float S1[R_PPL]) {
 #pragma unroll
     for (int s = 0; s < R_PPL; ++s) { P[s] = 1.0f; S0[s] = 0.0f; S1[s] = 0.0f; }
-    for (int k0 = 0; k0 < K; k0 += 64) {
-        unsigned long long m = tile_mask(lds, rec + (size_t)b * K * R_REC, k0, K, c0, r0, H, W);
-        while (m) {
-            const int k = k0 + __builtin_ctzll(m);
-            m &= m - 1;
-            const float4 q0 = lds[k * R_LREC], q1 = lds[k * R_LREC + 1], q2 = lds[k * R_LREC + 2],
-                         q3 = lds[k * R_LREC + 3];
+    for (int w = 0; w < words; ++w) {
+        const int n = stage_word(rec_b, uniform64(mrow[w]), w, K, srec);
+        for (int j = 0; j < n; ++j) {
+            const float4 q0 = srec[j * R_SLOT], q1 = srec[j * R_SLOT + 1], q2 = srec[j * R_SLOT + 2], q3 = srec[j * R_SLOT + 3];
+            auto body = [&](auto kind_c) {
 #pragma unroll
-            for (int s = 0; s < R_PPL; ++s) {
-                PixPrim q;
-                eval_prim(q0, q1, q2, q3, px, py[s], inv_sigma, inv_gamma, zref, q);
-                P[s] *= q.c;
-                S0[s] += q.wgt;
-                S1[s] += q.wgt * q.z;
-            }
+                for (int s = 0; s < R_PPL; ++s) {
+                    PixPrim q;
+                    eval_prim<decltype(kind_c)::value>(q0, q1, q2, q3, T.px, T.py[s], inv_sigma, inv_gamma, zref, q);
+                    P[s] *= q.c;
+                    S0[s] += q.wgt;
+                    S1[s] += q.wgt * q.z;
+                }
+            };
+            if (__builtin_amdgcn_readfirstlane(__float_as_int(q0.w)) == VPN_SPHERE) body(std::integral_constant<int, VPN_SPHERE>{});
+            else body(std::integral_constant<int, VPN_CUBOID>{});
         }
-    }
-    const size_t hw = (size_t)H * W;
-    float lsil = 0.0f, ldep = 0.0f;
-#pragma unroll
-    for (int s = 0; s < R_PPL; ++s) {
-        const int row = rbase + 4 * s;
-        if (col < W && row < H) {
-            const float A = 1.0f - P[s];
-            const float S = S0[s] + R_DELTA_S0;
-            const float zbar = S1[s] * R_RCP(S);
-            const float D = z_far + A * (zbar - z_far);
-            const size_t pix = (size_t)row * W + col;
-            if (MODE == 0) {
-                alpha[b * hw + pix] = A;
-                depth[b * hw + pix] = D;
-            } else {
-                if (la.gt_sil) { const float e = A - la.gt_sil[b * hw + pix]; lsil += la.sil_mse ? e * e : fabsf(e); }
-                if (la.gt_depth) ldep += fabsf(D - la.gt_depth[b * hw + pix]);
-            }
-            aux[(b * 3 + 0) * hw + pix] = P[s];
-            aux[(b * 3 + 1) * hw + pix] = zbar;
-            aux[(b * 3 + 2) * hw + pix] = S;
-        }
-    }
-    if (MODE == 1) {
-        lsil = wave_sum(lsil);
-        ldep = wave_sum(ldep);
-        if (lane == 0) {
-            const int ntile = gridDim.x * gridDim.y, tile = blockIdx.y * gridDim.x + blockIdx.x;
-            la.tile_loss[((size_t)b * ntile + tile) * 2 + 0] = lsil;
-            la.tile_loss[((size_t)b * ntile + tile) * 2 + 1] = ldep;
-        }
-    }
-}
-
-// fixed-order sum of the per-tile loss partials -> the two mean losses (one workgroup of 1024 lanes,
-// float2 loads, 4 independent accumulators per lane so the loads pipeline)
-// optional: losses[2] = w_extra * mean(extra_loss_b[0..nb)) + w_sil * losses[0] + w_dep * losses[1]
-__global__ __launch_bounds__(1024) void raster_loss_reduce_kernel(const float2* __restrict__ tile_loss, int n,
-                                                                  float inv_count, float* __restrict__ losses,
-                                                                  const float* __restrict__ extra_loss_b, int nb,
-                                                                  float w_extra, float w_sil, float w_dep) {
-    __shared__ float red[2][16];
-    float a[4] = {0.f, 0.f, 0.f, 0.f}, c[4] = {0.f, 0.f, 0.f, 0.f};
-    int i = threadIdx.x;
-    for (; i + 3 * 1024 < n; i += 4 * 1024) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { const float2 v = tile_loss[i + u * 1024]; a[u] += v.x; c[u] += v.y; }
-    }
-    for (; i < n; i += 1024) { const float2 v = tile_loss[i]; a[0] += v.x; c[0] += v.y; }
-    float sa = wave_sum((a[0] + a[1]) + (a[2] + a[3])), sc = wave_sum((c[0] + c[1]) + (c[2] + c[3]));
-    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sa; red[1][threadIdx.x >> 6] = sc; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float ta = 0.f, tc = 0.f;
-        for (int w = 0; w < 16; ++w) { ta += red[0][w]; tc += red[1][w]; }
-        losses[0] = ta * inv_count;
-        losses[1] = tc * inv_count;
-        if (extra_loss_b) {
-            float e = 0.f;
-            for (int i = 0; i < nb; ++i) e += extra_loss_b[i];
-            losses[2] = w_extra * (e / (float)nb) + w_sil * losses[0] + w_dep * losses[1];
-        }
+        if (words > 1) __builtin_amdgcn_wave_barrier();      // the next word overwrites srec
     }
 }
 
@@ -510,111 +538,246 @@ __device__ inline float wave_reduce16(float v[16]) {
     return r;
 }
 
-template <int MODE>   // 0: incoming gradient images, 1: gradients of the fused losses computed in place
-__global__ __launch_bounds__(64) void raster_bwd_kernel(const float4* __restrict__ rec, const float* __restrict__ cam,
-                                                        int K, int H, int W, float sigma, float gamma, float z_far,
-                                                        const float* __restrict__ aux,
-                                                        const float* __restrict__ galpha,
-                                                        const float* __restrict__ gdepth,
-                                                        float* __restrict__ partial, LossArgs la) {
-    extern __shared__ __attribute__((aligned(16))) float4 lds[];   // [K*5]: ray coefficients + pixel box records
-    const int b = blockIdx.z;
-    stage_records(rec + (size_t)b * K * R_REC, K, lds);
-    const int lane = threadIdx.x;
-    const int c0 = blockIdx.x * R_TW, r0 = blockIdx.y * R_TH;
-    const int col = c0 + (lane & 15), rbase = r0 + (lane >> 4);
-    const float px = ((2.0f * ((float)col + 0.5f) / (float)W) - 1.0f) * (R_TAN_HALF_FOV * (float)W / (float)H);
-    const float inv_sigma = 1.0f / sigma, inv_gamma = 1.0f / gamma, zref = cam[b * 3];
-    const size_t hw = (size_t)H * W;
+// backward over the tile's visible primitives: per pixel x primitive analytic gradient w.r.t. the 12 ray
+// coefficients, summed over the lane's 4 pixels, reduced over the wave and written as 48 contiguous bytes of
+// partial[b][k][tile] -- only for the (primitive, tile) pairs of the binning mask; raster_bwd_finish_kernel reads
+// exactly those.  No atomics: bitwise reproducible.  `staged`: srec already holds the records of word 0 (one-pass
+// kernel with K <= 64).
+__device__ inline void tile_backward(const Tile& T, const float4* __restrict__ rec_b, const unsigned long long* __restrict__ mrow,
+                                     int words, int K, int ntile, float4* srec, bool staged, float inv_sigma,
+                                     float inv_gamma, float zref, const float P[R_PPL], const float zbar[R_PPL],
+                                     const float invS[R_PPL], const float gAtot[R_PPL], const float gZbar[R_PPL],
+                                     float* __restrict__ partial) {
+    const int lane = threadIdx.x & 63;
+    for (int w = 0; w < words; ++w) {
+        const unsigned long long m = uniform64(mrow[w]);
+        const int n = staged ? __builtin_popcountll(m) : stage_word(rec_b, m, w, K, srec);
+        for (int j = 0; j < n; ++j) {
+            const float4 q0 = srec[j * R_SLOT], q1 = srec[j * R_SLOT + 1], q2 = srec[j * R_SLOT + 2], q3 = srec[j * R_SLOT + 3];
+            const int k = __builtin_amdgcn_readfirstlane(__float_as_int(q1.w));
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = 0.0f;
+            auto body = [&](auto kind_c) {
+                constexpr int KIND = decltype(kind_c)::value;
+#pragma unroll
+                for (int s = 0; s < R_PPL; ++s) {
+                    PixPrim q;
+                    eval_prim<KIND>(q0, q1, q2, q3, T.px, T.py[s], inv_sigma, inv_gamma, zref, q);
+                    // composite backward
+                    const float gw = gZbar[s] * (q.z - zbar[s]) * invS[s];
+                    float gz = gZbar[s] * q.wgt * invS[s];
+                    if (q.ein) gz -= gw * q.wgt * inv_gamma;
+                    const float ga = gAtot[s] * (P[s] * R_RCP(q.c)) + gw * q.E;
+                    const float gx = q.xin ? ga * q.a * q.c : 0.0f;
+                    const float gm2 = -gx * inv_sigma;
+                    float go[3], gd[3];
+                    prim_backward<KIND>(q0, q, gz, gm2, go, gd);
+                    v[0] += go[0]; v[1] += go[1]; v[2] += go[2];
+                    v[3] += T.px * gd[0]; v[4] += T.px * gd[1]; v[5] += T.px * gd[2];
+                    v[6] += T.py[s] * gd[0]; v[7] += T.py[s] * gd[1]; v[8] += T.py[s] * gd[2];
+                    v[9] += gd[0]; v[10] += gd[1]; v[11] += gd[2];
+                }
+            };
+            if (__builtin_amdgcn_readfirstlane(__float_as_int(q0.w)) == VPN_SPHERE) body(std::integral_constant<int, VPN_SPHERE>{});
+            else body(std::integral_constant<int, VPN_CUBOID>{});
+            const float tot = wave_reduce16(v);
+            if ((lane & 3) == 0 && (lane >> 2) < 12)
+                partial[(((size_t)T.b * K + k) * ntile + T.tile) * 12 + (lane >> 2)] = tot;
+        }
+        if (words > 1) __builtin_amdgcn_wave_barrier();
+    }
+}
 
-    float py[R_PPL], gAtot[R_PPL], gZbar[R_PPL], P[R_PPL], zbar[R_PPL], invS[R_PPL];
+template <int MODE>   // 0: write alpha/depth images, 1: fused losses (per-tile sums)
+__global__ __launch_bounds__(64) void raster_fwd_kernel(const float4* __restrict__ rec,
+                                                         const unsigned long long* __restrict__ masks,
+                                                         const float* __restrict__ cam, int B, int K, int H, int W,
+                                                         int tiles_x, int tiles_y, int words, float sigma, float gamma,
+                                                         float z_far, float* __restrict__ alpha,
+                                                         float* __restrict__ depth, float* __restrict__ aux, LossArgs la) {
+    const Tile T = make_tile(H, W, tiles_x, tiles_y, B);
+    if (!T.valid) return;
+    const int ntile = tiles_x * tiles_y, lane = threadIdx.x & 63;
+    const float vz0 = __int_as_float(vzero());
+    const float inv_sigma = 1.0f / (sigma + vz0), inv_gamma = 1.0f / (gamma + vz0), zref = cam[T.b * 3] + vz0;
+    __shared__ __attribute__((aligned(16))) float4 srec[64 * R_SLOT];
+    float P[R_PPL], S0[R_PPL], S1[R_PPL];
+    tile_forward(T, rec + (size_t)T.b * K * R_REC, masks + ((size_t)T.b * ntile + T.tile) * words, words, K, srec, inv_sigma,
+                 inv_gamma, zref, P, S0, S1);
+    const size_t hw = (size_t)H * W;
+    float lsil = 0.0f, ldep = 0.0f;
 #pragma unroll
     for (int s = 0; s < R_PPL; ++s) {
-        const int row = rbase + 4 * s;
-        py[s] = (1.0f - (2.0f * ((float)row + 0.5f) / (float)H)) * R_TAN_HALF_FOV;
+        const int row = T.rbase + 4 * s;
+        if (T.col < W && row < H) {
+            const float A = 1.0f - P[s];
+            const float S = S0[s] + R_DELTA_S0;
+            const float zbar = S1[s] * R_RCP(S);
+            const float D = z_far + A * (zbar - z_far);
+            const size_t pix = (size_t)row * W + T.col;
+            if (MODE == 0) {
+                alpha[T.b * hw + pix] = A;
+                depth[T.b * hw + pix] = D;
+            } else {
+                if (la.gt_sil) { const float e = A - la.gt_sil[T.b * hw + pix]; lsil += la.sil_mse ? e * e : fabsf(e); }
+                if (la.gt_depth) ldep += fabsf(D - la.gt_depth[T.b * hw + pix]);
+            }
+            aux[(T.b * 3 + 0) * hw + pix] = P[s];
+            aux[(T.b * 3 + 1) * hw + pix] = zbar;
+            aux[(T.b * 3 + 2) * hw + pix] = S;
+        }
+    }
+    if (MODE == 1) {
+        lsil = wave_sum(lsil);
+        ldep = wave_sum(ldep);
+        if (lane == 0) {
+            la.tile_loss[((size_t)T.b * ntile + T.tile) * 2 + 0] = lsil;
+            la.tile_loss[((size_t)T.b * ntile + T.tile) * 2 + 1] = ldep;
+        }
+    }
+}
+
+template <int MODE>   // 0: incoming gradient images, 1: gradients of the fused losses computed in place
+__global__ __launch_bounds__(64, 4) void raster_bwd_kernel(const float4* __restrict__ rec,
+                                                         const unsigned long long* __restrict__ masks,
+                                                         const float* __restrict__ cam, int B, int K, int H, int W,
+                                                         int tiles_x, int tiles_y, int words, float sigma, float gamma,
+                                                         float z_far, const float* __restrict__ aux,
+                                                         const float* __restrict__ galpha,
+                                                         const float* __restrict__ gdepth,
+                                                         float* __restrict__ partial, LossArgs la) {
+    const Tile T = make_tile(H, W, tiles_x, tiles_y, B);
+    if (!T.valid) return;
+    const int ntile = tiles_x * tiles_y;
+    const unsigned long long* mrow = masks + ((size_t)T.b * ntile + T.tile) * words;
+    const float vz0 = __int_as_float(vzero());
+    const float inv_sigma = 1.0f / (sigma + vz0), inv_gamma = 1.0f / (gamma + vz0), zref = cam[T.b * 3] + vz0;
+    const size_t hw = (size_t)H * W;
+    float gAtot[R_PPL], gZbar[R_PPL], P[R_PPL], zbar[R_PPL], invS[R_PPL];
+#pragma unroll
+    for (int s = 0; s < R_PPL; ++s) {
+        const int row = T.rbase + 4 * s;
         gAtot[s] = 0.0f; gZbar[s] = 0.0f; P[s] = 1.0f; zbar[s] = 0.0f; invS[s] = 0.0f;
-        if (col < W && row < H) {
-            const size_t pix = (size_t)row * W + col;
-            P[s] = aux[(b * 3 + 0) * hw + pix];
-            zbar[s] = aux[(b * 3 + 1) * hw + pix];
-            invS[s] = R_RCP(aux[(b * 3 + 2) * hw + pix]);
+        if (T.col < W && row < H) {
+            const size_t pix = (size_t)row * W + T.col;
+            P[s] = aux[(T.b * 3 + 0) * hw + pix];
+            zbar[s] = aux[(T.b * 3 + 1) * hw + pix];
+            invS[s] = R_RCP(aux[(T.b * 3 + 2) * hw + pix]);
             float gA = 0.0f, gD = 0.0f;
             if (MODE == 0) {
-                gA = galpha ? galpha[b * hw + pix] : 0.0f;
-                gD = gdepth ? gdepth[b * hw + pix] : 0.0f;
+                gA = galpha ? galpha[T.b * hw + pix] : 0.0f;
+                gD = gdepth ? gdepth[T.b * hw + pix] : 0.0f;
             } else {
                 const float A = 1.0f - P[s];
                 if (la.gt_sil) {
-                    const float e = A - la.gt_sil[b * hw + pix];
+                    const float e = A - la.gt_sil[T.b * hw + pix];
                     gA = la.grad_loss[0] * la.inv_count * (la.sil_mse ? 2.0f * e : sign0(e));
                 }
                 if (la.gt_depth) {
                     const float D = z_far + A * (zbar[s] - z_far);
-                    gD = la.grad_loss[1] * la.inv_count * sign0(D - la.gt_depth[b * hw + pix]);
+                    gD = la.grad_loss[1] * la.inv_count * sign0(D - la.gt_depth[T.b * hw + pix]);
                 }
             }
             gAtot[s] = gA + gD * (zbar[s] - z_far);     // depth = z_far + A (zbar - z_far)
             gZbar[s] = gD * (1.0f - P[s]);
         }
     }
-
-    const int ntile = gridDim.x * gridDim.y, tile = blockIdx.y * gridDim.x + blockIdx.x;
-    for (int k0 = 0; k0 < K; k0 += 64) {
-        unsigned long long m = tile_mask(lds, rec + (size_t)b * K * R_REC, k0, K, c0, r0, H, W);
-        while (m) {
-            const int k = k0 + __builtin_ctzll(m);
-            m &= m - 1;
-            const float4 q0 = lds[k * R_LREC], q1 = lds[k * R_LREC + 1], q2 = lds[k * R_LREC + 2],
-                         q3 = lds[k * R_LREC + 3];
-            float v[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = 0.0f;
-#pragma unroll
-            for (int s = 0; s < R_PPL; ++s) {
-                PixPrim q;
-                eval_prim(q0, q1, q2, q3, px, py[s], inv_sigma, inv_gamma, zref, q);
-                // composite backward
-                const float gw = gZbar[s] * (q.z - zbar[s]) * invS[s];
-                float gz = gZbar[s] * q.wgt * invS[s];
-                if (q.ein) gz -= gw * q.wgt * inv_gamma;
-                const float ga = gAtot[s] * (P[s] * R_RCP(q.c)) + gw * q.E;
-                const float gx = q.xin ? ga * q.a * q.c : 0.0f;
-                const float gm2 = -gx * inv_sigma;
-                float go[3], gd[3];
-                prim_backward(q0, q, gz, gm2, go, gd);
-                v[0] += go[0]; v[1] += go[1]; v[2] += go[2];
-                v[3] += px * gd[0]; v[4] += px * gd[1]; v[5] += px * gd[2];
-                v[6] += py[s] * gd[0]; v[7] += py[s] * gd[1]; v[8] += py[s] * gd[2];
-                v[9] += gd[0]; v[10] += gd[1]; v[11] += gd[2];
-            }
-            const float tot = wave_reduce16(v);
-            // partial[b][k][tile][12]: 48 contiguous bytes per visible (primitive, tile); the others are never
-            // written and never read (raster_bwd_finish_kernel repeats the visibility test)
-            if ((lane & 3) == 0 && (lane >> 2) < 12)
-                partial[(((size_t)b * K + k) * ntile + tile) * 12 + (lane >> 2)] = tot;
-        }
-    }
+    __shared__ __attribute__((aligned(16))) float4 srec[64 * R_SLOT];
+    tile_backward(T, rec + (size_t)T.b * K * R_REC, mrow, words, K, ntile, srec, false, inv_sigma,
+                  inv_gamma, zref, P, zbar, invS, gAtot, gZbar, partial);
 }
 
-// one wave per (b,k): sum the per-tile partials in a fixed order, then chain rule to (v,q,t)
+// Forward AND backward of  total = w_sil * SilhouetteLoss + w_dep * L1(depth)  in one pass over the image (the
+// training step, train.py:243-262): the per-pixel state (P, zbar, 1/S) stays in registers between the composite and
+// the gradient pass, so the 12 bytes per pixel of `aux` are neither written nor read back, the GT images are read
+// once, and there is one launch (and one tail) instead of two.  The gradient partials are those of d total / d(ray
+// coefficients) for an upstream gradient of 1: d total is linear in it, raster_bwd_finish_kernel multiplies by the
+// actual upstream gradient when backward runs.
+__global__ __launch_bounds__(64, 4) void raster_total_kernel(const float4* __restrict__ rec,
+                                                           const unsigned long long* __restrict__ masks,
+                                                           const float* __restrict__ cam, int B, int K, int H, int W,
+                                                           int tiles_x, int tiles_y, int words, float sigma, float gamma,
+                                                           float z_far, float* __restrict__ partial, LossArgs la) {
+    const Tile T = make_tile(H, W, tiles_x, tiles_y, B);
+    if (!T.valid) return;
+    const int ntile = tiles_x * tiles_y, lane = threadIdx.x & 63;
+    const float4* rec_b = rec + (size_t)T.b * K * R_REC;
+    const unsigned long long* mrow = masks + ((size_t)T.b * ntile + T.tile) * words;
+    const float vz0 = __int_as_float(vzero());           // +0.0f in a VGPR: keeps the loop's uniform scalars out of SGPRs
+    const float inv_sigma = 1.0f / (sigma + vz0), inv_gamma = 1.0f / (gamma + vz0), zref = cam[T.b * 3] + vz0;
+    const size_t hw = (size_t)H * W;
+    // GT pixels first: their latency hides behind the composite
+    float gs[R_PPL], gd[R_PPL];
+#pragma unroll
+    for (int s = 0; s < R_PPL; ++s) {
+        const int row = T.rbase + 4 * s;
+        const bool in = T.col < W && row < H;
+        const size_t pix = in ? (size_t)row * W + T.col : 0;
+        gs[s] = (la.gt_sil && in) ? la.gt_sil[T.b * hw + pix] : 0.0f;
+        gd[s] = (la.gt_depth && in) ? la.gt_depth[T.b * hw + pix] : 0.0f;
+    }
+    __shared__ __attribute__((aligned(16))) float4 srec[64 * R_SLOT];
+    float P[R_PPL], S0[R_PPL], S1[R_PPL];
+    tile_forward(T, rec_b, mrow, words, K, srec, inv_sigma, inv_gamma, zref, P, S0, S1);
+    float gAtot[R_PPL], gZbar[R_PPL], zbar[R_PPL], invS[R_PPL];
+    float lsil = 0.0f, ldep = 0.0f;
+#pragma unroll
+    for (int s = 0; s < R_PPL; ++s) {
+        const int row = T.rbase + 4 * s;
+        gAtot[s] = 0.0f; gZbar[s] = 0.0f; zbar[s] = 0.0f; invS[s] = 0.0f;
+        if (T.col < W && row < H) {
+            const float A = 1.0f - P[s];
+            const float S = S0[s] + R_DELTA_S0;
+            invS[s] = R_RCP(S);
+            zbar[s] = S1[s] * invS[s];
+            const float D = z_far + A * (zbar[s] - z_far);
+            float gA = 0.0f, gD = 0.0f;
+            if (la.gt_sil) {
+                const float e = A - gs[s];
+                lsil += la.sil_mse ? e * e : fabsf(e);
+                gA = la.w_sil * la.inv_count * (la.sil_mse ? 2.0f * e : sign0(e));
+            }
+            if (la.gt_depth) {
+                const float e = D - gd[s];
+                ldep += fabsf(e);
+                gD = la.w_dep * la.inv_count * sign0(e);
+            }
+            gAtot[s] = gA + gD * (zbar[s] - z_far);
+            gZbar[s] = gD * A;
+        } else {
+            P[s] = 1.0f;
+        }
+    }
+    lsil = wave_sum(lsil);
+    ldep = wave_sum(ldep);
+    if (lane == 0) {
+        la.tile_loss[((size_t)T.b * ntile + T.tile) * 2 + 0] = lsil;
+        la.tile_loss[((size_t)T.b * ntile + T.tile) * 2 + 1] = ldep;
+    }
+    tile_backward(T, rec_b, mrow, words, K, ntile, srec, words == 1, inv_sigma, inv_gamma, zref, P, zbar, invS, gAtot, gZbar,
+                  partial);
+}
+
+// one wave per (b,k): sum the per-tile partials of the tiles whose mask holds k, in a fixed order, then chain rule
+// to (v,q,t).  `scale` (device scalar or null = 1): the upstream gradient of the fused total.
 __global__ __launch_bounds__(256) void raster_bwd_finish_kernel(const float* __restrict__ params,
                                                                 const float* __restrict__ cam, int BK, int K,
-                                                                int ntile, int tiles_x, int H, int W,
-                                                                const float4* __restrict__ rec,
+                                                                int ntile, int words,
+                                                                const unsigned long long* __restrict__ masks,
                                                                 const float* __restrict__ partial,
+                                                                const float* __restrict__ scale,
                                                                 float* __restrict__ gparams, int accumulate) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int bk = blockIdx.x * 4 + wave;
     if (bk >= BK) return;
-    const int b = bk / K;
-    const float4* rec_k = rec + (size_t)bk * R_REC;
-    const float4 bb = rec_k[4];
+    const int b = bk / K, k = bk - b * K;
     float v[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) v[i] = 0.0f;
     for (int tile = lane; tile < ntile; tile += 64) {
-        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-        if (!prim_hits_tile(bb, rec_k, tx * R_TW, ty * R_TH, H, W)) continue;      // nothing was written for this pair
+        const unsigned long long m = masks[((size_t)b * ntile + tile) * words + (k >> 6)];
+        if (!((m >> (k & 63)) & 1ull)) continue;                                   // nothing was written for this pair
         const float4* src = reinterpret_cast<const float4*>(partial + ((size_t)bk * ntile + tile) * 12);
         const float4 a = src[0], c = src[1], d = src[2];
         v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
@@ -627,6 +790,7 @@ __global__ __launch_bounds__(256) void raster_bwd_finish_kernel(const float* __r
 #pragma unroll
     for (int i = 0; i < 12; ++i) G[i] = __shfl(tot, i * 4, 64);
     if (lane != 0) return;
+    const float sc = scale ? *scale : 1.0f;
     const float* prm = params + (size_t)bk * VPN_PARAM_STRIDE;
     const Camera C = make_camera(cam + b * 3);
     const Pose P = make_pose(prm[3], prm[4], prm[5], prm[6]);
@@ -654,26 +818,109 @@ __global__ __launch_bounds__(256) void raster_bwd_finish_kernel(const float* __r
     float* o = gparams + (size_t)bk * VPN_PARAM_STRIDE;
     const float r[10] = {gv[0], gv[1], gv[2], gq[0], gq[1], gq[2], gq[3], gt[0], gt[1], gt[2]};
 #pragma unroll
-    for (int i = 0; i < 10; ++i) o[i] = accumulate ? o[i] + r[i] : r[i];   // accumulate: add to the sampler's gradient
+    for (int i = 0; i < 10; ++i) o[i] = accumulate ? o[i] + sc * r[i] : sc * r[i];   // accumulate: add to the sampler's gradient
 }
 
-static inline dim3 raster_grid(int B, int H, int W) { return dim3((W + R_TW - 1) / R_TW, (H + R_TH - 1) / R_TH, B); }
-static inline size_t fwd_lds(int K) { return (size_t)K * R_LREC * sizeof(float4); }
-static inline size_t bwd_lds(int K) { return (size_t)K * R_LREC * sizeof(float4); }
-
-// kernels may need more than the 64 KB default of dynamic LDS (K up to VPN_MAX_PRIMS)
-static int raise_lds_limit() {
-    static int done = 0;
-    if (done) return 0;
-    const void* fns[4] = {reinterpret_cast<const void*>(raster_fwd_kernel<0>), reinterpret_cast<const void*>(raster_fwd_kernel<1>),
-                          reinterpret_cast<const void*>(raster_bwd_kernel<0>), reinterpret_cast<const void*>(raster_bwd_kernel<1>)};
-    for (int i = 0; i < 4; ++i) {
-        hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)(i < 2 ? fwd_lds(VPN_MAX_PRIMS) : bwd_lds(VPN_MAX_PRIMS)));
-        if (e != hipSuccess) return (int)e;
+// ---------------------------------------------------------------------------------------------------------------
+// Loss finalisation: one workgroup per sample sums that sample's tile losses and (optionally) its Chamfer minima
+// (chamfer_distance.py:25-28) in a fixed order; the workgroup that arrives last sums the per-sample values in sample
+// order and writes
+//   losses[0] = silhouette loss, [1] = depth loss, [2] = w_cd * mean_b cd_b + w_sil * [0] + w_dep * [1], [3] = mean_b cd_b.
+// Which workgroup is last varies, what it computes does not: bitwise reproducible.  ws = {counter[4] | persample[B][4]}.
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ tile_loss, int ntile, int B,
+                                                            float inv_count, const float* __restrict__ d1,
+                                                            const float* __restrict__ d2, int N, int M, float w1,
+                                                            float w2, float w_cd, float w_sil, float w_dep,
+                                                            int* __restrict__ counter, float4* __restrict__ persample,
+                                                            float* __restrict__ losses, float* __restrict__ loss_b) {
+    __shared__ float red[4][4];
+    __shared__ int is_last;
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (tile_loss) {
+        const float2* tl = reinterpret_cast<const float2*>(tile_loss) + (size_t)b * ntile;
+        for (int t = threadIdx.x; t < ntile; t += 256) { const float2 v = tl[t]; acc[0] += v.x; acc[1] += v.y; }
     }
-    done = 1;
-    return 0;
+    if (d1) {
+        // fixed order: thread t owns elements t, t + 256, ... (float4 groups where the row is 16-byte aligned); the
+        // loads of a batch of 8 are issued together, then summed
+        auto row_sum = [&](const float* __restrict__ a, int n) -> float {
+            float s = 0.f;
+            if ((n & 3) == 0) {
+                const float4* a4 = reinterpret_cast<const float4*>(a);
+                const int n4 = n >> 2;
+                for (int i = threadIdx.x; i < n4; i += 8 * 256) {
+                    float4 v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = (i + u * 256 < n4) ? a4[i + u * 256] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) s += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+                }
+            } else {
+                for (int i = threadIdx.x; i < n; i += 256) s += a[i];
+            }
+            return s;
+        };
+        acc[2] = row_sum(d1 + (size_t)b * N, N);
+        acc[3] = row_sum(d2 + (size_t)b * M, M);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float s = wave_sum(acc[i]);
+        if (lane == 0) red[wave][i] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s[i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+        const float cd = d1 ? w1 * (s[2] / (float)N) + w2 * (s[3] / (float)M) : 0.0f;
+        if (loss_b) loss_b[b] = cd;
+        float* ps = reinterpret_cast<float*>(persample + b);
+        __hip_atomic_store(ps + 0, s[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // sc1 stores: past L2's dirty lines
+        __hip_atomic_store(ps + 1, s[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ps + 2, cd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int old = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = old == B - 1;
+        if (is_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if (!is_last) return;
+    float t[3] = {0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < B; i += 256) {
+        const float* ps = reinterpret_cast<const float*>(persample + i);
+        t[0] += __hip_atomic_load(ps + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t[1] += __hip_atomic_load(ps + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t[2] += __hip_atomic_load(ps + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();                         // red is reused
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float s = wave_sum(t[i]);
+        if (lane == 0) red[wave][i] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) s[i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+        const float l0 = s[0] * inv_count, l1 = s[1] * inv_count, cd = s[2] / (float)B;
+        losses[0] = l0; losses[1] = l1;
+        losses[2] = w_cd * cd + w_sil * l0 + w_dep * l1;
+        losses[3] = cd;
+        __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next call
+    }
+}
+
+struct Grid { dim3 g; int tiles_x, tiles_y, ntile, words; };
+static inline Grid raster_grid(int B, int K, int H, int W) {
+    Grid G;
+    G.tiles_x = (W + R_TW - 1) / R_TW; G.tiles_y = (H + R_TH - 1) / R_TH;
+    G.ntile = G.tiles_x * G.tiles_y; G.words = (K + 63) / 64;
+    G.g = dim3((unsigned)G.ntile * (unsigned)B);
+    return G;
 }
 
 }  // namespace vpn
@@ -688,9 +935,28 @@ static int raster_check(const void* params, const void* kinds, const void* cam, 
     return 0;
 }
 
-extern "C" size_t vpn_raster_records_size(int B, int K) {
-    if (B <= 0 || K <= 0) return 0;
-    return (size_t)B * K * R_REC * sizeof(float4);
+// records = [B*K][7] float4, then the tile masks [B*ntile][words] uint64
+static inline size_t rec_bytes(int B, int K) { return (size_t)B * K * R_REC * sizeof(float4); }
+extern "C" size_t vpn_raster_records_size(int B, int K, int H, int W) {
+    if (B <= 0 || K <= 0 || H <= 0 || W <= 0) return 0;
+    const Grid G = raster_grid(B, K, H, W);
+    return rec_bytes(B, K) + (size_t)B * G.ntile * G.words * sizeof(unsigned long long);
+}
+static inline unsigned long long* masks_of(void* records, int B, int K) {
+    return reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(records) + rec_bytes(B, K));
+}
+static inline const unsigned long long* masks_of(const void* records, int B, int K) {
+    return reinterpret_cast<const unsigned long long*>(reinterpret_cast<const char*>(records) + rec_bytes(B, K));
+}
+
+static int launch_bin(const float* params, const int32_t* kinds, const float* cam, int B, int K, int H, int W,
+                      float sigma, void* records, int* zero_me, hipStream_t s) {
+    const Grid G = raster_grid(B, K, H, W);
+    const size_t lds = (size_t)K * R_CULL * sizeof(float4);         // <= 48 KB at VPN_MAX_PRIMS
+    VPN_LAUNCH(raster_bin_kernel, dim3((G.ntile + R_BIN_TILES - 1) / R_BIN_TILES, B), dim3(256), lds, s, params, kinds, cam,
+               K, H, W, sigma, G.tiles_x, G.ntile, G.words, (float4*)records, masks_of(records, B, K), zero_me);
+    VPN_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int vpn_raster_fwd(const float* params, const int32_t* kinds, const float* cam, int B, int K, int H,
@@ -700,54 +966,68 @@ extern "C" int vpn_raster_fwd(const float* params, const int32_t* kinds, const f
     if (rc) return rc;
     if (!alpha || !depth || !aux || !records) return VPN_E_BADARG;
     if (((uintptr_t)records & 15) != 0) return VPN_E_BADARG;
-    const int BK = B * K;
-    VPN_LAUNCH(raster_prep_kernel, dim3((BK + 255) / 256), dim3(256), 0, (hipStream_t)stream, params, kinds,
-                       cam, BK, K, H, W, sigma, (float4*)records);
-    VPN_LAUNCH_CHECK();
-    size_t lds = fwd_lds(K);
-    if (lds > 65536 && (rc = raise_lds_limit())) return rc;
-    VPN_LAUNCH(raster_fwd_kernel<0>, raster_grid(B, H, W), dim3(64), lds, (hipStream_t)stream,
-                       (const float4*)records, cam, K, H, W, sigma, gamma, z_far, alpha, depth, aux, LossArgs{});
+    if ((rc = launch_bin(params, kinds, cam, B, K, H, W, sigma, records, nullptr, (hipStream_t)stream))) return rc;
+    const Grid G = raster_grid(B, K, H, W);
+    VPN_LAUNCH(raster_fwd_kernel<0>, G.g, dim3(64), 0, (hipStream_t)stream, (const float4*)records,
+               masks_of((const void*)records, B, K), cam, B, K, H, W, G.tiles_x, G.tiles_y, G.words, sigma, gamma, z_far, alpha,
+               depth, aux, LossArgs{});
     VPN_LAUNCH_CHECK();
     return 0;
 }
 
+// loss workspace = {arrival counter (16 B) | per-sample sums [B] float4 | per-tile sums [B*ntile] float2}
+static inline size_t loss_head_bytes(int B) { return 16 + (size_t)B * sizeof(float4); }
 extern "C" size_t vpn_raster_loss_workspace(int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0) return 0;
-    dim3 g = raster_grid(B, H, W);
-    return (size_t)B * g.x * g.y * 2 * sizeof(float);
+    const Grid G = raster_grid(B, 1, H, W);
+    return loss_head_bytes(B) + (size_t)B * G.ntile * 2 * sizeof(float);
+}
+static inline float* tile_loss_of(void* ws, int B) { return reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + loss_head_bytes(B)); }
+
+static int launch_finalize(void* loss_ws, bool with_tiles, int B, int H, int W, const float* d1, const float* d2, int N,
+                           int M, float w1, float w2, float w_cd, float w_sil, float w_dep, float* losses, float* loss_b,
+                           hipStream_t s) {
+    const Grid G = raster_grid(B, 1, H > 0 ? H : 1, W > 0 ? W : 1);
+    const float inv_count = with_tiles ? 1.0f / ((float)B * (float)H * (float)W) : 0.0f;
+    VPN_LAUNCH(loss_finalize_kernel, dim3(B), dim3(256), 0, s, with_tiles ? (const float*)tile_loss_of(loss_ws, B) : nullptr,
+               G.ntile, B, inv_count, d1, d2, N, M, w1, w2, w_cd, w_sil, w_dep, (int*)loss_ws,
+               reinterpret_cast<float4*>(reinterpret_cast<char*>(loss_ws) + 16), losses, loss_b);
+    VPN_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int vpn_raster_loss_fwd(const float* params, const int32_t* kinds, const float* cam, int B, int K, int H,
                                    int W, float sigma, float gamma, float z_far, const float* gt_sil,
                                    const float* gt_depth, int sil_mse, float* aux, void* records, void* loss_ws,
-                                   float* losses, const float* extra_loss_b, int nb, float w_extra, float w_sil,
-                                   float w_dep, void* stream) {
+                                   float* losses, void* stream) {
     int rc = raster_check(params, kinds, cam, B, K, H, W, sigma, gamma);
     if (rc) return rc;
     if (!aux || !records || !loss_ws || !losses) return VPN_E_BADARG;
-    if (((uintptr_t)records & 15) != 0) return VPN_E_BADARG;
-    const int BK = B * K;
-    VPN_LAUNCH(raster_prep_kernel, dim3((BK + 255) / 256), dim3(256), 0, (hipStream_t)stream, params, kinds,
-                       cam, BK, K, H, W, sigma, (float4*)records);
+    if (((uintptr_t)records & 15) != 0 || ((uintptr_t)loss_ws & 15) != 0) return VPN_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    if ((rc = launch_bin(params, kinds, cam, B, K, H, W, sigma, records, (int*)loss_ws, s))) return rc;
+    const Grid G = raster_grid(B, K, H, W);
+    LossArgs la{gt_sil, gt_depth, sil_mse, 1.0f / ((float)B * (float)H * (float)W), tile_loss_of(loss_ws, B), nullptr, 0.f, 0.f};
+    VPN_LAUNCH(raster_fwd_kernel<1>, G.g, dim3(64), 0, s, (const float4*)records, masks_of((const void*)records, B, K), cam, B, K,
+               H, W, G.tiles_x, G.tiles_y, G.words, sigma, gamma, z_far, (float*)nullptr, (float*)nullptr, aux, la);
     VPN_LAUNCH_CHECK();
-    size_t lds = fwd_lds(K);
-    if (lds > 65536 && (rc = raise_lds_limit())) return rc;
-    dim3 g = raster_grid(B, H, W);
-    LossArgs la{gt_sil, gt_depth, sil_mse, 1.0f / ((float)B * (float)H * (float)W), (float*)loss_ws, nullptr};
-    VPN_LAUNCH(raster_fwd_kernel<1>, g, dim3(64), lds, (hipStream_t)stream, (const float4*)records, cam, K, H,
-                       W, sigma, gamma, z_far, (float*)nullptr, (float*)nullptr, aux, la);
-    VPN_LAUNCH_CHECK();
-    VPN_LAUNCH(raster_loss_reduce_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float2*)loss_ws,
-                       (int)(B * g.x * g.y), la.inv_count, losses, extra_loss_b, nb, w_extra, w_sil, w_dep);
-    VPN_LAUNCH_CHECK();
-    return 0;
+    return launch_finalize(loss_ws, true, B, H, W, nullptr, nullptr, 0, 0, 0.f, 0.f, 0.f, 1.0f, 1.0f, losses, nullptr, s);
 }
 
 extern "C" size_t vpn_raster_bwd_workspace(int B, int K, int H, int W) {
     if (B <= 0 || K <= 0 || H <= 0 || W <= 0) return 0;
-    dim3 g = raster_grid(B, H, W);
-    return (size_t)B * g.x * g.y * K * 12 * sizeof(float);
+    const Grid G = raster_grid(B, K, H, W);
+    return (size_t)B * G.ntile * K * 12 * sizeof(float);
+}
+
+static int launch_finish(const float* params, const float* cam, int B, int K, int H, int W, const void* records,
+                         const void* workspace, const float* scale, float* grad_params, int accumulate, hipStream_t s) {
+    const Grid G = raster_grid(B, K, H, W);
+    const int BK = B * K;
+    VPN_LAUNCH(raster_bwd_finish_kernel, dim3((BK + 3) / 4), dim3(256), 0, s, params, cam, BK, K, G.ntile, G.words,
+               masks_of(records, B, K), (const float*)workspace, scale, grad_params, accumulate);
+    VPN_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int vpn_raster_bwd(const float* params, const int32_t* kinds, const float* cam, int B, int K, int H,
@@ -758,17 +1038,12 @@ extern "C" int vpn_raster_bwd(const float* params, const int32_t* kinds, const f
     if (rc) return rc;
     if (!aux || !records || !workspace || !grad_params) return VPN_E_BADARG;
     if (((uintptr_t)records & 15) != 0 || ((uintptr_t)workspace & 15) != 0) return VPN_E_BADARG;
-    dim3 g = raster_grid(B, H, W);
-    size_t lds = bwd_lds(K);
-    if (lds > 65536 && (rc = raise_lds_limit())) return rc;
-    VPN_LAUNCH(raster_bwd_kernel<0>, g, dim3(64), lds, (hipStream_t)stream, (const float4*)records, cam, K, H,
-                       W, sigma, gamma, z_far, aux, grad_alpha, grad_depth, (float*)workspace, LossArgs{});
+    const Grid G = raster_grid(B, K, H, W);
+    VPN_LAUNCH(raster_bwd_kernel<0>, G.g, dim3(64), 0, (hipStream_t)stream, (const float4*)records, masks_of(records, B, K),
+               cam, B, K, H, W, G.tiles_x, G.tiles_y, G.words, sigma, gamma, z_far, aux, grad_alpha, grad_depth,
+               (float*)workspace, LossArgs{});
     VPN_LAUNCH_CHECK();
-    const int BK = B * K;
-    VPN_LAUNCH(raster_bwd_finish_kernel, dim3((BK + 3) / 4), dim3(256), 0, (hipStream_t)stream, params, cam,
-                       BK, K, (int)(g.x * g.y), (int)g.x, H, W, (const float4*)records, (const float*)workspace, grad_params, 0);
-    VPN_LAUNCH_CHECK();
-    return 0;
+    return launch_finish(params, cam, B, K, H, W, records, workspace, nullptr, grad_params, 0, (hipStream_t)stream);
 }
 
 extern "C" int vpn_raster_loss_bwd(const float* params, const int32_t* kinds, const float* cam, int B, int K, int H,
@@ -779,35 +1054,50 @@ extern "C" int vpn_raster_loss_bwd(const float* params, const int32_t* kinds, co
     if (rc) return rc;
     if (!aux || !records || !grad_losses || !workspace || !grad_params) return VPN_E_BADARG;
     if (((uintptr_t)records & 15) != 0 || ((uintptr_t)workspace & 15) != 0) return VPN_E_BADARG;
-    dim3 g = raster_grid(B, H, W);
-    size_t lds = bwd_lds(K);
-    if (lds > 65536 && (rc = raise_lds_limit())) return rc;
-    LossArgs la{gt_sil, gt_depth, sil_mse, 1.0f / ((float)B * (float)H * (float)W), nullptr, grad_losses};
-    VPN_LAUNCH(raster_bwd_kernel<1>, g, dim3(64), lds, (hipStream_t)stream, (const float4*)records, cam, K, H,
-                       W, sigma, gamma, z_far, aux, (const float*)nullptr, (const float*)nullptr, (float*)workspace, la);
+    const Grid G = raster_grid(B, K, H, W);
+    LossArgs la{gt_sil, gt_depth, sil_mse, 1.0f / ((float)B * (float)H * (float)W), nullptr, grad_losses, 0.f, 0.f};
+    VPN_LAUNCH(raster_bwd_kernel<1>, G.g, dim3(64), 0, (hipStream_t)stream, (const float4*)records, masks_of(records, B, K),
+               cam, B, K, H, W, G.tiles_x, G.tiles_y, G.words, sigma, gamma, z_far, aux, (const float*)nullptr,
+               (const float*)nullptr, (float*)workspace, la);
     VPN_LAUNCH_CHECK();
-    const int BK = B * K;
-    VPN_LAUNCH(raster_bwd_finish_kernel, dim3((BK + 3) / 4), dim3(256), 0, (hipStream_t)stream, params, cam,
-                       BK, K, (int)(g.x * g.y), (int)g.x, H, W, (const float4*)records, (const float*)workspace, grad_params,
-                       accumulate);
+    return launch_finish(params, cam, B, K, H, W, records, workspace, nullptr, grad_params, accumulate, (hipStream_t)stream);
+}
+
+extern "C" int vpn_raster_total_fwd(const float* params, const int32_t* kinds, const float* cam, int B, int K, int H,
+                                    int W, float sigma, float gamma, float z_far, const float* gt_sil,
+                                    const float* gt_depth, int sil_mse, float w_sil, float w_dep, void* records,
+                                    void* loss_ws, void* workspace, void* stream) {
+    int rc = raster_check(params, kinds, cam, B, K, H, W, sigma, gamma);
+    if (rc) return rc;
+    if (!records || !loss_ws || !workspace) return VPN_E_BADARG;
+    if (((uintptr_t)records & 15) != 0 || ((uintptr_t)workspace & 15) != 0 || ((uintptr_t)loss_ws & 15) != 0) return VPN_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    if ((rc = launch_bin(params, kinds, cam, B, K, H, W, sigma, records, (int*)loss_ws, s))) return rc;
+    const Grid G = raster_grid(B, K, H, W);
+    LossArgs la{gt_sil, gt_depth, sil_mse, 1.0f / ((float)B * (float)H * (float)W), tile_loss_of(loss_ws, B), nullptr, w_sil, w_dep};
+    VPN_LAUNCH(raster_total_kernel, G.g, dim3(64), 0, s, (const float4*)records, masks_of((const void*)records, B, K), cam, B, K,
+               H, W, G.tiles_x, G.tiles_y, G.words, sigma, gamma, z_far, (float*)workspace, la);
     VPN_LAUNCH_CHECK();
     return 0;
 }
 
-// losses[2] = w_extra * mean(loss_b) + w_sil * losses[0] + w_dep * losses[1]  (weighted sum of train.py:243-262)
-__global__ void total_loss_kernel(const float* __restrict__ loss_b, int nb, float w_extra, float w_sil, float w_dep,
-                                  float* __restrict__ losses) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        float e = 0.f;
-        for (int i = 0; i < nb; ++i) e += loss_b[i];
-        losses[2] = w_extra * (e / (float)nb) + w_sil * losses[0] + w_dep * losses[1];
-    }
+extern "C" int vpn_loss_finalize(void* loss_ws, int B, int H, int W, const float* dist1, const float* dist2, int N, int M,
+                                 float cd_w1, float cd_w2, float w_cd, float w_sil, float w_dep, float* losses,
+                                 float* loss_b, void* stream) {
+    if (!loss_ws || !losses || B <= 0) return VPN_E_BADARG;
+    if (((uintptr_t)loss_ws & 15) != 0) return VPN_E_BADARG;
+    if ((dist1 == nullptr) != (dist2 == nullptr)) return VPN_E_BADARG;
+    if (dist1 && (N <= 0 || M <= 0)) return VPN_E_BADARG;
+    if (B > 65535) return VPN_E_TOOBIG;
+    return launch_finalize(loss_ws, H > 0 && W > 0, B, H, W, dist1, dist2, N, M, cd_w1, cd_w2, w_cd, w_sil, w_dep, losses, loss_b,
+                           (hipStream_t)stream);
 }
 
-extern "C" int vpn_total_loss(const float* loss_b, int nb, float w_extra, float w_sil, float w_dep, float* losses,
-                              void* stream) {
-    if (!loss_b || !losses || nb <= 0) return VPN_E_BADARG;
-    VPN_LAUNCH(total_loss_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, loss_b, nb, w_extra, w_sil, w_dep, losses);
-    VPN_LAUNCH_CHECK();
-    return 0;
+extern "C" int vpn_raster_total_bwd(const float* params, const float* cam, int B, int K, int H, int W,
+                                    const void* records, const void* workspace, const float* grad_total,
+                                    float* grad_params, int accumulate, void* stream) {
+    if (!params || !cam || !records || !workspace || !grad_params) return VPN_E_BADARG;
+    if (B <= 0 || K <= 0 || H <= 0 || W <= 0) return VPN_E_BADARG;
+    if (K > VPN_MAX_PRIMS || B > 65535) return VPN_E_TOOBIG;
+    return launch_finish(params, cam, B, K, H, W, records, workspace, grad_total, grad_params, accumulate, (hipStream_t)stream);
 }

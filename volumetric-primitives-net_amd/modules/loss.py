@@ -4,7 +4,7 @@ import torch
 import torch.nn as nn
 
 from .. import config
-from ..ops import ChamferFunction, EmdFunction, RasterLossFunction
+from ..ops import ChamferFunction, EmdFunction, RasterTotalFunction
 from ..primitives import PrimitivePack
 from .render import VertexRenderer
 
@@ -74,7 +74,9 @@ class SilhouetteLoss(nn.Module):
         dev = predict_meshes.params.device
         cam = torch.stack([dists.to(dev).float().reshape(-1).expand(B), elevs.to(dev).float().reshape(-1).expand(B),
                            azims.to(dev).float().reshape(-1).expand(B)], 1)
-        # render + loss fused (silhouette.py:16-22 renders, concatenates and applies L1Loss/MSELoss)
-        losses = RasterLossFunction.apply(predict_meshes.params, predict_meshes.kinds, cam, gt_silhouettes, None, H, W,
-                                          VertexRenderer.sigma, VertexRenderer.gamma, VertexRenderer.z_far, self.is_mse)
-        return losses[0]
+        # render + loss + gradient partials in one pass (silhouette.py:16-22 renders B times, concatenates and applies
+        # L1Loss/MSELoss); with w_sil = 1, w_dep = 0 the differentiable total IS the silhouette loss
+        losses = RasterTotalFunction.apply(predict_meshes.params, predict_meshes.kinds, cam, gt_silhouettes, None, H, W,
+                                           VertexRenderer.sigma, VertexRenderer.gamma, VertexRenderer.z_far, self.is_mse,
+                                           1.0, 0.0)
+        return losses[2]

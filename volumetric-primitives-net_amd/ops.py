@@ -332,7 +332,7 @@ class RasterFunction(Function):
         alpha = torch.empty((B, H, W), dtype=torch.float32, device=dev)
         depth = torch.empty((B, H, W), dtype=torch.float32, device=dev)
         aux = torch.empty((B, 3, H, W), dtype=torch.float32, device=dev)
-        rec = torch.empty((_lib.lib().vpn_raster_records_size(B, K) // 4,), dtype=torch.float32, device=dev)
+        rec = torch.empty((_lib.lib().vpn_raster_records_size(B, K, H, W) // 4,), dtype=torch.float32, device=dev)
         _lib.call('vpn_raster_fwd', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(cam), B, K, H, W,
                   float(sigma), float(gamma), float(z_far), _lib.ptr(alpha), _lib.ptr(depth), _lib.ptr(aux),
                   _lib.ptr(rec), _lib.stream())
@@ -372,12 +372,12 @@ class RasterLossFunction(Function):
         dev = params.device
         L = _lib.lib()
         aux = torch.empty((B, 3, H, W), dtype=torch.float32, device=dev)
-        rec = torch.empty((L.vpn_raster_records_size(B, K) // 4,), dtype=torch.float32, device=dev)
+        rec = torch.empty((L.vpn_raster_records_size(B, K, H, W) // 4,), dtype=torch.float32, device=dev)
         lws = torch.empty((L.vpn_raster_loss_workspace(B, H, W) // 4,), dtype=torch.float32, device=dev)
-        losses = torch.empty((3,), dtype=torch.float32, device=dev)
+        losses = torch.empty((4,), dtype=torch.float32, device=dev)
         _lib.call('vpn_raster_loss_fwd', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(cam), B, K, H, W, float(sigma),
                   float(gamma), float(z_far), _lib.ptr(gt_sil), _lib.ptr(gt_depth), int(bool(sil_mse)), _lib.ptr(aux),
-                  _lib.ptr(rec), _lib.ptr(lws), _lib.ptr(losses), None, 0, 0.0, 0.0, 0.0, _lib.stream())
+                  _lib.ptr(rec), _lib.ptr(lws), _lib.ptr(losses), _lib.stream())
         losses = losses[:2]
         empty = torch.empty(0, device=dev)
         ctx.save_for_backward(params, kinds, cam, aux, rec, gt_sil if gt_sil is not None else empty,
@@ -401,6 +401,49 @@ class RasterLossFunction(Function):
         return (grad_params,) + (None,) * 10
 
 
+class RasterTotalFunction(Function):
+    """total_img = w_sil * SilhouetteLoss + w_dep * L1(depth), forward and backward in one pass over the image
+    (vpn_raster_total_fwd: no aux tensor, GT read once, the gradient partials are produced by the forward launch;
+    backward is the small finishing kernel).  Returns (silhouette loss, depth loss, total_img); only the total is
+    differentiable."""
+
+    @staticmethod
+    def forward(ctx, params, kinds, cam, gt_sil, gt_depth, H, W, sigma, gamma, z_far, sil_mse, w_sil, w_dep):
+        params, cam = _f32c(params), _f32c(cam)
+        B, K, S = params.shape
+        kinds = kinds_tensor(kinds, params.device)
+        assert S == PARAM_STRIDE and kinds.numel() == K and cam.shape == (B, 3)
+        gt_sil = _f32c(gt_sil).reshape(B, H, W) if gt_sil is not None else None
+        gt_depth = _f32c(gt_depth).reshape(B, H, W) if gt_depth is not None else None
+        dev = params.device
+        L = _lib.lib()
+        s = _lib.stream()
+        rec = torch.empty((L.vpn_raster_records_size(B, K, H, W) // 4,), dtype=torch.float32, device=dev)
+        lws = torch.empty((L.vpn_raster_loss_workspace(B, H, W) // 4,), dtype=torch.float32, device=dev)
+        ws = torch.empty((L.vpn_raster_bwd_workspace(B, K, H, W) // 4,), dtype=torch.float32, device=dev)
+        losses = torch.empty((4,), dtype=torch.float32, device=dev)
+        _lib.call('vpn_raster_total_fwd', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(cam), B, K, H, W, float(sigma),
+                  float(gamma), float(z_far), _lib.ptr(gt_sil), _lib.ptr(gt_depth), int(bool(sil_mse)), float(w_sil),
+                  float(w_dep), _lib.ptr(rec), _lib.ptr(lws), _lib.ptr(ws), s)
+        _lib.call('vpn_loss_finalize', _lib.ptr(lws), B, H, W, None, None, 0, 0, 0.0, 0.0, 0.0, float(w_sil), float(w_dep),
+                  _lib.ptr(losses), None, s)
+        ctx.save_for_backward(params, cam, rec, ws)
+        ctx.meta = (B, K, H, W)
+        sil, dep, tot, _ = losses.unbind(0)
+        ctx.mark_non_differentiable(sil, dep)
+        return sil, dep, tot
+
+    @staticmethod
+    def backward(ctx, _g_sil, _g_dep, grad_total):
+        params, cam, rec, ws = ctx.saved_tensors
+        B, K, H, W = ctx.meta
+        g = _f32c(grad_total).reshape(1)
+        grad_params = torch.empty_like(params)
+        _lib.call('vpn_raster_total_bwd', _lib.ptr(params), _lib.ptr(cam), B, K, H, W, _lib.ptr(rec), _lib.ptr(ws),
+                  _lib.ptr(g), _lib.ptr(grad_params), 0, _lib.stream())
+        return (grad_params,) + (None,) * 12
+
+
 _PATTERNS = {}
 FUSED_BWD_MAX_GT = 15360      # vpn_sample_chamfer_bwd keeps per-wave match lists of the GT points in LDS (include/vpn_hip.h)
 _SIDE = {}
@@ -415,13 +458,12 @@ def _side_stream(dev):
     return _SIDE[key]
 
 
-
-def _grad_pattern(B, w_cd, w_sil, w_depth, dev):
-    """d total / d(loss_b[0..B), sil, depth): constant per configuration, cached on the device (created
-    outside any graph capture by the first eager call)."""
-    key = (B, float(w_cd), float(w_sil), float(w_depth), str(dev))
+def _grad_pattern(B, w_cd, dev):
+    """d total / d loss_b[0..B): constant per configuration, cached on the device (created outside any graph capture
+    by the first eager call)."""
+    key = (B, float(w_cd), str(dev))
     if key not in _PATTERNS:
-        _PATTERNS[key] = torch.tensor([w_cd / B] * B + [w_sil, w_depth], dtype=torch.float32, device=dev)
+        _PATTERNS[key] = torch.full((B,), w_cd / B, dtype=torch.float32, device=dev)
     return _PATTERNS[key]
 
 
@@ -429,11 +471,12 @@ class HotPathLossFunction(Function):
     """One training-step loss of the reference's hot path in a single autograd node (train.py:243-262):
         total = w_cd * ChamferDistanceLoss(sample(params), gt_points; cd_w1, cd_w2) + w_sil * SilhouetteLoss
                 + w_depth * L1(depth)
-    Forward: sampler -> Chamfer scans -> per-sample loss -> raster with fused image losses (which also
-    assembles the total).  Backward: Chamfer backward -> sampler backward (writes d/dparams) -> raster
-    backward (adds to it).  No intermediate ever goes through an ATen kernel.  Returns three scalars
-    (silhouette loss, depth loss, total); only the total is differentiable (the first two are reported values:
-    they are marked non-differentiable, so `out[0].backward()` raises instead of returning a wrong gradient).
+    Forward: sampler -> Chamfer scans; binning -> raster forward+backward pass (image losses and their gradient
+    partials in one launch) -> loss finalisation (per-sample Chamfer losses, image losses, total).  Backward:
+    Chamfer + sampler backward (writes d/dparams) -> raster finishing kernel (adds to it).  No intermediate ever goes
+    through an ATen kernel.  Returns three scalars (silhouette loss, depth loss, total); only the total is
+    differentiable (the first two are reported values: they are marked non-differentiable, so `out[0].backward()`
+    raises instead of returning a wrong gradient).
     `seed`: int, or a device int64 tensor of one element read by the kernels (see _seed_args).
     cd_w1 / cd_w2 = config.CD_W1 / CD_W2 (chamfer_distance.py:10), sil_mse = SILHOUETTE_LOSS_FUNC != 'L1'."""
 
@@ -453,21 +496,27 @@ class HotPathLossFunction(Function):
         cd_w1, cd_w2, sil_mse = float(cd_w1), float(cd_w2), int(bool(sil_mse))
         gt_sil = _f32c(gt_sil).reshape(B, H, W) if gt_sil is not None else None
         gt_depth = _f32c(gt_depth).reshape(B, H, W) if gt_depth is not None else None
-        aux = torch.empty((B, 3, H, W), dtype=torch.float32, device=dev)
-        rec = torch.empty((L.vpn_raster_records_size(B, K) // 4,), dtype=torch.float32, device=dev)
+        rec = torch.empty((L.vpn_raster_records_size(B, K, H, W) // 4,), dtype=torch.float32, device=dev)
         lws = torch.empty((L.vpn_raster_loss_workspace(B, H, W) // 4,), dtype=torch.float32, device=dev)
-        losses = torch.empty((3,), dtype=torch.float32, device=dev)
+        rws = torch.empty((L.vpn_raster_bwd_workspace(B, K, H, W) // 4,), dtype=torch.float32, device=dev)
+        losses = torch.empty((4,), dtype=torch.float32, device=dev)
+
+        def raster_branch(stream):
+            _lib.call('vpn_raster_total_fwd', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(cam), B, K, H, W, float(sigma),
+                      float(gamma), float(z_far), _lib.ptr(gt_sil), _lib.ptr(gt_depth), sil_mse, float(w_sil),
+                      float(w_depth), _lib.ptr(rec), _lib.ptr(lws), _lib.ptr(rws), stream)
+
         main = torch.cuda.current_stream()
-        # optionally the raster branch (independent of the sampler + Chamfer branch until the total) runs on a side
-        # stream; fork / join is captured into HIP graphs as such
+        # optionally the raster branch (independent of the sampler + Chamfer branch until the finalisation) runs on a
+        # side stream; fork / join is captured into HIP graphs as such
         side = _side_stream(dev) if CONCURRENT_BRANCHES else None
         if side is not None:
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                _lib.call('vpn_raster_loss_fwd', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(cam), B, K, H, W,
-                          float(sigma), float(gamma), float(z_far), _lib.ptr(gt_sil), _lib.ptr(gt_depth), sil_mse,
-                          _lib.ptr(aux), _lib.ptr(rec), _lib.ptr(lws), _lib.ptr(losses), None, 0, 0.0, 0.0, 0.0,
-                          _lib.stream())
+                raster_branch(_lib.stream())
+                for t in (params, kinds, cam, gt_sil, gt_depth, rec, lws, rws):
+                    if t is not None:
+                        t.record_stream(side)
         points = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
         _lib.call('vpn_sample_fwd', _lib.ptr(params), _lib.ptr(kinds), None, seed_host, seed_dev, int(sample_base), B, K,
                   n, _lib.ptr(points), s)
@@ -478,54 +527,30 @@ class HotPathLossFunction(Function):
         cws = torch.empty((L.vpn_chamfer_workspace(B, N, M) // 4,), dtype=torch.float32, device=dev)
         _lib.call('vpn_chamfer_fwd_ws', _lib.ptr(points), _lib.ptr(gt_points), B, N, M, _lib.ptr(d1), _lib.ptr(i1),
                   _lib.ptr(d2), _lib.ptr(i2), _lib.ptr(cws), cws.numel() * 4, 0, s)
-        loss_b = torch.empty((B,), dtype=torch.float32, device=dev)
-        _lib.call('vpn_chamfer_loss', _lib.ptr(d1), _lib.ptr(d2), B, N, M, cd_w1, cd_w2, _lib.ptr(loss_b), s)
         if side is not None:
             main.wait_stream(side)
-            _lib.call('vpn_total_loss', _lib.ptr(loss_b), B, float(w_cd), float(w_sil), float(w_depth),
-                      _lib.ptr(losses), s)
         else:
-            _lib.call('vpn_raster_loss_fwd', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(cam), B, K, H, W,
-                      float(sigma), float(gamma), float(z_far), _lib.ptr(gt_sil), _lib.ptr(gt_depth), sil_mse,
-                      _lib.ptr(aux), _lib.ptr(rec), _lib.ptr(lws), _lib.ptr(losses), _lib.ptr(loss_b), B, float(w_cd),
-                      float(w_sil), float(w_depth), s)
-        pattern = _grad_pattern(B, w_cd, w_sil, w_depth, dev)
+            raster_branch(s)
+        _lib.call('vpn_loss_finalize', _lib.ptr(lws), B, H, W, _lib.ptr(d1), _lib.ptr(d2), N, M, cd_w1, cd_w2, float(w_cd),
+                  float(w_sil), float(w_depth), _lib.ptr(losses), None, s)
+        pattern = _grad_pattern(B, w_cd, dev)
         empty = torch.empty(0, device=dev)
         seed_t = seed if isinstance(seed, torch.Tensor) else empty
-        ctx.save_for_backward(params, kinds, cam, gt_points, points, d1, i1, d2, i2, aux, rec,
-                              gt_sil if gt_sil is not None else empty, gt_depth if gt_depth is not None else empty,
-                              pattern, seed_t)
-        ctx.meta = (B, K, n, M, H, W, seed_host, seed_dev is not None, int(sample_base), float(sigma), float(gamma),
-                    float(z_far), gt_sil is not None, gt_depth is not None, cd_w1, cd_w2, sil_mse)
-        sil, dep, tot = losses.unbind(0)
+        ctx.save_for_backward(params, kinds, cam, gt_points, points, d1, i1, d2, i2, rec, rws, pattern, seed_t)
+        ctx.meta = (B, K, n, M, H, W, seed_host, seed_dev is not None, int(sample_base), cd_w1, cd_w2)
+        sil, dep, tot, _ = losses.unbind(0)
         ctx.mark_non_differentiable(sil, dep)
         return sil, dep, tot
 
     @staticmethod
     def backward(ctx, _g_sil, _g_dep, grad_total):
-        (params, kinds, cam, gt_points, points, d1, i1, d2, i2, aux, rec, gt_sil, gt_depth, pattern,
-         seed_t) = ctx.saved_tensors
-        (B, K, n, M, H, W, seed, has_seed_dev, base, sigma, gamma, z_far, has_sil, has_depth, cd_w1, cd_w2,
-         sil_mse) = ctx.meta
+        (params, kinds, cam, gt_points, points, d1, i1, d2, i2, rec, rws, pattern, seed_t) = ctx.saved_tensors
+        B, K, n, M, H, W, seed, has_seed_dev, base, cd_w1, cd_w2 = ctx.meta
         N = K * n
         s = _lib.stream()
         seed_dev = _lib.ptr(seed_t) if has_seed_dev else None
-        gvec = (pattern * grad_total).contiguous()              # one small kernel: [B] for Chamfer, [2] for the raster
-        g2 = ctypes.c_void_p(gvec.data_ptr() + 4 * B)           # the last two entries: (sil, depth) gradients
-        ws = torch.empty((_lib.lib().vpn_raster_bwd_workspace(B, K, H, W) // 4,), dtype=torch.float32,
-                         device=params.device)
-        main = torch.cuda.current_stream()
-        side = _side_stream(params.device) if CONCURRENT_BRANCHES else None
-        grad_raster = None
-        if side is not None:
-            grad_raster = torch.empty_like(params)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                _lib.call('vpn_raster_loss_bwd', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(cam), B, K, H, W, sigma,
-                          gamma, z_far, _lib.ptr(aux), _lib.ptr(rec), _lib.ptr(gt_sil) if has_sil else None,
-                          _lib.ptr(gt_depth) if has_depth else None, sil_mse, g2, _lib.ptr(ws), _lib.ptr(grad_raster), 0,
-                          _lib.stream())
-                gvec.record_stream(side)
+        grad_total = _f32c(grad_total).reshape(1)
+        gvec = pattern * grad_total                             # one small kernel: d total / d loss_b [B]
         # Chamfer backward and sampler backward in one launch: the [B,N,3] point gradient never exists
         grad_params = torch.empty_like(params)
         if M <= FUSED_BWD_MAX_GT:
@@ -538,11 +563,7 @@ class HotPathLossFunction(Function):
                       _lib.ptr(i2), _lib.ptr(gvec), B, N, M, cd_w1, cd_w2, _lib.ptr(grad_points), None, s)
             _lib.call('vpn_sample_bwd', _lib.ptr(params), _lib.ptr(kinds), None, seed, seed_dev, base, B, K, n,
                       _lib.ptr(grad_points), _lib.ptr(grad_params), s)
-        if side is not None:
-            main.wait_stream(side)
-            grad_params += grad_raster
-        else:
-            _lib.call('vpn_raster_loss_bwd', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(cam), B, K, H, W, sigma,
-                      gamma, z_far, _lib.ptr(aux), _lib.ptr(rec), _lib.ptr(gt_sil) if has_sil else None,
-                      _lib.ptr(gt_depth) if has_depth else None, sil_mse, g2, _lib.ptr(ws), _lib.ptr(grad_params), 1, s)
+        # the raster's gradient partials were produced by the forward launch: chain rule x upstream gradient, added
+        _lib.call('vpn_raster_total_bwd', _lib.ptr(params), _lib.ptr(cam), B, K, H, W, _lib.ptr(rec), _lib.ptr(rws),
+                  _lib.ptr(grad_total), _lib.ptr(grad_params), 1, s)
         return (grad_params,) + (None,) * 19
