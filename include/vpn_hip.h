@@ -213,6 +213,16 @@ int vpn_loss_finalize(void* loss_ws, int B, int H, int W, const float* dist1, co
 int vpn_raster_total_bwd(const float* params, const float* cam, int B, int K, int H, int W,
                          const void* records, const void* workspace, const float* grad_total,
                          float* grad_params, int accumulate, void* stream);
+/* Backward of the whole training step in ONE launch: vpn_sample_chamfer_bwd and vpn_raster_total_bwd together
+ * (both are one workgroup per (sample, primitive)):
+ *   grad_params = d(Chamfer term)/d params [as vpn_sample_chamfer_bwd] + (*grad_total) * d(total_img)/d params. */
+int vpn_hotpath_bwd(const float* params, const int32_t* kinds, const float* u,
+                    uint64_t seed, const uint64_t* seed_dev, uint64_t sample_base, int B, int K, int n,
+                    const float* points, const float* gt_points, int M,
+                    const float* dist1, const int32_t* idx1, const float* dist2, const int32_t* idx2,
+                    const float* grad_loss_b, float w1, float w2,
+                    const float* cam, int H, int W, const void* records, const void* workspace,
+                    const float* grad_total, float* grad_params, void* stream);
 
 /* ---- fused camera transforms (row f3): view_to_obj_points / obj_to_view_points
  * (modules/transform/transform.py:21-47, :50-73; called on train.py:158 every step).

@@ -1,24 +1,25 @@
+"""Chamfer scan at the C3 workload: per-kernel times (library launch profiler), undecided counts."""
 import sys, torch
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import vpn_amd
+from vpn_amd import _lib
 from bench import synth_inputs
 dev = torch.device('cuda')
 B, K, n, M = 64, 32, 256, 2048
 params, gt = synth_inputs(B, K, M, 1234, dev)
 kinds = vpn_amd.kinds_tensor([0] * K, dev)
 pts = vpn_amd.Sampling.sample_primitives(params, kinds, n, seed=1234)
-for mode in sys.argv[1:]:
+for mode in (sys.argv[1:] or ['mfma']):
     for _ in range(3): vpn_amd.chamfer_nn(pts, gt, mode=mode)
-    torch.cuda.synchronize()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(20): vpn_amd.chamfer_nn(pts, gt, mode=mode)
-    b.record(); torch.cuda.synchronize()
-    print('%-8s both directions: %.1f us' % (mode, a.elapsed_time(b) * 1e3 / 20))
-
+    with _lib.KernelProfile() as kp:
+        for _ in range(20): vpn_amd.chamfer_nn(pts, gt, mode=mode)
+    r = {k: round(v[1] * 1e3, 1) for k, v in kp.summary().items()}
+    print('%-8s %s  sum %.1f us' % (mode, r, sum(r.values())))
+d1, i1, d2, i2 = vpn_amd.chamfer_nn(pts, gt, mode='mfma')
+e1, j1, e2, j2 = vpn_amd.chamfer_nn(pts, gt, mode='brute')
+print('mfma == brute:', bool(torch.equal(d1, e1) and torch.equal(i1, j1) and torch.equal(d2, e2) and torch.equal(i2, j2)))
 # how many queries the filter leaves to the fix-up kernel (counter at the head of each direction's list)
-from vpn_amd import _lib
 N = pts.shape[1]
 ws = torch.empty((_lib.lib().vpn_chamfer_workspace(B, N, M) // 4,), dtype=torch.float32, device=dev)
 d1 = torch.empty(B, N, device=dev); d2 = torch.empty(B, M, device=dev)
@@ -29,9 +30,10 @@ torch.cuda.synchronize()
 pad = lambda n: (n + 63) & ~63
 p4 = lambda n: (n + 3) & ~3
 wi = ws.view(torch.int32)
-off1 = B * 16 * pad(M) + 3072 + B * 16                # direction 1: targets p2 (M), queries p1 (N)
+SLOTS = 32
+off1 = B * 16 * pad(M) + 3072 + B * SLOTS                # direction 1: targets p2 (M), queries p1 (N)
 size1 = off1 + p4(B) + 4 * B * N + B * pad(M) + B * (pad(M) // 32) * 8   # + permutation + block boxes
-off2 = size1 + B * 16 * pad(N) + 3072 + B * 16
-c1, c2 = wi[off1:off1 + B], wi[off2:off2 + B]
-print('undecided: direction 1 %d of %d (max %d per sample), direction 2 %d of %d (max %d per sample)'
-      % (int(c1.sum()), B * N, int(c1.max()), int(c2.sum()), B * M, int(c2.max())))
+off2 = size1 + B * 16 * pad(N) + 3072 + B * SLOTS
+c1, c2 = wi[off1:off1 + B].cpu(), wi[off2:off2 + B].cpu()
+print('undecided dir1 (8192 queries/sample): total %d max %d | dir2 (2048 queries/sample): total %d max %d' % (int(c1.sum()), int(c1.max()), int(c2.sum()), int(c2.max())))
+print('dir2 per sample:', sorted(c2.tolist())[-10:], 'dir1:', sorted(c1.tolist())[-10:])

@@ -672,7 +672,13 @@ __device__ inline void write_row(unsigned short* H, size_t row, float x, float y
 }
 
 constexpr int CFEAT_THREADS = 256;
-constexpr int CFEAT_SLOTS = 16;                    // workgroups per cloud and sample, at most
+#ifndef CFEAT_SLOTS_N
+#define CFEAT_SLOTS_N 32
+#endif
+#ifndef CFEAT_WGPTS
+#define CFEAT_WGPTS 256             // points per feature workgroup (1024: r1; 256: 4x the workgroups, the kernel is latency-bound)
+#endif
+constexpr int CFEAT_SLOTS = CFEAT_SLOTS_N;         // workgroups per cloud and sample, at most
 constexpr int CFEAT_PTS = 4;                       // points per lane in flight
 
 struct FeatJob {          // one cloud: slices [0, ysplit) of a sample's workgroups belong to it
@@ -746,7 +752,10 @@ __global__ __launch_bounds__(CFEAT_THREADS) void chamfer_feat_kernel(const FeatJ
 constexpr int CF_THREADS = 256;
 constexpr int CF_Q = 4;
 constexpr int CF_UNROLL = 4;
-constexpr int CF_GROUPS = 16;                      // workgroups per sample
+#ifndef CF_GROUPS_N
+#define CF_GROUPS_N 16
+#endif
+constexpr int CF_GROUPS = CF_GROUPS_N;             // workgroups per sample
 
 // list layout: count[B] then entries[B][Nq] (query numbers of sample b)
 struct FixJob {           // one direction of a Chamfer call
@@ -915,6 +924,18 @@ __device__ inline float min16(const f16v& v) {
     // v[15] is read by an asm instruction, but one that also consumes d and e: it cannot issue before they have
     const float g = vmin3(d, e, v[15]);
     return vmin3(vmin3(a, b, c), g, g);
+}
+
+// Filter error of the targets that can still WIN OR TIE once the exact minimum m2 of the best block is known: such a
+// target b has exact d2(a, b) <= m2 (1 + 1e-6), hence |b| <= |a| + sqrt(m2) (triangle inequality): its error bound
+// needs the query's norm and m2 only, not the largest norm of the cloud -- for a query near the centre of the cloud
+// the band shrinks ~2x and with it the number of undecided queries.  (Rigour: DESIGN.md 4.1; the factors 1 + 2e-6
+// cover the fp32 rounding of the two square roots and of the sum.)
+__device__ inline float near_error(float eps, float na, float m2, float E_cloud) {
+    const float rb = (sqrtf(na) + sqrtf(m2)) * (1.0f + 2.0e-6f);
+    const float nbn = rb * rb;
+    const float En = eps * (2.0f * sqrtf(na * nbn) + nbn + na) * (1.0f + 1.0e-6f);
+    return fminf(En, E_cloud);
 }
 
 struct ScanJob {          // one direction of a Chamfer call
@@ -1176,8 +1197,9 @@ __global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_kernel(const ScanJob
     // m2 is exact, so the runner-up is compared with it rather than with the filtered value of the best block:
     // only the runner-up's own filter error E remains (the band was 2E before; this halves the undecided queries).
     // 4e-6 m2 covers the rounding of m2 and of |a|^2 and the width of a sqrt bucket.
-    const float band = E + 4.0e-6f * (m2 + na);
-    const bool ambiguous = !(V2 > (m2 - na) + band) || !(m2 - na <= Bv + band);
+    const float band = E + 4.0e-6f * (m2 + na);                     // any target of the cloud (consistency of the best block)
+    const float band_near = near_error(PREC == 1 ? CM_EPS_BF16 : CM_EPS, na, m2, E) + 4.0e-6f * (m2 + na);   // possible winners
+    const bool ambiguous = !(V2 > (m2 - na) + band_near) || !(m2 - na <= Bv + band);
     const float s = sqrtf(m2);
     // lowest index attaining the minimum; a different d2 can only share the sqrt if it lies within a few ulp
     // of it, which is rare: only then are the sqrt values compared
@@ -1502,7 +1524,8 @@ __global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_pruned_kernel(
     }
     m2 = fminf(m2, __shfl_xor(m2, 32, 64));
     const float band = E + 4.0e-6f * (m2 + na);
-    const bool ambiguous = !(V2 > (m2 - na) + band) || !(m2 - na <= Bv + band);
+    const float band_near = near_error(CM_EPS_BF16, na, m2, E) + 4.0e-6f * (m2 + na);
+    const bool ambiguous = !(V2 > (m2 - na) + band_near) || !(m2 - na <= Bv + band);
     const float s = sqrtf(m2);
     const float lim = m2 * (1.0f + 1.0e-6f);
     int idx = 0x7fffffff;
@@ -1556,7 +1579,7 @@ static int mfma_both(const float* p1, const float* p2, int B, int N, int M, floa
                      int32_t* i2, bool fp32_filter, hipStream_t s) {
     const MfmaWs w2 = mfma_carve(ws, B, M, N);                            // p2 = targets of direction 1
     const MfmaWs w1 = mfma_carve(ws + mfma_ws_floats(B, M, N), B, N, M);  // p1 = targets of direction 2
-    auto split = [](int Ntp) { const int y = (Ntp + 1023) / 1024; return y > CFEAT_SLOTS ? CFEAT_SLOTS : y; };
+    auto split = [](int Ntp) { const int y = (Ntp + CFEAT_WGPTS - 1) / CFEAT_WGPTS; return y > CFEAT_SLOTS ? CFEAT_SLOTS : y; };
     const FeatJob f2{p2, M, w2.Ntp, split(w2.Ntp), w2.F, w2.nmax, fp32_filter ? nullptr : w2.H, w2.undecided};
     const FeatJob f1{p1, N, w1.Ntp, split(w1.Ntp), w1.F, w1.nmax, fp32_filter ? nullptr : w1.H, w1.undecided};
     VPN_LAUNCH(chamfer_feat_kernel, dim3(B * (f2.ysplit + f1.ysplit)), dim3(CFEAT_THREADS), 0, s, f2, f1, B);

@@ -29,7 +29,7 @@
 //     gradient: bitwise reproducible;
 //   * loss_finalize_kernel: per-sample sums of the tile losses (and of the Chamfer minima) and the batch
 //     totals by the last-arriving workgroup, in a fixed order.
-#include "vpn_common.h"
+#include "vpn_raster_common.h"
 #include <type_traits>
 
 #define R_EXP(x) __expf(x)   // v_exp_f32 based; the raster is a 1e-4 contract
@@ -38,124 +38,6 @@
 #define R_RCP(x) __builtin_amdgcn_rcpf(x)
 
 namespace vpn {
-
-constexpr float R_TAN_HALF_FOV = 0.4571428511950223f;   // tan(49.13434207744484 deg / 2): kaolin v0.1 default fov
-constexpr float R_X_CLAMP = 80.0f;
-constexpr float R_E_CLAMP = 8.0f;
-constexpr float R_EPS_H = 1e-3f;     // squareplus smoothing of relu(1 - m2) under the chord sqrt
-constexpr float R_DELTA_S0 = 1e-12f;
-constexpr float R_EPS_D = 1e-9f;
-constexpr float R_X_CUT = 16.0f;     // primitives whose coverage logit is below -X_CUT on a tile are skipped: coverage < 1.2e-7
-constexpr int R_TW = 16, R_TH = 16;  // pixel tile per wave
-constexpr int R_PPL = 4;             // pixels per lane (row groups of 4 rows)
-constexpr int R_REC = 7;             // float4 per primitive record in HBM
-constexpr int R_CULL = 3;            // float4 per primitive staged in LDS by the binning kernel (pixel box + conic)
-
-struct Camera {
-    float eye[3], right[3], up[3], fwd[3];
-    float dist;
-};
-
-// look-at camera of vertex_renderer.py:18 (set_look_at_parameters([azim],[elev],[dist]), degrees)
-__device__ inline Camera make_camera(const float* cam) {
-    Camera C;
-    const float d = cam[0];
-    const float el = cam[1] * 0.017453292519943295f, az = cam[2] * 0.017453292519943295f;
-    float ce = cosf(el), se = sinf(el), ca = cosf(az), sa = sinf(az);
-    C.eye[0] = d * ce * ca; C.eye[1] = d * se; C.eye[2] = d * ce * sa;
-    float inv = 1.0f / sqrtf(C.eye[0] * C.eye[0] + C.eye[1] * C.eye[1] + C.eye[2] * C.eye[2]);
-    float zx = C.eye[0] * inv, zy = C.eye[1] * inv, zz = C.eye[2] * inv;
-    // right = normalize((0,1,0) x zax) ; up = zax x right
-    float rx = zz, ry = 0.0f, rz = -zx;
-    float rinv = 1.0f / sqrtf(rx * rx + rz * rz);
-    rx *= rinv; rz *= rinv;
-    C.right[0] = rx; C.right[1] = ry; C.right[2] = rz;
-    C.up[0] = zy * rz - zz * ry; C.up[1] = zz * rx - zx * rz; C.up[2] = zx * ry - zy * rx;
-    C.fwd[0] = -zx; C.fwd[1] = -zy; C.fwd[2] = -zz;
-    C.dist = d;
-    return C;
-}
-
-struct PrimGeo {   // per-primitive quantities that do not depend on the pixel
-    float o[3], Mr[3], Mu[3], Mf[3];
-};
-
-__device__ inline void prim_geometry(const Camera& C, const Mat3& R, const float* v, const float* t, PrimGeo& G) {
-    float e[3] = {C.eye[0] - t[0], C.eye[1] - t[1], C.eye[2] - t[2]};
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        float iv = 1.0f / v[a];
-        G.o[a] = (R.m[0][a] * e[0] + R.m[1][a] * e[1] + R.m[2][a] * e[2]) * iv;
-        G.Mr[a] = (R.m[0][a] * C.right[0] + R.m[1][a] * C.right[1] + R.m[2][a] * C.right[2]) * iv;
-        G.Mu[a] = (R.m[0][a] * C.up[0] + R.m[1][a] * C.up[1] + R.m[2][a] * C.up[2]) * iv;
-        G.Mf[a] = (R.m[0][a] * C.fwd[0] + R.m[1][a] * C.fwd[1] + R.m[2][a] * C.fwd[2]) * iv;
-    }
-}
-
-// Record of one primitive for one camera: out[0..3] = (o~|kind, Mr, Mu, Mf) so that d~ = Mf + px Mr + py Mu;
-// out[4] = pixel bounding box of the culling ellipse (jmin, jmax, imin, imax as int bits); out[5..6] = its conic.
-__device__ inline void make_record(const float* __restrict__ prm, int kind, const float* __restrict__ cam, int b, int H,
-                                   int W, float sigma, float4 out[R_REC]) {
-    const Camera C = make_camera(cam + b * 3);
-    float v[3] = {prm[0], prm[1], prm[2]};
-    float t[3] = {prm[7], prm[8], prm[9]};
-    Pose P = make_pose(prm[3], prm[4], prm[5], prm[6]);
-    PrimGeo G;
-    prim_geometry(C, P.R, v, t, G);
-    out[0] = make_float4(G.o[0], G.o[1], G.o[2], __int_as_float(kind));
-    out[1] = make_float4(G.Mr[0], G.Mr[1], G.Mr[2], 0.f);
-    out[2] = make_float4(G.Mu[0], G.Mu[1], G.Mu[2], 0.f);
-    out[3] = make_float4(G.Mf[0], G.Mf[1], G.Mf[2], 0.f);
-    // Culling region: rays whose squared miss distance m2 (scaled frame) is <= L2 = lam_cut^2, outside
-    // of which the coverage logit (1 - m2)/sigma is below -X_CUT.  With d~ = M p, p = (px, py, 1) and
-    // M = [Mr Mu Mf]:  m2 <= L2  <=>  q(p) = (u.p)^2 - c p^T G p >= 0,  u = M^T o~, G = M^T M,
-    // c = |o~|^2 - L2: a conic in the image plane (an ellipse when the camera is outside the inflated
-    // primitive).  A cuboid is bounded by the sphere of radius sqrt(3) lam in its scaled frame.
-    float L2 = (1.0f + R_X_CUT * sigma) * 1.004f;
-    if (kind != VPN_SPHERE) L2 *= 3.0f;
-    const float txs = R_TAN_HALF_FOV * (float)W / (float)H;
-    const float* col[3] = {G.Mr, G.Mu, G.Mf};
-    float u[3], Gm[3][3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        u[i] = col[i][0] * G.o[0] + col[i][1] * G.o[1] + col[i][2] * G.o[2];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) Gm[i][j] = col[i][0] * col[j][0] + col[i][1] * col[j][1] + col[i][2] * col[j][2];
-    }
-    const float c = (G.o[0] * G.o[0] + G.o[1] * G.o[1] + G.o[2] * G.o[2]) - L2;
-    float Q[3][3], qmax = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) { Q[i][j] = u[i] * u[j] - c * Gm[i][j]; qmax = fmaxf(qmax, fabsf(Q[i][j])); }
-    const float qs = 1.0f / qmax;                       // positive scaling keeps the sign of q
-    const float A00 = Q[0][0] * qs, A01 = Q[0][1] * qs, A11 = Q[1][1] * qs;
-    const float b0 = Q[0][2] * qs, b1 = Q[1][2] * qs, c0 = Q[2][2] * qs;
-    const float det = A00 * A11 - A01 * A01;
-    int jmin = 0, jmax = W - 1, imin = 0, imax = H - 1;
-    float valid = 0.0f;
-    if (c > 0.0f && A00 < 0.0f && det > 1e-12f) {       // proper ellipse; anything else: keep the full image
-        const float xs = -(A11 * b0 - A01 * b1) / det, ys = -(A00 * b1 - A01 * b0) / det;
-        const float qstar = c0 + b0 * xs + b1 * ys;     // value at the centre
-        if (qstar > 0.0f) {
-            const float hx = sqrtf(qstar * (-A11) / det), hy = sqrtf(qstar * (-A00) / det);
-            const float jl = ((xs - hx) / txs + 1.0f) * (0.5f * W) - 0.5f, jh = ((xs + hx) / txs + 1.0f) * (0.5f * W) - 0.5f;
-            const float il = (1.0f - (ys + hy) / R_TAN_HALF_FOV) * (0.5f * H) - 0.5f;
-            const float ih = (1.0f - (ys - hy) / R_TAN_HALF_FOV) * (0.5f * H) - 0.5f;
-            jmin = (int)fminf(fmaxf(floorf(jl) - 1.0f, -1.0e6f), 1.0e6f);
-            jmax = (int)fminf(fmaxf(ceilf(jh) + 1.0f, -1.0e6f), 1.0e6f);
-            imin = (int)fminf(fmaxf(floorf(il) - 1.0f, -1.0e6f), 1.0e6f);
-            imax = (int)fminf(fmaxf(ceilf(ih) + 1.0f, -1.0e6f), 1.0e6f);
-            valid = 1.0f;
-        } else if (qstar < 0.0f) {                       // empty region: never visible
-            jmin = 1; jmax = 0; imin = 1; imax = 0;
-            valid = 1.0f;
-        }
-    }
-    out[4] = make_float4(__int_as_float(jmin), __int_as_float(jmax), __int_as_float(imin), __int_as_float(imax));
-    out[5] = make_float4(A00, A01, A11, valid);
-    out[6] = make_float4(b0, b1, c0, det);
-}
 
 // does the region q >= 0 of the conic touch the rectangle [x0,x1] x [y0,y1] (slope units)?  Exact for an
 // ellipse: the centre if it is inside, otherwise the maximum of the concave quadratic over the 4 edges.
@@ -315,11 +197,11 @@ __device__ inline void prim_backward(const float4 r0, const PixPrim& q, float gz
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// Binning: records + the visibility mask of every (tile, primitive) pair, computed ONCE per call and shared by the
-// forward, backward and finishing kernels (each of them used to repeat the conic-vs-tile test per wave).
-//   masks[(b * ntile + tile) * words + w] bit j  <=>  primitive 64 w + j may touch the 16x16 tile
-// (pixel box first, then the exact conic-vs-rectangle test: a primitive is dropped only where its coverage logit is
-// below -X_CUT on the whole tile).
+// Visibility of (tile, primitive) pairs.  The FORWARD tile kernels test their tile against the primitives (one
+// primitive per lane: pixel box first, then the exact conic-vs-rectangle test; a primitive is dropped only where its
+// coverage logit is below -X_CUT on the whole tile) and store the result,
+//   masks[(b * ntile + tile) * words + w] bit j  <=>  primitive 64 w + j may touch the 16x16 tile,
+// which the backward and finishing kernels read back instead of repeating the test.
 
 // does primitive (pixel box bb, conic qa/qb) touch the 16x16 tile at (c0, r0)?
 __device__ inline bool prim_hits_tile(const float4 bb, const float4 qa, const float4 qb, int c0, int r0, int H, int W) {
@@ -336,54 +218,20 @@ __device__ inline bool prim_hits_tile(const float4 bb, const float4 qa, const fl
     return vis;
 }
 
-constexpr int R_BIN_TILES = 64;      // tiles per binning workgroup (4 waves x 16 tiles)
-
-// grid (ceil(ntile / 64), B), 256 threads, dynamic LDS = K * 3 float4.  Every workgroup of an image computes the K
-// records (the first one writes them), then its waves test their tiles, one primitive per lane, and ballot.
-__global__ __launch_bounds__(256) void raster_bin_kernel(const float* __restrict__ params,
-                                                         const int32_t* __restrict__ kinds,
-                                                         const float* __restrict__ cam, int K, int H, int W,
-                                                         float sigma, int tiles_x, int ntile, int words,
-                                                         float4* __restrict__ rec,
-                                                         unsigned long long* __restrict__ masks,
-                                                         int* __restrict__ zero_me) {
-    extern __shared__ __attribute__((aligned(16))) float4 cull[];   // [K][3]: pixel box, conic A, conic b
-    const int b = blockIdx.y;
-    if (zero_me && blockIdx.x == 0 && b == 0 && threadIdx.x < 4) zero_me[threadIdx.x] = 0;   // arrival counters of later kernels
-    for (int k = threadIdx.x; k < K; k += 256) {
-        float4 r[R_REC];
-        make_record(params + ((size_t)b * K + k) * VPN_PARAM_STRIDE, kinds[k] == VPN_SPHERE ? VPN_SPHERE : VPN_CUBOID, cam, b,
-                    H, W, sigma, r);
-        if (blockIdx.x == 0) {
-            float4* out = rec + ((size_t)b * K + k) * R_REC;
+// records of all (image, primitive) pairs: one lane each (also zeroes the arrival counter of the loss finalisation)
+__global__ __launch_bounds__(256) void raster_prep_kernel(const float* __restrict__ params,
+                                                          const int32_t* __restrict__ kinds,
+                                                          const float* __restrict__ cam, int BK, int K, int H, int W,
+                                                          float sigma, float4* __restrict__ rec, int* __restrict__ zero_me) {
+    const int bk = blockIdx.x * 256 + threadIdx.x;
+    if (zero_me && bk < 4) zero_me[bk] = 0;
+    if (bk >= BK) return;
+    const int b = bk / K, k = bk - b * K;
+    float4 r[R_REC];
+    make_record(params + (size_t)bk * VPN_PARAM_STRIDE, kinds[k] == VPN_SPHERE ? VPN_SPHERE : VPN_CUBOID, cam, b, H, W, sigma, r);
+    float4* out = rec + (size_t)bk * R_REC;
 #pragma unroll
-            for (int i = 0; i < R_REC; ++i) out[i] = r[i];
-        }
-        cull[k * R_CULL + 0] = r[4]; cull[k * R_CULL + 1] = r[5]; cull[k * R_CULL + 2] = r[6];
-    }
-    __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int t0 = blockIdx.x * R_BIN_TILES + wave * (R_BIN_TILES / 4);
-    for (int w = 0; w < words; ++w) {
-        const int k = w * 64 + lane;
-        const bool live = k < K;
-        const float4 bb = cull[(live ? k : 0) * R_CULL], qa = cull[(live ? k : 0) * R_CULL + 1], qb = cull[(live ? k : 0) * R_CULL + 2];
-        // 4 tiles per iteration: the tests are independent, their latencies overlap (one wave per SIMD here)
-        for (int tb = t0; tb < t0 + R_BIN_TILES / 4; tb += 4) {
-            bool vis[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int t = min(tb + u, ntile - 1);
-                const int ty = t / tiles_x, tx = t - ty * tiles_x;
-                vis[u] = live && prim_hits_tile(bb, qa, qb, tx * R_TW, ty * R_TH, H, W);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const unsigned long long m = __ballot(vis[u]);
-                if (lane == 0 && tb + u < ntile) masks[((size_t)b * ntile + tb + u) * words + w] = m;
-            }
-        }
-    }
+    for (int i = 0; i < R_REC; ++i) out[i] = r[i];
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -443,19 +291,32 @@ __device__ inline unsigned long long uniform64(unsigned long long v) {
 
 constexpr int R_SLOT = 4;            // float4 per staged primitive: (o~|kind, Mr|k, Mu, Mf)
 
-// stage the visible primitives of mask word w; returns their number.  srec: this wave's 64 x R_SLOT float4.
-__device__ inline int stage_word(const float4* __restrict__ rec_b, unsigned long long m, int w, int K, float4* srec) {
+// Mask word w of this tile and staging of its visible primitives in one go: lane i fetches the whole record of
+// primitive 64 w + i (7 float4, one round trip), tests it against the tile, and if visible stores its ray coefficients
+// at slot = number of visible primitives below i.  `mask_in`: a mask computed earlier (backward kernels) instead of the
+// test; `mask_out`: where lane 0 stores the mask (forward kernels).  Returns the mask (wave-uniform).
+__device__ inline unsigned long long stage_word(const Tile& T, const float4* __restrict__ rec_b, int w, int K, int H, int W,
+                                                float4* srec, const unsigned long long* mask_in,
+                                                unsigned long long* mask_out) {
     const int lane = threadIdx.x & 63;
+    const int k = w * 64 + lane;
+    const float4* rk = rec_b + (size_t)(k < K ? k : 0) * R_REC;
+    unsigned long long m;
+    float4 a = rk[0], b = rk[1], c = rk[2], d = rk[3];
+    if (mask_in) {
+        m = uniform64(mask_in[w]);
+    } else {
+        const float4 bb = rk[4], qa = rk[5], qb = rk[6];
+        m = __ballot(k < K && prim_hits_tile(bb, qa, qb, T.c0, T.r0, H, W));
+        if (mask_out && lane == 0) mask_out[w] = m;
+    }
     if ((m >> lane) & 1ull) {
         const int slot = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-        const int k = w * 64 + lane;
-        const float4* rk = rec_b + (size_t)k * R_REC;
-        float4 a = rk[0], b = rk[1], c = rk[2], d = rk[3];
         b.w = __int_as_float(k);
         srec[slot * R_SLOT + 0] = a; srec[slot * R_SLOT + 1] = b; srec[slot * R_SLOT + 2] = c; srec[slot * R_SLOT + 3] = d;
     }
     __builtin_amdgcn_wave_barrier();
-    return __builtin_popcountll(m);
+    return m;
 }
 
 // Fused image losses: SilhouetteLoss (L1 / MSE mean against the GT silhouette, modules/loss/silhouette.py:11,22) and
@@ -474,13 +335,16 @@ struct LossArgs {
 __device__ inline float sign0(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }   // torch.sign
 
 // forward composite of the tile's visible primitives: P = prod(1 - a), S0 = sum w, S1 = sum w z
-__device__ inline void tile_forward(const Tile& T, const float4* __restrict__ rec_b, const unsigned long long* __restrict__ mrow,
-                                    int words, int K, float4* srec, float inv_sigma, float inv_gamma, float zref,
-                                    float P[R_PPL], float S0[R_PPL], float S1[R_PPL]) {
+__device__ inline unsigned long long tile_forward(const Tile& T, const float4* __restrict__ rec_b, unsigned long long* __restrict__ mrow,
+                                    int words, int K, int H, int W, float4* srec, float inv_sigma, float inv_gamma,
+                                    float zref, float P[R_PPL], float S0[R_PPL], float S1[R_PPL]) {
 #pragma unroll
     for (int s = 0; s < R_PPL; ++s) { P[s] = 1.0f; S0[s] = 0.0f; S1[s] = 0.0f; }
+    unsigned long long m0 = 0ull;
     for (int w = 0; w < words; ++w) {
-        const int n = stage_word(rec_b, uniform64(mrow[w]), w, K, srec);
+        const unsigned long long m = stage_word(T, rec_b, w, K, H, W, srec, nullptr, mrow);
+        if (w == 0) m0 = m;
+        const int n = __builtin_popcountll(m);
         for (int j = 0; j < n; ++j) {
             const float4 q0 = srec[j * R_SLOT], q1 = srec[j * R_SLOT + 1], q2 = srec[j * R_SLOT + 2], q3 = srec[j * R_SLOT + 3];
             auto body = [&](auto kind_c) {
@@ -498,60 +362,24 @@ __device__ inline void tile_forward(const Tile& T, const float4* __restrict__ re
         }
         if (words > 1) __builtin_amdgcn_wave_barrier();      // the next word overwrites srec
     }
-}
-
-// Transposing butterfly: 16 per-lane values -> lane L holds the wave total of value (L >> 2).
-__device__ inline float wave_reduce16(float v[16]) {
-    const int lane = threadIdx.x & 63;
-    {
-        const bool hi = lane & 32;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            float send = hi ? v[i] : v[i + 8], keep = hi ? v[i + 8] : v[i];
-            v[i] = keep + __shfl_xor(send, 32, 64);
-        }
-    }
-    {
-        const bool hi = lane & 16;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float send = hi ? v[i] : v[i + 4], keep = hi ? v[i + 4] : v[i];
-            v[i] = keep + __shfl_xor(send, 16, 64);
-        }
-    }
-    {
-        const bool hi = lane & 8;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            float send = hi ? v[i] : v[i + 2], keep = hi ? v[i + 2] : v[i];
-            v[i] = keep + __shfl_xor(send, 8, 64);
-        }
-    }
-    float r;
-    {
-        const bool hi = lane & 4;
-        float send = hi ? v[0] : v[1], keep = hi ? v[1] : v[0];
-        r = keep + __shfl_xor(send, 4, 64);
-    }
-    r += __shfl_xor(r, 2, 64);
-    r += __shfl_xor(r, 1, 64);
-    return r;
+    return m0;
 }
 
 // backward over the tile's visible primitives: per pixel x primitive analytic gradient w.r.t. the 12 ray
 // coefficients, summed over the lane's 4 pixels, reduced over the wave and written as 48 contiguous bytes of
 // partial[b][k][tile] -- only for the (primitive, tile) pairs of the binning mask; raster_bwd_finish_kernel reads
-// exactly those.  No atomics: bitwise reproducible.  `staged`: srec already holds the records of word 0 (one-pass
-// kernel with K <= 64).
+// exactly those.  No atomics: bitwise reproducible.  `staged`: srec already holds the records of mask word 0 = m0
+// (one-pass kernel with K <= 64); mrow: masks stored by an EARLIER launch, or null to repeat the test (a wave does not
+// read back the mask words it stored itself a moment ago).
 __device__ inline void tile_backward(const Tile& T, const float4* __restrict__ rec_b, const unsigned long long* __restrict__ mrow,
-                                     int words, int K, int ntile, float4* srec, bool staged, float inv_sigma,
+                                     int words, int K, int ntile, int H, int W, float4* srec, bool staged,
+                                     unsigned long long m0, float inv_sigma,
                                      float inv_gamma, float zref, const float P[R_PPL], const float zbar[R_PPL],
                                      const float invS[R_PPL], const float gAtot[R_PPL], const float gZbar[R_PPL],
                                      float* __restrict__ partial) {
     const int lane = threadIdx.x & 63;
     for (int w = 0; w < words; ++w) {
-        const unsigned long long m = uniform64(mrow[w]);
-        const int n = staged ? __builtin_popcountll(m) : stage_word(rec_b, m, w, K, srec);
+        const int n = __builtin_popcountll(staged ? m0 : stage_word(T, rec_b, w, K, H, W, srec, mrow, nullptr));
         for (int j = 0; j < n; ++j) {
             const float4 q0 = srec[j * R_SLOT], q1 = srec[j * R_SLOT + 1], q2 = srec[j * R_SLOT + 2], q3 = srec[j * R_SLOT + 3];
             const int k = __builtin_amdgcn_readfirstlane(__float_as_int(q1.w));
@@ -591,7 +419,7 @@ __device__ inline void tile_backward(const Tile& T, const float4* __restrict__ r
 
 template <int MODE>   // 0: write alpha/depth images, 1: fused losses (per-tile sums)
 __global__ __launch_bounds__(64) void raster_fwd_kernel(const float4* __restrict__ rec,
-                                                         const unsigned long long* __restrict__ masks,
+                                                         unsigned long long* __restrict__ masks,
                                                          const float* __restrict__ cam, int B, int K, int H, int W,
                                                          int tiles_x, int tiles_y, int words, float sigma, float gamma,
                                                          float z_far, float* __restrict__ alpha,
@@ -603,8 +431,8 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(const float4* __restrict
     const float inv_sigma = 1.0f / (sigma + vz0), inv_gamma = 1.0f / (gamma + vz0), zref = cam[T.b * 3] + vz0;
     __shared__ __attribute__((aligned(16))) float4 srec[64 * R_SLOT];
     float P[R_PPL], S0[R_PPL], S1[R_PPL];
-    tile_forward(T, rec + (size_t)T.b * K * R_REC, masks + ((size_t)T.b * ntile + T.tile) * words, words, K, srec, inv_sigma,
-                 inv_gamma, zref, P, S0, S1);
+    tile_forward(T, rec + (size_t)T.b * K * R_REC, masks + ((size_t)T.b * ntile + T.tile) * words, words, K, H, W, srec,
+                 inv_sigma, inv_gamma, zref, P, S0, S1);
     const size_t hw = (size_t)H * W;
     float lsil = 0.0f, ldep = 0.0f;
 #pragma unroll
@@ -684,7 +512,7 @@ __global__ __launch_bounds__(64, 4) void raster_bwd_kernel(const float4* __restr
         }
     }
     __shared__ __attribute__((aligned(16))) float4 srec[64 * R_SLOT];
-    tile_backward(T, rec + (size_t)T.b * K * R_REC, mrow, words, K, ntile, srec, false, inv_sigma,
+    tile_backward(T, rec + (size_t)T.b * K * R_REC, mrow, words, K, ntile, H, W, srec, false, 0ull, inv_sigma,
                   inv_gamma, zref, P, zbar, invS, gAtot, gZbar, partial);
 }
 
@@ -695,7 +523,7 @@ __global__ __launch_bounds__(64, 4) void raster_bwd_kernel(const float4* __restr
 // coefficients) for an upstream gradient of 1: d total is linear in it, raster_bwd_finish_kernel multiplies by the
 // actual upstream gradient when backward runs.
 __global__ __launch_bounds__(64, 4) void raster_total_kernel(const float4* __restrict__ rec,
-                                                           const unsigned long long* __restrict__ masks,
+                                                           unsigned long long* __restrict__ masks,
                                                            const float* __restrict__ cam, int B, int K, int H, int W,
                                                            int tiles_x, int tiles_y, int words, float sigma, float gamma,
                                                            float z_far, float* __restrict__ partial, LossArgs la) {
@@ -703,7 +531,7 @@ __global__ __launch_bounds__(64, 4) void raster_total_kernel(const float4* __res
     if (!T.valid) return;
     const int ntile = tiles_x * tiles_y, lane = threadIdx.x & 63;
     const float4* rec_b = rec + (size_t)T.b * K * R_REC;
-    const unsigned long long* mrow = masks + ((size_t)T.b * ntile + T.tile) * words;
+    unsigned long long* mrow = masks + ((size_t)T.b * ntile + T.tile) * words;
     const float vz0 = __int_as_float(vzero());           // +0.0f in a VGPR: keeps the loop's uniform scalars out of SGPRs
     const float inv_sigma = 1.0f / (sigma + vz0), inv_gamma = 1.0f / (gamma + vz0), zref = cam[T.b * 3] + vz0;
     const size_t hw = (size_t)H * W;
@@ -719,7 +547,7 @@ __global__ __launch_bounds__(64, 4) void raster_total_kernel(const float4* __res
     }
     __shared__ __attribute__((aligned(16))) float4 srec[64 * R_SLOT];
     float P[R_PPL], S0[R_PPL], S1[R_PPL];
-    tile_forward(T, rec_b, mrow, words, K, srec, inv_sigma, inv_gamma, zref, P, S0, S1);
+    const unsigned long long m0 = tile_forward(T, rec_b, mrow, words, K, H, W, srec, inv_sigma, inv_gamma, zref, P, S0, S1);
     float gAtot[R_PPL], gZbar[R_PPL], zbar[R_PPL], invS[R_PPL];
     float lsil = 0.0f, ldep = 0.0f;
 #pragma unroll
@@ -755,12 +583,11 @@ __global__ __launch_bounds__(64, 4) void raster_total_kernel(const float4* __res
         la.tile_loss[((size_t)T.b * ntile + T.tile) * 2 + 0] = lsil;
         la.tile_loss[((size_t)T.b * ntile + T.tile) * 2 + 1] = ldep;
     }
-    tile_backward(T, rec_b, mrow, words, K, ntile, srec, words == 1, inv_sigma, inv_gamma, zref, P, zbar, invS, gAtot, gZbar,
-                  partial);
+    tile_backward(T, rec_b, nullptr, words, K, ntile, H, W, srec, words == 1, m0, inv_sigma, inv_gamma, zref, P, zbar, invS,
+                  gAtot, gZbar, partial);
 }
 
-// one wave per (b,k): sum the per-tile partials of the tiles whose mask holds k, in a fixed order, then chain rule
-// to (v,q,t).  `scale` (device scalar or null = 1): the upstream gradient of the fused total.
+// one wave per (b,k): raster_finish_wave (vpn_raster_common.h), then write / accumulate the gradient
 __global__ __launch_bounds__(256) void raster_bwd_finish_kernel(const float* __restrict__ params,
                                                                 const float* __restrict__ cam, int BK, int K,
                                                                 int ntile, int words,
@@ -771,52 +598,11 @@ __global__ __launch_bounds__(256) void raster_bwd_finish_kernel(const float* __r
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int bk = blockIdx.x * 4 + wave;
     if (bk >= BK) return;
-    const int b = bk / K, k = bk - b * K;
-    float v[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = 0.0f;
-    for (int tile = lane; tile < ntile; tile += 64) {
-        const unsigned long long m = masks[((size_t)b * ntile + tile) * words + (k >> 6)];
-        if (!((m >> (k & 63)) & 1ull)) continue;                                   // nothing was written for this pair
-        const float4* src = reinterpret_cast<const float4*>(partial + ((size_t)bk * ntile + tile) * 12);
-        const float4 a = src[0], c = src[1], d = src[2];
-        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
-        v[4] += c.x; v[5] += c.y; v[6] += c.z; v[7] += c.w;
-        v[8] += d.x; v[9] += d.y; v[10] += d.z; v[11] += d.w;
-    }
-    const float tot = wave_reduce16(v);
-    // gather the 12 totals into lane 0
-    float G[12];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) G[i] = __shfl(tot, i * 4, 64);
+    float r[10];
+    raster_finish_wave(params, cam, bk, K, ntile, words, masks, partial, r);
     if (lane != 0) return;
     const float sc = scale ? *scale : 1.0f;
-    const float* prm = params + (size_t)bk * VPN_PARAM_STRIDE;
-    const Camera C = make_camera(cam + b * 3);
-    const Pose P = make_pose(prm[3], prm[4], prm[5], prm[6]);
-    const float vv[3] = {prm[0], prm[1], prm[2]};
-    const float t[3] = {prm[7], prm[8], prm[9]};
-    PrimGeo Ge;
-    prim_geometry(C, P.R, vv, t, Ge);
-    const float e[3] = {C.eye[0] - t[0], C.eye[1] - t[1], C.eye[2] - t[2]};
-    float gv[3], gyo[3], gyr[3], gyu[3], gyf[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const float iv = 1.0f / vv[a];
-        gv[a] = -(G[a] * Ge.o[a] + G[3 + a] * Ge.Mr[a] + G[6 + a] * Ge.Mu[a] + G[9 + a] * Ge.Mf[a]) * iv;
-        gyo[a] = G[a] * iv; gyr[a] = G[3 + a] * iv; gyu[a] = G[6 + a] * iv; gyf[a] = G[9 + a] * iv;
-    }
-    float gR[3][3], gt[3], gq[4];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-            gR[r][a] = e[r] * gyo[a] + C.right[r] * gyr[a] + C.up[r] * gyu[a] + C.fwd[r] * gyf[a];
-        gt[r] = -(P.R.m[r][0] * gyo[0] + P.R.m[r][1] * gyo[1] + P.R.m[r][2] * gyo[2]);
-    }
-    pose_backward(P, prm[3], prm[4], prm[5], gR, gq);
     float* o = gparams + (size_t)bk * VPN_PARAM_STRIDE;
-    const float r[10] = {gv[0], gv[1], gv[2], gq[0], gq[1], gq[2], gq[3], gt[0], gt[1], gt[2]};
 #pragma unroll
     for (int i = 0; i < 10; ++i) o[i] = accumulate ? o[i] + sc * r[i] : sc * r[i];   // accumulate: add to the sampler's gradient
 }
@@ -949,12 +735,11 @@ static inline const unsigned long long* masks_of(const void* records, int B, int
     return reinterpret_cast<const unsigned long long*>(reinterpret_cast<const char*>(records) + rec_bytes(B, K));
 }
 
-static int launch_bin(const float* params, const int32_t* kinds, const float* cam, int B, int K, int H, int W,
-                      float sigma, void* records, int* zero_me, hipStream_t s) {
-    const Grid G = raster_grid(B, K, H, W);
-    const size_t lds = (size_t)K * R_CULL * sizeof(float4);         // <= 48 KB at VPN_MAX_PRIMS
-    VPN_LAUNCH(raster_bin_kernel, dim3((G.ntile + R_BIN_TILES - 1) / R_BIN_TILES, B), dim3(256), lds, s, params, kinds, cam,
-               K, H, W, sigma, G.tiles_x, G.ntile, G.words, (float4*)records, masks_of(records, B, K), zero_me);
+static int launch_prep(const float* params, const int32_t* kinds, const float* cam, int B, int K, int H, int W,
+                       float sigma, void* records, int* zero_me, hipStream_t s) {
+    const int BK = B * K;
+    VPN_LAUNCH(raster_prep_kernel, dim3((BK + 255) / 256), dim3(256), 0, s, params, kinds, cam, BK, K, H, W, sigma,
+               (float4*)records, zero_me);
     VPN_LAUNCH_CHECK();
     return 0;
 }
@@ -966,10 +751,10 @@ extern "C" int vpn_raster_fwd(const float* params, const int32_t* kinds, const f
     if (rc) return rc;
     if (!alpha || !depth || !aux || !records) return VPN_E_BADARG;
     if (((uintptr_t)records & 15) != 0) return VPN_E_BADARG;
-    if ((rc = launch_bin(params, kinds, cam, B, K, H, W, sigma, records, nullptr, (hipStream_t)stream))) return rc;
+    if ((rc = launch_prep(params, kinds, cam, B, K, H, W, sigma, records, nullptr, (hipStream_t)stream))) return rc;
     const Grid G = raster_grid(B, K, H, W);
     VPN_LAUNCH(raster_fwd_kernel<0>, G.g, dim3(64), 0, (hipStream_t)stream, (const float4*)records,
-               masks_of((const void*)records, B, K), cam, B, K, H, W, G.tiles_x, G.tiles_y, G.words, sigma, gamma, z_far, alpha,
+               masks_of(records, B, K), cam, B, K, H, W, G.tiles_x, G.tiles_y, G.words, sigma, gamma, z_far, alpha,
                depth, aux, LossArgs{});
     VPN_LAUNCH_CHECK();
     return 0;
@@ -1005,10 +790,10 @@ extern "C" int vpn_raster_loss_fwd(const float* params, const int32_t* kinds, co
     if (!aux || !records || !loss_ws || !losses) return VPN_E_BADARG;
     if (((uintptr_t)records & 15) != 0 || ((uintptr_t)loss_ws & 15) != 0) return VPN_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
-    if ((rc = launch_bin(params, kinds, cam, B, K, H, W, sigma, records, (int*)loss_ws, s))) return rc;
+    if ((rc = launch_prep(params, kinds, cam, B, K, H, W, sigma, records, (int*)loss_ws, s))) return rc;
     const Grid G = raster_grid(B, K, H, W);
     LossArgs la{gt_sil, gt_depth, sil_mse, 1.0f / ((float)B * (float)H * (float)W), tile_loss_of(loss_ws, B), nullptr, 0.f, 0.f};
-    VPN_LAUNCH(raster_fwd_kernel<1>, G.g, dim3(64), 0, s, (const float4*)records, masks_of((const void*)records, B, K), cam, B, K,
+    VPN_LAUNCH(raster_fwd_kernel<1>, G.g, dim3(64), 0, s, (const float4*)records, masks_of(records, B, K), cam, B, K,
                H, W, G.tiles_x, G.tiles_y, G.words, sigma, gamma, z_far, (float*)nullptr, (float*)nullptr, aux, la);
     VPN_LAUNCH_CHECK();
     return launch_finalize(loss_ws, true, B, H, W, nullptr, nullptr, 0, 0, 0.f, 0.f, 0.f, 1.0f, 1.0f, losses, nullptr, s);
@@ -1072,10 +857,10 @@ extern "C" int vpn_raster_total_fwd(const float* params, const int32_t* kinds, c
     if (!records || !loss_ws || !workspace) return VPN_E_BADARG;
     if (((uintptr_t)records & 15) != 0 || ((uintptr_t)workspace & 15) != 0 || ((uintptr_t)loss_ws & 15) != 0) return VPN_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
-    if ((rc = launch_bin(params, kinds, cam, B, K, H, W, sigma, records, (int*)loss_ws, s))) return rc;
+    if ((rc = launch_prep(params, kinds, cam, B, K, H, W, sigma, records, (int*)loss_ws, s))) return rc;
     const Grid G = raster_grid(B, K, H, W);
     LossArgs la{gt_sil, gt_depth, sil_mse, 1.0f / ((float)B * (float)H * (float)W), tile_loss_of(loss_ws, B), nullptr, w_sil, w_dep};
-    VPN_LAUNCH(raster_total_kernel, G.g, dim3(64), 0, s, (const float4*)records, masks_of((const void*)records, B, K), cam, B, K,
+    VPN_LAUNCH(raster_total_kernel, G.g, dim3(64), 0, s, (const float4*)records, masks_of(records, B, K), cam, B, K,
                H, W, G.tiles_x, G.tiles_y, G.words, sigma, gamma, z_far, (float*)workspace, la);
     VPN_LAUNCH_CHECK();
     return 0;

@@ -11,7 +11,7 @@
 // volume and face quotas are computed once by lane 0 and staged in LDS; lanes stride
 // over the n points.  Backward: dL/d(v,q,t) only needs G = sum_n g_n c_n^T (3x3) and
 // sum_n g_n, reduced wave-shuffle -> LDS -> one chain-rule pass by lane 0.
-#include "vpn_common.h"
+#include "vpn_raster_common.h"
 
 namespace vpn {
 
@@ -178,9 +178,10 @@ __global__ __launch_bounds__(SAMP_BLOCK) void sample_chamfer_bwd_kernel(
     uint64_t seed, const uint64_t* __restrict__ seed_dev, uint64_t sample_base, int K, int n,
     const float* __restrict__ points, const float* __restrict__ gt, int M, const float* __restrict__ dist1, const int32_t* __restrict__ idx1,
     const float* __restrict__ dist2, const int32_t* __restrict__ idx2, const float* __restrict__ grad_loss_b,
-    float w1, float w2, float* __restrict__ grad_params) {
+    float w1, float w2, float* __restrict__ grad_params, const RasterFinish rf) {
     __shared__ PrimLds P;
     __shared__ float red[SAMP_BLOCK / 64][12];
+    __shared__ float rgrad[10];
     if (seed_dev) seed += *seed_dev;
     const int k = blockIdx.x, b = blockIdx.y, N = K * n;
     const float* prm = params + ((size_t)b * K + k) * VPN_PARAM_STRIDE;
@@ -222,13 +223,22 @@ __global__ __launch_bounds__(SAMP_BLOCK) void sample_chamfer_bwd_kernel(
     const int cap = (M + SAMP_BLOCK - 1) / SAMP_BLOCK * 64;             // entries one wave looks at
     int* mine = match + wave * cap;
     int cnt = 0;
-    for (int e0 = 0; e0 < M; e0 += SAMP_BLOCK) {
-        const int e = e0 + threadIdx.x;
-        const int i = e < M ? idx2[(size_t)b * M + e] : -1;
-        const bool hit = i >= k * n && i < (k + 1) * n;
-        const unsigned long long m = __ballot(hit);
-        if (hit) mine[cnt + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = e;
-        cnt += __builtin_popcountll(m);
+    // 8 passes at a time: their loads are issued together (each pass used to wait out its own L2 round trip)
+    for (int e0 = 0; e0 < M; e0 += 8 * SAMP_BLOCK) {
+        int iv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u * SAMP_BLOCK + threadIdx.x;
+            iv[u] = e < M ? idx2[(size_t)b * M + e] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (e0 + u * SAMP_BLOCK >= M) break;
+            const bool hit = iv[u] >= k * n && iv[u] < (k + 1) * n;
+            const unsigned long long m = __ballot(hit);
+            if (hit) mine[cnt + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = e0 + u * SAMP_BLOCK + threadIdx.x;
+            cnt += __builtin_popcountll(m);
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");             // the wave reads its own LDS writes below
     __builtin_amdgcn_wave_barrier();
@@ -241,6 +251,17 @@ __global__ __launch_bounds__(SAMP_BLOCK) void sample_chamfer_bwd_kernel(
     for (int i = 0; i < 12; ++i) {
         float s = wave_sum(acc[i]);
         if (lane == 0) red[wave][i] = s;
+    }
+    // the raster's finishing step for the same primitive (its gradient partials were written by the forward launch
+    // of the training step): done by wave 1 while wave 0 runs the sampler's chain rule; saves a launch of its own
+    if (rf.partial && wave == 1) {
+        float r[10];
+        raster_finish_wave(params, rf.cam, b * K + k, K, rf.ntile, rf.words, rf.masks, rf.partial, r);
+        if (lane == 0) {
+            const float sc = rf.scale ? *rf.scale : 1.0f;
+#pragma unroll
+            for (int i = 0; i < 10; ++i) rgrad[i] = sc * r[i];
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -263,9 +284,9 @@ __global__ __launch_bounds__(SAMP_BLOCK) void sample_chamfer_bwd_kernel(
         }
         pose_backward(P.pose, prm[3], prm[4], prm[5], gR, gq);
         float* o = grad_params + ((size_t)b * K + k) * VPN_PARAM_STRIDE;
-        o[0] = gv[0]; o[1] = gv[1]; o[2] = gv[2];
-        o[3] = gq[0]; o[4] = gq[1]; o[5] = gq[2]; o[6] = gq[3];
-        o[7] = gt3[0]; o[8] = gt3[1]; o[9] = gt3[2];
+        const float res[10] = {gv[0], gv[1], gv[2], gq[0], gq[1], gq[2], gq[3], gt3[0], gt3[1], gt3[2]};
+#pragma unroll
+        for (int i = 0; i < 10; ++i) o[i] = rf.partial ? res[i] + rgrad[i] : res[i];
     }
 }
 
@@ -584,11 +605,11 @@ extern "C" int vpn_camera_transform_bwd(const float* grad_out, const float* dist
     return camera_launch(grad_out, dists, elevs, azims, angles, B, N, to_object, 1, grad_points, stream);
 }
 
-extern "C" int vpn_sample_chamfer_bwd(const float* params, const int32_t* kinds, const float* u, uint64_t seed,
-                                      const uint64_t* seed_dev, uint64_t sample_base, int B, int K, int n, const float* points,
-                                      const float* gt_points, int M, const float* dist1, const int32_t* idx1,
-                                      const float* dist2, const int32_t* idx2, const float* grad_loss_b, float w1,
-                                      float w2, float* grad_params, void* stream) {
+static int launch_scb(const float* params, const int32_t* kinds, const float* u, uint64_t seed,
+                      const uint64_t* seed_dev, uint64_t sample_base, int B, int K, int n, const float* points,
+                      const float* gt_points, int M, const float* dist1, const int32_t* idx1,
+                      const float* dist2, const int32_t* idx2, const float* grad_loss_b, float w1,
+                      float w2, float* grad_params, const RasterFinish& rf, void* stream) {
     if (!params || !kinds || !points || !gt_points || !dist1 || !idx1 || !dist2 || !idx2 || !grad_loss_b || !grad_params)
         return VPN_E_BADARG;
     if (B <= 0 || K <= 0 || n <= 0 || M <= 0) return VPN_E_BADARG;
@@ -596,9 +617,38 @@ extern "C" int vpn_sample_chamfer_bwd(const float* params, const int32_t* kinds,
     const size_t lds = (size_t)((M + SAMP_BLOCK - 1) / SAMP_BLOCK) * 64 * (SAMP_BLOCK / 64) * sizeof(int);   // = M rounded up
     if (lds > 60 * 1024) return VPN_E_TOOBIG;                           // 15 k GT points; beyond: vpn_chamfer_bwd + vpn_sample_bwd
     VPN_LAUNCH(sample_chamfer_bwd_kernel, dim3(K, B), dim3(SAMP_BLOCK), lds, (hipStream_t)stream, params, kinds, u, seed,
-               seed_dev, sample_base, K, n, points, gt_points, M, dist1, idx1, dist2, idx2, grad_loss_b, w1, w2, grad_params);
+               seed_dev, sample_base, K, n, points, gt_points, M, dist1, idx1, dist2, idx2, grad_loss_b, w1, w2, grad_params, rf);
     VPN_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int vpn_sample_chamfer_bwd(const float* params, const int32_t* kinds, const float* u, uint64_t seed,
+                                      const uint64_t* seed_dev, uint64_t sample_base, int B, int K, int n, const float* points,
+                                      const float* gt_points, int M, const float* dist1, const int32_t* idx1,
+                                      const float* dist2, const int32_t* idx2, const float* grad_loss_b, float w1,
+                                      float w2, float* grad_params, void* stream) {
+    return launch_scb(params, kinds, u, seed, seed_dev, sample_base, B, K, n, points, gt_points, M, dist1, idx1, dist2, idx2,
+                      grad_loss_b, w1, w2, grad_params, RasterFinish{}, stream);
+}
+
+// the same launch also finishes the raster backward of the training step (vpn_raster_total_fwd wrote the partials):
+// grad_params = d(Chamfer term)/d params + (*grad_total) * d(total_img)/d params
+extern "C" int vpn_hotpath_bwd(const float* params, const int32_t* kinds, const float* u, uint64_t seed,
+                               const uint64_t* seed_dev, uint64_t sample_base, int B, int K, int n, const float* points,
+                               const float* gt_points, int M, const float* dist1, const int32_t* idx1,
+                               const float* dist2, const int32_t* idx2, const float* grad_loss_b, float w1, float w2,
+                               const float* cam, int H, int W, const void* records, const void* workspace,
+                               const float* grad_total, float* grad_params, void* stream) {
+    if (!cam || !records || !workspace || H <= 0 || W <= 0) return VPN_E_BADARG;
+    RasterFinish rf;
+    rf.cam = cam;
+    rf.ntile = ((W + R_TW - 1) / R_TW) * ((H + R_TH - 1) / R_TH);
+    rf.words = (K + 63) / 64;
+    rf.masks = reinterpret_cast<const unsigned long long*>(reinterpret_cast<const char*>(records) + (size_t)B * K * R_REC * sizeof(float4));
+    rf.partial = (const float*)workspace;
+    rf.scale = grad_total;
+    return launch_scb(params, kinds, u, seed, seed_dev, sample_base, B, K, n, points, gt_points, M, dist1, idx1, dist2, idx2,
+                      grad_loss_b, w1, w2, grad_params, rf, stream);
 }
 
 static int mesh_check(const void* params, const void* kinds, const void* offsets, const void* ts, const void* tc,

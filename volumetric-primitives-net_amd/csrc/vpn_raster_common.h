@@ -1,0 +1,228 @@
+// vpn_raster_common.h — pieces of the primitive raster shared by raster.hip (binning, tile kernels) and
+// sampler.hip (the hot-path kernels that fold the raster's per-primitive work into the sampler's launches):
+// camera, per-primitive records, the wave reduction and the finishing chain rule.  gfx950 only.
+#pragma once
+#include "vpn_common.h"
+
+namespace vpn {
+
+constexpr float R_TAN_HALF_FOV = 0.4571428511950223f;   // tan(49.13434207744484 deg / 2): kaolin v0.1 default fov
+constexpr float R_X_CLAMP = 80.0f;
+constexpr float R_E_CLAMP = 8.0f;
+constexpr float R_EPS_H = 1e-3f;     // squareplus smoothing of relu(1 - m2) under the chord sqrt
+constexpr float R_DELTA_S0 = 1e-12f;
+constexpr float R_EPS_D = 1e-9f;
+constexpr float R_X_CUT = 16.0f;     // primitives whose coverage logit is below -X_CUT on a tile are skipped: coverage < 1.2e-7
+constexpr int R_TW = 16, R_TH = 16;  // pixel tile per wave
+constexpr int R_PPL = 4;             // pixels per lane (row groups of 4 rows)
+constexpr int R_REC = 7;             // float4 per primitive record in HBM
+constexpr int R_CULL = 3;            // float4 per primitive staged in LDS by the binning kernel (pixel box + conic)
+
+struct Camera {
+    float eye[3], right[3], up[3], fwd[3];
+    float dist;
+};
+
+// look-at camera of vertex_renderer.py:18 (set_look_at_parameters([azim],[elev],[dist]), degrees)
+__device__ inline Camera make_camera(const float* cam) {
+    Camera C;
+    const float d = cam[0];
+    const float el = cam[1] * 0.017453292519943295f, az = cam[2] * 0.017453292519943295f;
+    float ce = cosf(el), se = sinf(el), ca = cosf(az), sa = sinf(az);
+    C.eye[0] = d * ce * ca; C.eye[1] = d * se; C.eye[2] = d * ce * sa;
+    float inv = 1.0f / sqrtf(C.eye[0] * C.eye[0] + C.eye[1] * C.eye[1] + C.eye[2] * C.eye[2]);
+    float zx = C.eye[0] * inv, zy = C.eye[1] * inv, zz = C.eye[2] * inv;
+    // right = normalize((0,1,0) x zax) ; up = zax x right
+    float rx = zz, ry = 0.0f, rz = -zx;
+    float rinv = 1.0f / sqrtf(rx * rx + rz * rz);
+    rx *= rinv; rz *= rinv;
+    C.right[0] = rx; C.right[1] = ry; C.right[2] = rz;
+    C.up[0] = zy * rz - zz * ry; C.up[1] = zz * rx - zx * rz; C.up[2] = zx * ry - zy * rx;
+    C.fwd[0] = -zx; C.fwd[1] = -zy; C.fwd[2] = -zz;
+    C.dist = d;
+    return C;
+}
+
+struct PrimGeo {   // per-primitive quantities that do not depend on the pixel
+    float o[3], Mr[3], Mu[3], Mf[3];
+};
+
+__device__ inline void prim_geometry(const Camera& C, const Mat3& R, const float* v, const float* t, PrimGeo& G) {
+    float e[3] = {C.eye[0] - t[0], C.eye[1] - t[1], C.eye[2] - t[2]};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float iv = 1.0f / v[a];
+        G.o[a] = (R.m[0][a] * e[0] + R.m[1][a] * e[1] + R.m[2][a] * e[2]) * iv;
+        G.Mr[a] = (R.m[0][a] * C.right[0] + R.m[1][a] * C.right[1] + R.m[2][a] * C.right[2]) * iv;
+        G.Mu[a] = (R.m[0][a] * C.up[0] + R.m[1][a] * C.up[1] + R.m[2][a] * C.up[2]) * iv;
+        G.Mf[a] = (R.m[0][a] * C.fwd[0] + R.m[1][a] * C.fwd[1] + R.m[2][a] * C.fwd[2]) * iv;
+    }
+}
+
+// Record of one primitive for one camera: out[0..3] = (o~|kind, Mr, Mu, Mf) so that d~ = Mf + px Mr + py Mu;
+// out[4] = pixel bounding box of the culling ellipse (jmin, jmax, imin, imax as int bits); out[5..6] = its conic.
+__device__ inline void make_record(const float* __restrict__ prm, int kind, const float* __restrict__ cam, int b, int H,
+                                   int W, float sigma, float4 out[R_REC]) {
+    const Camera C = make_camera(cam + b * 3);
+    float v[3] = {prm[0], prm[1], prm[2]};
+    float t[3] = {prm[7], prm[8], prm[9]};
+    Pose P = make_pose(prm[3], prm[4], prm[5], prm[6]);
+    PrimGeo G;
+    prim_geometry(C, P.R, v, t, G);
+    out[0] = make_float4(G.o[0], G.o[1], G.o[2], __int_as_float(kind));
+    out[1] = make_float4(G.Mr[0], G.Mr[1], G.Mr[2], 0.f);
+    out[2] = make_float4(G.Mu[0], G.Mu[1], G.Mu[2], 0.f);
+    out[3] = make_float4(G.Mf[0], G.Mf[1], G.Mf[2], 0.f);
+    // Culling region: rays whose squared miss distance m2 (scaled frame) is <= L2 = lam_cut^2, outside
+    // of which the coverage logit (1 - m2)/sigma is below -X_CUT.  With d~ = M p, p = (px, py, 1) and
+    // M = [Mr Mu Mf]:  m2 <= L2  <=>  q(p) = (u.p)^2 - c p^T G p >= 0,  u = M^T o~, G = M^T M,
+    // c = |o~|^2 - L2: a conic in the image plane (an ellipse when the camera is outside the inflated
+    // primitive).  A cuboid is bounded by the sphere of radius sqrt(3) lam in its scaled frame.
+    float L2 = (1.0f + R_X_CUT * sigma) * 1.004f;
+    if (kind != VPN_SPHERE) L2 *= 3.0f;
+    const float txs = R_TAN_HALF_FOV * (float)W / (float)H;
+    const float* col[3] = {G.Mr, G.Mu, G.Mf};
+    float u[3], Gm[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        u[i] = col[i][0] * G.o[0] + col[i][1] * G.o[1] + col[i][2] * G.o[2];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) Gm[i][j] = col[i][0] * col[j][0] + col[i][1] * col[j][1] + col[i][2] * col[j][2];
+    }
+    const float c = (G.o[0] * G.o[0] + G.o[1] * G.o[1] + G.o[2] * G.o[2]) - L2;
+    float Q[3][3], qmax = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { Q[i][j] = u[i] * u[j] - c * Gm[i][j]; qmax = fmaxf(qmax, fabsf(Q[i][j])); }
+    const float qs = 1.0f / qmax;                       // positive scaling keeps the sign of q
+    const float A00 = Q[0][0] * qs, A01 = Q[0][1] * qs, A11 = Q[1][1] * qs;
+    const float b0 = Q[0][2] * qs, b1 = Q[1][2] * qs, c0 = Q[2][2] * qs;
+    const float det = A00 * A11 - A01 * A01;
+    int jmin = 0, jmax = W - 1, imin = 0, imax = H - 1;
+    float valid = 0.0f;
+    if (c > 0.0f && A00 < 0.0f && det > 1e-12f) {       // proper ellipse; anything else: keep the full image
+        const float xs = -(A11 * b0 - A01 * b1) / det, ys = -(A00 * b1 - A01 * b0) / det;
+        const float qstar = c0 + b0 * xs + b1 * ys;     // value at the centre
+        if (qstar > 0.0f) {
+            const float hx = sqrtf(qstar * (-A11) / det), hy = sqrtf(qstar * (-A00) / det);
+            const float jl = ((xs - hx) / txs + 1.0f) * (0.5f * W) - 0.5f, jh = ((xs + hx) / txs + 1.0f) * (0.5f * W) - 0.5f;
+            const float il = (1.0f - (ys + hy) / R_TAN_HALF_FOV) * (0.5f * H) - 0.5f;
+            const float ih = (1.0f - (ys - hy) / R_TAN_HALF_FOV) * (0.5f * H) - 0.5f;
+            jmin = (int)fminf(fmaxf(floorf(jl) - 1.0f, -1.0e6f), 1.0e6f);
+            jmax = (int)fminf(fmaxf(ceilf(jh) + 1.0f, -1.0e6f), 1.0e6f);
+            imin = (int)fminf(fmaxf(floorf(il) - 1.0f, -1.0e6f), 1.0e6f);
+            imax = (int)fminf(fmaxf(ceilf(ih) + 1.0f, -1.0e6f), 1.0e6f);
+            valid = 1.0f;
+        } else if (qstar < 0.0f) {                       // empty region: never visible
+            jmin = 1; jmax = 0; imin = 1; imax = 0;
+            valid = 1.0f;
+        }
+    }
+    out[4] = make_float4(__int_as_float(jmin), __int_as_float(jmax), __int_as_float(imin), __int_as_float(imax));
+    out[5] = make_float4(A00, A01, A11, valid);
+    out[6] = make_float4(b0, b1, c0, det);
+}
+
+// Transposing butterfly: 16 per-lane values -> lane L holds the wave total of value (L >> 2).
+__device__ inline float wave_reduce16(float v[16]) {
+    const int lane = threadIdx.x & 63;
+    {
+        const bool hi = lane & 32;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float send = hi ? v[i] : v[i + 8], keep = hi ? v[i + 8] : v[i];
+            v[i] = keep + __shfl_xor(send, 32, 64);
+        }
+    }
+    {
+        const bool hi = lane & 16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float send = hi ? v[i] : v[i + 4], keep = hi ? v[i + 4] : v[i];
+            v[i] = keep + __shfl_xor(send, 16, 64);
+        }
+    }
+    {
+        const bool hi = lane & 8;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float send = hi ? v[i] : v[i + 2], keep = hi ? v[i + 2] : v[i];
+            v[i] = keep + __shfl_xor(send, 8, 64);
+        }
+    }
+    float r;
+    {
+        const bool hi = lane & 4;
+        float send = hi ? v[0] : v[1], keep = hi ? v[1] : v[0];
+        r = keep + __shfl_xor(send, 4, 64);
+    }
+    r += __shfl_xor(r, 2, 64);
+    r += __shfl_xor(r, 1, 64);
+    return r;
+}
+
+struct RasterFinish {     // what a kernel outside raster.hip needs to run the finishing step (partial == nullptr: nothing to do)
+    const float* cam = nullptr;
+    const unsigned long long* masks = nullptr;
+    const float* partial = nullptr;
+    const float* scale = nullptr;      // device scalar: upstream gradient of the fused total (nullptr = 1)
+    int ntile = 0, words = 0;
+};
+
+// Finishing step of the raster backward for primitive bk = b * K + k, executed by ONE WAVE: sum the per-tile
+// partials of the tiles whose mask holds k (lane = tile, fixed order), reduce, and apply the chain rule from the 12
+// ray coefficients to (v,q,t).  Lane 0 returns r[10] = d loss / d(v0 v1 v2 q0 q1 q2 q3 t0 t1 t2) for an upstream
+// gradient of 1.
+__device__ inline void raster_finish_wave(const float* __restrict__ params, const float* __restrict__ cam, int bk, int K,
+                                          int ntile, int words, const unsigned long long* __restrict__ masks,
+                                          const float* __restrict__ partial, float r[10]) {
+    const int lane = threadIdx.x & 63;
+    const int b = bk / K, k = bk - b * K;
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = 0.0f;
+    for (int tile = lane; tile < ntile; tile += 64) {
+        const unsigned long long m = masks[((size_t)b * ntile + tile) * words + (k >> 6)];
+        if (!((m >> (k & 63)) & 1ull)) continue;                                   // nothing was written for this pair
+        const float4* src = reinterpret_cast<const float4*>(partial + ((size_t)bk * ntile + tile) * 12);
+        const float4 a = src[0], c = src[1], d = src[2];
+        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+        v[4] += c.x; v[5] += c.y; v[6] += c.z; v[7] += c.w;
+        v[8] += d.x; v[9] += d.y; v[10] += d.z; v[11] += d.w;
+    }
+    const float tot = wave_reduce16(v);
+    // gather the 12 totals into lane 0
+    float G[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) G[i] = __shfl(tot, i * 4, 64);
+    if (lane != 0) return;
+    const float* prm = params + (size_t)bk * VPN_PARAM_STRIDE;
+    const Camera C = make_camera(cam + b * 3);
+    const Pose P = make_pose(prm[3], prm[4], prm[5], prm[6]);
+    const float vv[3] = {prm[0], prm[1], prm[2]};
+    const float t[3] = {prm[7], prm[8], prm[9]};
+    PrimGeo Ge;
+    prim_geometry(C, P.R, vv, t, Ge);
+    const float e[3] = {C.eye[0] - t[0], C.eye[1] - t[1], C.eye[2] - t[2]};
+    float gv[3], gyo[3], gyr[3], gyu[3], gyf[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float iv = 1.0f / vv[a];
+        gv[a] = -(G[a] * Ge.o[a] + G[3 + a] * Ge.Mr[a] + G[6 + a] * Ge.Mu[a] + G[9 + a] * Ge.Mf[a]) * iv;
+        gyo[a] = G[a] * iv; gyr[a] = G[3 + a] * iv; gyu[a] = G[6 + a] * iv; gyf[a] = G[9 + a] * iv;
+    }
+    float gR[3][3], gt[3], gq[4];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+            gR[r][a] = e[r] * gyo[a] + C.right[r] * gyr[a] + C.up[r] * gyu[a] + C.fwd[r] * gyf[a];
+        gt[r] = -(P.R.m[r][0] * gyo[0] + P.R.m[r][1] * gyo[1] + P.R.m[r][2] * gyo[2]);
+    }
+    pose_backward(P, prm[3], prm[4], prm[5], gR, gq);
+    r[0] = gv[0]; r[1] = gv[1]; r[2] = gv[2]; r[3] = gq[0]; r[4] = gq[1]; r[5] = gq[2]; r[6] = gq[3];
+    r[7] = gt[0]; r[8] = gt[1]; r[9] = gt[2];
+}
+
+}  // namespace vpn

@@ -553,10 +553,12 @@ class HotPathLossFunction(Function):
         gvec = pattern * grad_total                             # one small kernel: d total / d loss_b [B]
         # Chamfer backward and sampler backward in one launch: the [B,N,3] point gradient never exists
         grad_params = torch.empty_like(params)
-        if M <= FUSED_BWD_MAX_GT:
-            _lib.call('vpn_sample_chamfer_bwd', _lib.ptr(params), _lib.ptr(kinds), None, seed, seed_dev, base, B, K, n,
+        if M <= FUSED_BWD_MAX_GT:          # ... and the raster's finishing step rides in the same launch
+            _lib.call('vpn_hotpath_bwd', _lib.ptr(params), _lib.ptr(kinds), None, seed, seed_dev, base, B, K, n,
                       _lib.ptr(points), _lib.ptr(gt_points), M, _lib.ptr(d1), _lib.ptr(i1), _lib.ptr(d2), _lib.ptr(i2),
-                      _lib.ptr(gvec), cd_w1, cd_w2, _lib.ptr(grad_params), s)
+                      _lib.ptr(gvec), cd_w1, cd_w2, _lib.ptr(cam), H, W, _lib.ptr(rec), _lib.ptr(rws),
+                      _lib.ptr(grad_total), _lib.ptr(grad_params), s)
+            return (grad_params,) + (None,) * 19
         else:                                                   # GT clouds beyond the fused kernel's LDS match lists
             grad_points = torch.empty_like(points)
             _lib.call('vpn_chamfer_bwd', _lib.ptr(points), _lib.ptr(gt_points), _lib.ptr(d1), _lib.ptr(i1), _lib.ptr(d2),
