@@ -267,9 +267,14 @@ int vpn_head_pack_bwd(const float* volumes, const float* rotates, const float* t
  * assignment [B,n] int32.  The nine scratch tensors the reference's caller allocates (emd_module.py:44-54)
  * become one workspace of vpn_emd_workspace(B, n) bytes.  iters >= 1, eps >= 0.  n need not be a multiple
  * of 1024 and B is not limited to 512 (emd_module.py:38-39). */
+/* max_group: cap on the number of workgroups that cooperate on one sample (0 = automatic: as many as can be
+ * resident together, power of two <= 16; 1 = one workgroup per sample, no inter-workgroup barrier).  With more than
+ * one the kernel is launched cooperatively (the runtime checks residency; the call falls back to 1 if it refuses) and
+ * its group barrier gives up after ~0.5 s (dist = NaN, assignment = -1 for that sample) rather than hang when
+ * something else holds the CUs: pass 1 when other streams or processes share the GPU.  Results do not depend on it. */
 size_t vpn_emd_workspace(int B, int n);
 int vpn_emd_fwd(const float* xyz1, const float* xyz2, int B, int n, float eps, int iters,
-                float* dist, int32_t* assignment, void* workspace, void* stream);
+                float* dist, int32_t* assignment, void* workspace, int max_group, void* stream);
 /* grad_xyz1 [B,n,3] = 2 grad_dist (xyz1 - xyz2[assignment]) is written; xyz2 receives no gradient
  * (emd_module.py:66-70 returns zeros for it). */
 int vpn_emd_bwd(const float* xyz1, const float* xyz2, const float* grad_dist, const int32_t* assignment,

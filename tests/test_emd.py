@@ -79,9 +79,9 @@ def test_cabi_validation_and_surface():
     import vpn_amd
     import vpn_amd._lib as lib
     L = lib.lib()
-    assert L.vpn_emd_workspace(3, 1000) == 3 * 1000 * 8 * 4 + 16      # state + one barrier counter per sample
+    assert L.vpn_emd_workspace(3, 1000) == 3 * 1000 * 8 * 4 + 24      # state + (arrival counter, gave-up flag) per sample
     assert L.vpn_emd_workspace(0, 5) == 0
-    assert L.vpn_emd_fwd(None, None, 1, 8, 0.005, 50, None, None, None, None) == -1
+    assert L.vpn_emd_fwd(None, None, 1, 8, 0.005, 50, None, None, None, 0, None) == -1
     assert L.vpn_emd_bwd(None, None, None, None, 1, 8, None, None) == -1
     from vpn_amd.modules import loss
     assert list(inspect.signature(loss.EarthMoverDistanceLoss.forward).parameters) == \
@@ -170,3 +170,19 @@ def test_emd_reference_selfcheck_at_full_size(emd):
     assert torch.equal(assign, assign2) and torch.equal(dist, dist2)
     emd_value = dist.sqrt().mean().item()
     assert 0.02 < emd_value < 0.2                               # uniform clouds in the unit cube
+
+
+@pytest.mark.gpu
+def test_emd_group_size_does_not_change_the_result():
+    """The workgroups of a sample's group (cooperative launch, inter-workgroup barrier) versus one workgroup per sample
+    (max_group = 1, what the op uses when other streams share the GPU): bit-identical assignments and distances."""
+    import vpn_amd
+    from vpn_amd.ops import EmdFunction
+    for B, n, eps, iters in ((8, 2048, 0.005, 50), (3, 1000, 0.01, 30), (1, 4100, 0.005, 20)):
+        x1, x2 = _clouds(B, n, 900 + n)
+        a, b = x1.to(DEV), x2.to(DEV)
+        d0, i0 = EmdFunction.apply(a, b, eps, iters, 0)       # automatic: up to 16 workgroups per sample
+        d1, i1 = EmdFunction.apply(a, b, eps, iters, 1)
+        d2, i2 = EmdFunction.apply(a, b, eps, iters, 4)
+        assert torch.equal(i0, i1) and torch.equal(d0, d1) and torch.equal(i0, i2) and torch.equal(d0, d2)
+        assert bool(torch.isfinite(d0).all()) and int(i0.min()) >= 0

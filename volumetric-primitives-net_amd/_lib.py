@@ -51,7 +51,7 @@ SIGNATURES = {
     'vpn_head_pack_fwd': (_i, [_c_f, _c_f, _c_f, _i, _i, _i, _f, _f, _f, _f, _f, _c_f, _c_f]),
     'vpn_head_pack_bwd': (_i, [_c_f, _c_f, _c_f, _c_f, _i, _i, _i, _f, _f, _f, _f, _f, _c_f, _c_f, _c_f, _c_f]),
     'vpn_emd_workspace': (_sz, [_i, _i]),
-    'vpn_emd_fwd': (_i, [_c_f, _c_f, _i, _i, _f, _i, _c_f, _c_f, _c_f, _c_f]),
+    'vpn_emd_fwd': (_i, [_c_f, _c_f, _i, _i, _f, _i, _c_f, _c_f, _c_f, _i, _c_f]),
     'vpn_emd_bwd': (_i, [_c_f, _c_f, _c_f, _c_f, _i, _i, _c_f, _c_f]),
 }
 

@@ -898,6 +898,10 @@ __global__ __launch_bounds__(CF_THREADS) void chamfer_fixup_kernel(const FixJob 
             float sc = s[0]; int qc = q[0];
 #pragma unroll
             for (int e = 1; e < CF_Q; ++e) { sc = c == e ? s[e] : sc; qc = c == e ? q[e] : qc; }
+            // the query number comes from a list entry: entries below `count` were written by the scan kernel, but a
+            // store address must not depend on that alone (an ablation build that dropped the `count` guard above
+            // faulted on a stale entry: DESIGN.md Finding 4)
+            qc = min(max(qc, 0), Nq - 1);
             out_dist[(size_t)b * Nq + qc] = sc;
             out_idx[(size_t)b * Nq + qc] = min(min(redi[c][0], redi[c][1]), min(redi[c][2], redi[c][3]));
         }
@@ -1166,6 +1170,12 @@ __global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_kernel(const ScanJob
     // the (padded) feature planes: 4 float4 per coordinate
     float d2[16];
     float m2 = __builtin_inff();
+#ifdef VPN_CHAMFER_DEBUG
+    if (K < 0 || K + 32 > Ntp || (K & 31)) atomicAdd(&g_dbg[7], 1ull);    // the block index the gather below trusts
+#endif
+    // K is a multiple of 32 below Ntp by construction (tile base + block number inside the tile); the clamp costs one
+    // instruction per query and keeps the gather inside the padded planes whatever happened upstream
+    K = min(max(K, 0), Ntp - 32);
     {
         const int base = K + half * 16;
         const float4* px4 = reinterpret_cast<const float4*>(Fb + base);

@@ -60,19 +60,36 @@ __device__ inline T emd_ld(const T* p) { return __hip_atomic_load(p, __ATOMIC_RE
 template <typename T>
 __device__ inline void emd_st(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// Barrier over the G workgroups of one sample (all resident: the host keeps B*G within the CU count).  Every
-// wave first waits for its own stores and atomics to be acknowledged (vmcnt counts stores on gfx9).
-__device__ inline void emd_group_sync(unsigned* counter, unsigned& passed, int G) {
-    if (G == 1) { __syncthreads(); return; }
+// Barrier over the G workgroups of one sample.  Protocol (the hand-off form MI355X_MICROARCH.md lists as valid
+// without cache-wide fences): every byte of shared state is stored and loaded with agent-scope (sc1) accesses
+// (emd_st / emd_ld); every wave waits for its own stores and atomics to be acknowledged (vmcnt counts stores on gfx9)
+// BEFORE the workgroup barrier; only then one lane adds to the group's counter and polls it with sc1 loads; the other
+// waves load shared state only after the second workgroup barrier.
+// Co-residency of the G workgroups is required while they spin: the host launches this kernel COOPERATIVELY when
+// G > 1 (the runtime rejects a grid that cannot be resident) and falls back to G = 1 otherwise.  As a last resort
+// the spin is bounded: after ~1 s (other work holding the CUs, a partitioned device) the workgroup gives up, flags
+// the sample and the kernel writes NaN distances for it instead of hanging the GPU.
+constexpr unsigned EMD_SPIN_LIMIT = 1u << 24;          // x s_sleep(1) = 64 cycles each: ~0.5 s at 2.1 GHz
+
+__device__ inline bool emd_group_sync(unsigned* counter, unsigned& passed, int G, int* gave_up) {
+    if (G == 1) { __syncthreads(); return true; }
     __asm__ volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
     passed += G;
     if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < passed)
+        unsigned spins = 0;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < passed) {
             __builtin_amdgcn_s_sleep(1);
+            if (++spins > EMD_SPIN_LIMIT || __hip_atomic_load(counter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                __hip_atomic_store(counter + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // tell the others
+                *gave_up = 1;
+                break;
+            }
+        }
     }
     __syncthreads();
+    return *gave_up == 0;
 }
 
 // grid: (ceil(B/8) * 8 * G) workgroups; the G workgroups of a sample sit on one XCD (workgroups are dealt to the
@@ -84,6 +101,8 @@ __global__ __launch_bounds__(EMD_THREADS) void emd_auction_kernel(const float* _
                                                                   float* wsf, unsigned* counters) {
     __shared__ __attribute__((aligned(16))) float tx[EMD_TILE], ty[EMD_TILE], tz[EMD_TILE], tp[EMD_TILE];
     __shared__ int wcount[EMD_WAVES];
+    __shared__ int gave_up;
+    if (threadIdx.x == 0) gave_up = 0;
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
     const int b = (q / G) * 8 + xcd, g = q % G;
     if (b >= B) return;                                         // padding workgroups of a ragged batch
@@ -100,16 +119,17 @@ __global__ __launch_bounds__(EMD_THREADS) void emd_auction_kernel(const float* _
     float* second = base + 5 * n;                               // per point: running second best
     int* bid = reinterpret_cast<int*>(base + 6 * n);            // per point: target it bids for
     int* ulist = reinterpret_cast<int*>(base + 7 * n);          // unassigned points, ascending
-    unsigned* counter = counters + b;
+    unsigned* counter = counters + 2 * b;                       // [arrivals, gave-up flag] of this sample's group
     unsigned passed = 0;
+    bool ok = true;
 
     for (int j = gtid; j < n; j += gthreads) {                  // emd_module.py:44-50 initial state
         emd_st(assign + j, -1); emd_st(assign_inv + j, -1); emd_st(price + j, 0.0f); emd_st(top + j, 0ull);
     }
-    emd_group_sync(counter, passed, G);
+    ok = emd_group_sync(counter, passed, G, &gave_up);
 
     const int per = (n + EMD_THREADS - 1) / EMD_THREADS, j0 = min(n, tid * per), j1 = min(n, j0 + per);
-    for (int it = 0; it < iters; ++it) {
+    for (int it = 0; ok && it < iters; ++it) {
         const bool last = it == iters - 1;
         // ---- unassigned points in ascending order (calc_unass_cnt .. calc_unass_idx :30-93; the reference's order
         //      depends on atomics, the bids do not depend on the order).  Every workgroup of the sample builds the
@@ -190,7 +210,7 @@ __global__ __launch_bounds__(EMD_THREADS) void emd_auction_kernel(const float* _
                 }
             }
         }
-        emd_group_sync(counter, passed, G);
+        if (!(ok = emd_group_sync(counter, passed, G, &gave_up))) break;
 
         // ---- Assign (:196-215): each workgroup settles the bidders it bid for (bid / inc stay CU-local)
         for (int v = tid; v < (U + G * EMD_WAVES - 1) / (G * EMD_WAVES) * EMD_WAVES; v += EMD_THREADS) {
@@ -208,9 +228,13 @@ __global__ __launch_bounds__(EMD_THREADS) void emd_auction_kernel(const float* _
             emd_st(price + t, pt + inc[i]);
             emd_st(top + t, 0ull);                              // :212
         }
-        emd_group_sync(counter, passed, G);
+        ok = emd_group_sync(counter, passed, G, &gave_up);
     }
 
+    if (!ok) {                                                  // the group barrier timed out: no result for this sample
+        for (int j = gtid; j < n; j += gthreads) { dist[(size_t)b * n + j] = __builtin_nanf(""); assign[j] = -1; }
+        return;
+    }
     for (int j = gtid; j < n; j += gthreads) {                  // CalcDist :217-226
         const int t = emd_ld(assign + j);
         const float dx = p1[j * 3] - p2[t * 3], dy = p1[j * 3 + 1] - p2[t * 3 + 1], dz = p1[j * 3 + 2] - p2[t * 3 + 2];
@@ -238,17 +262,21 @@ __global__ __launch_bounds__(256) void emd_bwd_kernel(const float* __restrict__ 
 
 using namespace vpn;
 
-static int emd_group_size(int B, int n) {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-            cus = 8;
-    }
+// Largest group size G (power of two) such that the whole grid is resident: workgroups per CU from the occupancy
+// query of THIS kernel on the CURRENT device (asked every call: nothing is cached across devices) times its CU
+// count.  max_group caps it (1 = no inter-workgroup barrier at all).
+static int emd_group_size(int B, int n, int max_group) {
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        return 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, emd_auction_kernel, EMD_THREADS, 0) != hipSuccess || per_cu <= 0)
+        return 1;
+    const long long slots = (long long)cus * per_cu;
     const int padded = (B + 7) / 8 * 8;
-    int G = 1;                                   // every workgroup of the launch must be resident: B*G <= CUs
-    while (G * 2 <= EMD_MAX_GROUP && padded * G * 2 <= cus && G * 2 * EMD_WAVES * 4 <= n) G *= 2;
+    const int cap = max_group > 0 && max_group < EMD_MAX_GROUP ? max_group : EMD_MAX_GROUP;
+    int G = 1;
+    while (G * 2 <= cap && (long long)padded * G * 2 <= slots && G * 2 * EMD_WAVES * 4 <= n) G *= 2;
     return G;
 }
 
@@ -256,22 +284,37 @@ static size_t emd_state_bytes(int B, int n) { return (size_t)B * n * EMD_WS_PLAN
 
 extern "C" size_t vpn_emd_workspace(int B, int n) {
     if (B <= 0 || n <= 0) return 0;
-    return emd_state_bytes(B, n) + ((size_t)B * sizeof(unsigned) + 7) / 8 * 8;
+    return emd_state_bytes(B, n) + ((size_t)2 * B * sizeof(unsigned) + 7) / 8 * 8;
 }
 
 extern "C" int vpn_emd_fwd(const float* xyz1, const float* xyz2, int B, int n, float eps, int iters, float* dist,
-                           int32_t* assignment, void* workspace, void* stream) {
+                           int32_t* assignment, void* workspace, int max_group, void* stream) {
     if (!xyz1 || !xyz2 || !dist || !assignment || !workspace || B < 0 || n < 0 || iters < 1 || !(eps >= 0.0f))
         return VPN_E_BADARG;
     if ((long long)B * n * 3 > 0x7fffffffLL) return VPN_E_TOOBIG;
     if (((uintptr_t)workspace & 7) != 0) return VPN_E_BADARG;
     if (B == 0 || n == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    const int G = emd_group_size(B, n);
+    int G = emd_group_size(B, n, max_group);
     unsigned* counters = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + emd_state_bytes(B, n));
-    if (hipMemsetAsync(counters, 0, (size_t)B * sizeof(unsigned), s) != hipSuccess) return (int)hipGetLastError();
+    if (hipMemsetAsync(counters, 0, (size_t)2 * B * sizeof(unsigned), s) != hipSuccess) return (int)hipGetLastError();
+    float* wsf = (float*)workspace;
+    if (G > 1) {
+        // the G workgroups of a sample synchronise with each other: a COOPERATIVE launch makes the runtime check that
+        // the whole grid can be resident at once; if it says no, fall back to one workgroup per sample
+        void* args[] = {(void*)&xyz1, (void*)&xyz2, (void*)&B, (void*)&n, (void*)&G, (void*)&eps, (void*)&iters,
+                        (void*)&dist, (void*)&assignment, (void*)&wsf, (void*)&counters};
+        vpn::prof_begin("emd_auction_kernel", s);
+        const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(emd_auction_kernel),
+                                                        dim3((B + 7) / 8 * 8 * G), dim3(EMD_THREADS), args, 0, s);
+        vpn::prof_end(s);
+        if (e == hipSuccess) return 0;
+        (void)hipGetLastError();
+        if (e != hipErrorCooperativeLaunchTooLarge && e != hipErrorNotSupported && e != hipErrorInvalidConfiguration) return (int)e;
+        G = 1;
+    }
     VPN_LAUNCH(emd_auction_kernel, dim3((B + 7) / 8 * 8 * G), dim3(EMD_THREADS), 0, s, xyz1, xyz2, B, n, G, eps, iters,
-               dist, assignment, (float*)workspace, counters);
+               dist, assignment, wsf, counters);
     VPN_LAUNCH_CHECK();
     return 0;
 }

@@ -291,7 +291,9 @@ class EmdFunction(Function):
     point, assignment [B,n] int32).  The reference's nine scratch tensors are one workspace here."""
 
     @staticmethod
-    def forward(ctx, xyz1, xyz2, eps, iters):
+    def forward(ctx, xyz1, xyz2, eps, iters, max_group=None):
+        """max_group: workgroups per sample (None: VPN_EMD_GROUP or automatic; 1: no inter-workgroup barrier -- forced
+        when other streams share the GPU (VPN_CONCURRENT=1), because the group barrier needs the whole grid resident)."""
         B, n, _ = xyz1.size()
         assert n == xyz2.size(1)                       # emd_module.py:36-37
         assert B == xyz2.size(0)
@@ -300,8 +302,10 @@ class EmdFunction(Function):
         dist = torch.empty((B, n), dtype=torch.float32, device=dev)
         assignment = torch.empty((B, n), dtype=torch.int32, device=dev)
         ws = torch.empty((max(1, _lib.lib().vpn_emd_workspace(B, n) // 4),), dtype=torch.float32, device=dev)
+        if max_group is None:
+            max_group = 1 if CONCURRENT_BRANCHES else int(os.environ.get('VPN_EMD_GROUP', '0'))
         _lib.call('vpn_emd_fwd', _lib.ptr(xyz1), _lib.ptr(xyz2), B, n, float(eps), int(iters), _lib.ptr(dist),
-                  _lib.ptr(assignment), _lib.ptr(ws), _lib.stream())
+                  _lib.ptr(assignment), _lib.ptr(ws), int(max_group), _lib.stream())
         ctx.save_for_backward(xyz1, xyz2, assignment)
         ctx.mark_non_differentiable(assignment)
         return dist, assignment
@@ -315,7 +319,7 @@ class EmdFunction(Function):
         _lib.call('vpn_emd_bwd', _lib.ptr(xyz1), _lib.ptr(xyz2), _lib.ptr(g), _lib.ptr(assignment), B, n,
                   _lib.ptr(g1), _lib.stream())
         g2 = torch.zeros_like(xyz2) if ctx.needs_input_grad[1] else None     # emd_module.py:67
-        return g1, g2, None, None
+        return g1, g2, None, None, None
 
 
 class RasterFunction(Function):
