@@ -13,6 +13,15 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # tests/test_dist_gpu.py forks its rank processes from a fork SERVER; the server itself is spawned (fork + exec) here,
+    # before any test has initialised the GPU: a process that has touched the GPU must never exec (the pool forbids it)
+    import multiprocessing
+    import multiprocessing.forkserver as fs
+    try:
+        multiprocessing.get_context('forkserver')
+        fs.ensure_running()
+    except Exception:              # no fork server on this platform: the test that needs it fails by itself
+        pass
 
 
 def load_golden(name):
