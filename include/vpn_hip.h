@@ -203,10 +203,18 @@ int vpn_raster_loss_bwd(const float* params, const int32_t* kinds, const float* 
  * then needs 16 + 16 B bytes, zeroed once by the caller).
  * vpn_raster_total_bwd (when backward runs): grad_params (+)= (*grad_total) * d total_img / d params from the
  * partials; grad_total is a DEVICE scalar (NULL = 1). */
+/* records_ready != 0: `records` were already written (and the counter at the head of loss_ws zeroed) by
+ * vpn_hotpath_sample_fwd for the same (params, kinds, cam, H, W, sigma): the record launch is skipped. */
 int vpn_raster_total_fwd(const float* params, const int32_t* kinds, const float* cam,
                          int B, int K, int H, int W, float sigma, float gamma, float z_far,
                          const float* gt_sil, const float* gt_depth, int sil_mse, float w_sil, float w_dep,
-                         void* records, void* loss_ws, void* workspace, void* stream);
+                         void* records, void* loss_ws, void* workspace, int records_ready, void* stream);
+/* vpn_sample_fwd of the training step: the same launch also writes the raster records of the primitives it samples
+ * (one workgroup per (sample, primitive) in both) and zeroes the arrival counter of loss_ws. */
+int vpn_hotpath_sample_fwd(const float* params, const int32_t* kinds, const float* u,
+                           uint64_t seed, const uint64_t* seed_dev, uint64_t sample_base, int B, int K, int n,
+                           float* points, const float* cam, int H, int W, float sigma, void* records, void* loss_ws,
+                           void* stream);
 int vpn_loss_finalize(void* loss_ws, int B, int H, int W, const float* dist1, const float* dist2, int N, int M,
                       float cd_w1, float cd_w2, float w_cd, float w_sil, float w_dep, float* losses, float* loss_b,
                       void* stream);

@@ -41,7 +41,7 @@ def test_argument_validation_needs_no_gpu():
     assert L.vpn_sample_fwd(None, None, None, 0, None, 0, 1, 1, 1, None, None) == -1
     assert L.vpn_raster_fwd(None, None, None, 1, 1, 8, 8, 0.1, 0.1, 2.0, None, None, None, None, None) == -1
     assert L.vpn_raster_loss_fwd(None, None, None, 1, 1, 8, 8, 0.1, 0.1, 2.0, None, None, 0, None, None, None, None, None) == -1
-    assert L.vpn_raster_total_fwd(None, None, None, 1, 1, 8, 8, 0.1, 0.1, 2.0, None, None, 0, 1.0, 1.0, None, None, None, None) == -1
+    assert L.vpn_raster_total_fwd(None, None, None, 1, 1, 8, 8, 0.1, 0.1, 2.0, None, None, 0, 1.0, 1.0, None, None, None, 0, None) == -1
     assert L.vpn_loss_finalize(None, 1, 8, 8, None, None, 0, 0, 1.0, 1.0, 1.0, 1.0, 1.0, None, None, None) == -1
     assert L.vpn_raster_total_bwd(None, None, 1, 1, 8, 8, None, None, None, None, 0, None) == -1
     assert L.vpn_camera_transform_fwd(None, None, None, None, None, 1, 8, 1, None, None) == -1

@@ -851,13 +851,13 @@ extern "C" int vpn_raster_loss_bwd(const float* params, const int32_t* kinds, co
 extern "C" int vpn_raster_total_fwd(const float* params, const int32_t* kinds, const float* cam, int B, int K, int H,
                                     int W, float sigma, float gamma, float z_far, const float* gt_sil,
                                     const float* gt_depth, int sil_mse, float w_sil, float w_dep, void* records,
-                                    void* loss_ws, void* workspace, void* stream) {
+                                    void* loss_ws, void* workspace, int records_ready, void* stream) {
     int rc = raster_check(params, kinds, cam, B, K, H, W, sigma, gamma);
     if (rc) return rc;
     if (!records || !loss_ws || !workspace) return VPN_E_BADARG;
     if (((uintptr_t)records & 15) != 0 || ((uintptr_t)workspace & 15) != 0 || ((uintptr_t)loss_ws & 15) != 0) return VPN_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
-    if ((rc = launch_prep(params, kinds, cam, B, K, H, W, sigma, records, (int*)loss_ws, s))) return rc;
+    if (!records_ready && (rc = launch_prep(params, kinds, cam, B, K, H, W, sigma, records, (int*)loss_ws, s))) return rc;
     const Grid G = raster_grid(B, K, H, W);
     LossArgs la{gt_sil, gt_depth, sil_mse, 1.0f / ((float)B * (float)H * (float)W), tile_loss_of(loss_ws, B), nullptr, w_sil, w_dep};
     VPN_LAUNCH(raster_total_kernel, G.g, dim3(64), 0, s, (const float4*)records, masks_of(records, B, K), cam, B, K,

@@ -77,12 +77,22 @@ __device__ inline void load_prim(PrimLds& P, const float* prm, int kind, int n) 
 __global__ __launch_bounds__(SAMP_BLOCK) void sample_fwd_kernel(
     const float* __restrict__ params, const int32_t* __restrict__ kinds, const float* __restrict__ u,
     uint64_t seed, const uint64_t* __restrict__ seed_dev, uint64_t sample_base, int K, int n,
-    float* __restrict__ points) {
+    float* __restrict__ points, const RasterPrep rp) {
     __shared__ PrimLds P;
     if (seed_dev) seed += *seed_dev;
     const int k = blockIdx.x, b = blockIdx.y;
     const float* prm = params + ((size_t)b * K + k) * VPN_PARAM_STRIDE;
     if (threadIdx.x == 0) load_prim(P, prm, kinds[k], n);
+    // the training step renders the same primitives: their raster records (pose, ray coefficients, culling conic) are
+    // written here by the second wave while the first one computes the sampler's pose -- one launch less per step
+    if (rp.rec && threadIdx.x == 64) {
+        float4 r[R_REC];
+        make_record(prm, kinds[k] == VPN_SPHERE ? VPN_SPHERE : VPN_CUBOID, rp.cam, b, rp.H, rp.W, rp.sigma, r);
+        float4* out = rp.rec + ((size_t)b * K + k) * R_REC;
+#pragma unroll
+        for (int i = 0; i < R_REC; ++i) out[i] = r[i];
+    }
+    if (rp.zero_me && threadIdx.x >= 128 && threadIdx.x < 132 && k == 0 && b == 0) rp.zero_me[threadIdx.x - 128] = 0;
     __syncthreads();
     const float tx = prm[7], ty = prm[8], tz = prm[9];
     const float* ub = u ? u + ((size_t)b * K + k) * n * 3 : nullptr;
@@ -532,16 +542,35 @@ __global__ __launch_bounds__(TR_BLOCK) void camera_transform_kernel(
 
 using namespace vpn;
 
-extern "C" int vpn_sample_fwd(const float* params, const int32_t* kinds, const float* u, uint64_t seed,
-                              const uint64_t* seed_dev, uint64_t sample_base, int B, int K, int n, float* points,
-                              void* stream) {
+static int launch_sample_fwd(const float* params, const int32_t* kinds, const float* u, uint64_t seed,
+                             const uint64_t* seed_dev, uint64_t sample_base, int B, int K, int n, float* points,
+                             const RasterPrep& rp, void* stream) {
     if (!params || !kinds || !points) return VPN_E_BADARG;
     if (B <= 0 || K <= 0 || n <= 0) return VPN_E_BADARG;
     if (B > 65535) return VPN_E_TOOBIG;
     VPN_LAUNCH(sample_fwd_kernel, dim3(K, B), dim3(SAMP_BLOCK), 0, (hipStream_t)stream, params, kinds, u,
-                       seed, seed_dev, sample_base, K, n, points);
+                       seed, seed_dev, sample_base, K, n, points, rp);
     VPN_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int vpn_sample_fwd(const float* params, const int32_t* kinds, const float* u, uint64_t seed,
+                              const uint64_t* seed_dev, uint64_t sample_base, int B, int K, int n, float* points,
+                              void* stream) {
+    return launch_sample_fwd(params, kinds, u, seed, seed_dev, sample_base, B, K, n, points, RasterPrep{}, stream);
+}
+
+// sampler forward of the training step: also writes the raster records of the same primitives (what the first launch
+// of vpn_raster_total_fwd would compute) and zeroes the arrival counter at the head of loss_ws
+extern "C" int vpn_hotpath_sample_fwd(const float* params, const int32_t* kinds, const float* u, uint64_t seed,
+                                      const uint64_t* seed_dev, uint64_t sample_base, int B, int K, int n, float* points,
+                                      const float* cam, int H, int W, float sigma, void* records, void* loss_ws,
+                                      void* stream) {
+    if (!cam || !records || H <= 0 || W <= 0 || !(sigma > 0.f) || K > VPN_MAX_PRIMS) return VPN_E_BADARG;
+    if (((uintptr_t)records & 15) != 0) return VPN_E_BADARG;
+    RasterPrep rp;
+    rp.cam = cam; rp.H = H; rp.W = W; rp.sigma = sigma; rp.rec = (float4*)records; rp.zero_me = (int*)loss_ws;
+    return launch_sample_fwd(params, kinds, u, seed, seed_dev, sample_base, B, K, n, points, rp, stream);
 }
 
 extern "C" int vpn_sample_bwd(const float* params, const int32_t* kinds, const float* u, uint64_t seed,

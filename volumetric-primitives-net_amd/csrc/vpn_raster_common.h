@@ -162,6 +162,14 @@ __device__ inline float wave_reduce16(float v[16]) {
     return r;
 }
 
+struct RasterPrep {       // what a kernel outside raster.hip needs to write the raster records (rec == nullptr: nothing to do)
+    const float* cam = nullptr;
+    float4* rec = nullptr;
+    int* zero_me = nullptr;            // 4 ints: arrival counter of the loss finalisation
+    int H = 0, W = 0;
+    float sigma = 0.f;
+};
+
 struct RasterFinish {     // what a kernel outside raster.hip needs to run the finishing step (partial == nullptr: nothing to do)
     const float* cam = nullptr;
     const unsigned long long* masks = nullptr;

@@ -428,7 +428,7 @@ class RasterTotalFunction(Function):
         losses = torch.empty((4,), dtype=torch.float32, device=dev)
         _lib.call('vpn_raster_total_fwd', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(cam), B, K, H, W, float(sigma),
                   float(gamma), float(z_far), _lib.ptr(gt_sil), _lib.ptr(gt_depth), int(bool(sil_mse)), float(w_sil),
-                  float(w_dep), _lib.ptr(rec), _lib.ptr(lws), _lib.ptr(ws), s)
+                  float(w_dep), _lib.ptr(rec), _lib.ptr(lws), _lib.ptr(ws), 0, s)
         _lib.call('vpn_loss_finalize', _lib.ptr(lws), B, H, W, None, None, 0, 0, 0.0, 0.0, 0.0, float(w_sil), float(w_dep),
                   _lib.ptr(losses), None, s)
         ctx.save_for_backward(params, cam, rec, ws)
@@ -505,10 +505,10 @@ class HotPathLossFunction(Function):
         rws = torch.empty((L.vpn_raster_bwd_workspace(B, K, H, W) // 4,), dtype=torch.float32, device=dev)
         losses = torch.empty((4,), dtype=torch.float32, device=dev)
 
-        def raster_branch(stream):
+        def raster_branch(stream, records_ready):
             _lib.call('vpn_raster_total_fwd', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(cam), B, K, H, W, float(sigma),
                       float(gamma), float(z_far), _lib.ptr(gt_sil), _lib.ptr(gt_depth), sil_mse, float(w_sil),
-                      float(w_depth), _lib.ptr(rec), _lib.ptr(lws), _lib.ptr(rws), stream)
+                      float(w_depth), _lib.ptr(rec), _lib.ptr(lws), _lib.ptr(rws), records_ready, stream)
 
         main = torch.cuda.current_stream()
         # optionally the raster branch (independent of the sampler + Chamfer branch until the finalisation) runs on a
@@ -517,13 +517,18 @@ class HotPathLossFunction(Function):
         if side is not None:
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                raster_branch(_lib.stream())
+                raster_branch(_lib.stream(), 0)
                 for t in (params, kinds, cam, gt_sil, gt_depth, rec, lws, rws):
                     if t is not None:
                         t.record_stream(side)
         points = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
-        _lib.call('vpn_sample_fwd', _lib.ptr(params), _lib.ptr(kinds), None, seed_host, seed_dev, int(sample_base), B, K,
-                  n, _lib.ptr(points), s)
+        if side is None:        # one stream: the sampler's launch also writes the raster records of the same primitives
+            _lib.call('vpn_hotpath_sample_fwd', _lib.ptr(params), _lib.ptr(kinds), None, seed_host, seed_dev,
+                      int(sample_base), B, K, n, _lib.ptr(points), _lib.ptr(cam), H, W, float(sigma), _lib.ptr(rec),
+                      _lib.ptr(lws), s)
+        else:
+            _lib.call('vpn_sample_fwd', _lib.ptr(params), _lib.ptr(kinds), None, seed_host, seed_dev, int(sample_base), B,
+                      K, n, _lib.ptr(points), s)
         d1 = torch.empty((B, N), dtype=torch.float32, device=dev)
         d2 = torch.empty((B, M), dtype=torch.float32, device=dev)
         i1 = torch.empty((B, N), dtype=torch.int32, device=dev)
@@ -534,7 +539,7 @@ class HotPathLossFunction(Function):
         if side is not None:
             main.wait_stream(side)
         else:
-            raster_branch(s)
+            raster_branch(s, 1)
         _lib.call('vpn_loss_finalize', _lib.ptr(lws), B, H, W, _lib.ptr(d1), _lib.ptr(d2), N, M, cd_w1, cd_w2, float(w_cd),
                   float(w_sil), float(w_depth), _lib.ptr(losses), None, s)
         pattern = _grad_pattern(B, w_cd, dev)
