@@ -363,7 +363,8 @@ def main():
     N = K * n
     nn_bytes = B * 16 * (N + M)                       # mean of the two directions: both clouds in, dist + idx out
     alg_bytes = {
-        'chamfer_nn_mfma_kernel<1>': 2 * nn_bytes, 'chamfer_nn_mfma_kernel<0>': 2 * nn_bytes,     # one launch = both directions
+        'chamfer_nn_mfma_kernel<2>': 2 * nn_bytes, 'chamfer_nn_mfma_kernel<1>': 2 * nn_bytes,
+        'chamfer_nn_mfma_kernel<0>': 2 * nn_bytes,                                                 # one launch = both directions
         'chamfer_nn_kernel<R>': nn_bytes,
         'chamfer_nn_pruned_kernel<1>': nn_bytes,
         'raster_fwd_kernel<0>': B * (40 * K + 8 * H * W), 'raster_fwd_kernel<1>': B * (40 * K + 8 * H * W),
@@ -386,12 +387,17 @@ def main():
                     'frac': round(tf / FP32_PEAK_TFLOPS, 4), 'traffic': traffic_of(dom, pmc),
                     'basis': 'ALGORITHMIC fp32 flops (8 per point pair: 3 sub, 3 mul, 2 add) / launch time, priced at the '
                              'fp32 peak of MI355X (157.3 TFLOP/s: vector = fp32-input MFMA, MI355X_MICROARCH.md).  The '
-                             'kernel EXECUTES on the bf16 matrix pipe (exact 3-way bf16 split as a conservative filter, '
-                             'exact fp32 finish): see `executed`',
+                             'kernel EXECUTES on the 16-bit matrix pipe (fp16 / bf16 pieces of the fp32 coordinates as a '
+                             'conservative filter with a rigorous error band, exact fp32 finish): see `executed`',
                     'algorithmic_flops_per_launch': pair_flops, 'avg_launch_us': round(dom_s * 1e6, 2),
                     'hbm_view': {'algorithmic_bytes_per_launch': alg_bytes[dom], 'achieved_GBps': round(hbm_gbs, 2),
                                  'frac_of_8TBps': round(hbm_gbs / HBM_PEAK_GBS, 5)}}
-        if dom.endswith('<1>'):    # v_mfma_f32_32x32x16_bf16 + v_mfma_f32_32x32x8_bf16 per 32x32 pairs = 48 flop per pair
+        if dom.endswith('<2>'):    # ONE v_mfma_f32_32x32x16_f16 per 32x32 pairs = 32 flop per pair (12 of 16 K slots used)
+            ex = 2.0 * 32.0 * B * N * M / dom_s / 1e12
+            roofline['executed'] = {'unit': 'fp16 MFMA', 'instruction': 'v_mfma_f32_32x32x16_f16 (fp32 coordinates scaled by 2^11 and '
+                                    'split into 2 fp16 pieces, 12 of 16 K slots used)', 'achieved_TFLOPs': round(ex, 1),
+                                    'peak_TFLOPs': BF16_PEAK_TFLOPS, 'frac': round(ex / BF16_PEAK_TFLOPS, 4)}
+        elif dom.endswith('<1>'):  # v_mfma_f32_32x32x16_bf16 + v_mfma_f32_32x32x8_bf16 per 32x32 pairs = 48 flop per pair
             ex = 2.0 * 48.0 * B * N * M / dom_s / 1e12
             roofline['executed'] = {'unit': 'bf16 MFMA', 'instruction': 'v_mfma_f32_32x32x16_bf16 + v_mfma_f32_32x32x8_bf16 '
                                     '(fp32 coordinates split exactly into 3 bf16 pieces, 21 of 24 K slots used)',

@@ -229,7 +229,7 @@ def _chamfer_exact(vpn, p1, p2, torch_sqrt_too=True):
     CPU sqrt (MKL VML, <= 1 ulp, see vpn_oracle.chamfer_nn_ieee) indices must still agree and
     distances agree to 1 ulp."""
     m1, j1, m2, j2 = O.chamfer_nn_ieee(p1, p2)
-    for mode in ('brute', 'pruned', 'mfma', 'mfma32', 'sorted'):   # every scan strategy must give the same bits
+    for mode in ('brute', 'pruned', 'mfma', 'mfma32', 'sorted', 'mfma16'):   # every scan strategy must give the same bits
         d1, i1, d2, i2 = vpn.chamfer_nn(g(p1), g(p2), mode=mode)
         assert torch.equal(i1.cpu().long(), j1), 'argmin direction 1 differs (%s)' % mode
         assert torch.equal(i2.cpu().long(), j2), 'argmin direction 2 differs (%s)' % mode
@@ -243,7 +243,7 @@ def _chamfer_exact(vpn, p1, p2, torch_sqrt_too=True):
 @pytest.mark.parametrize('name', ['g4_chamfer_b4_n128_m96', 'g4_chamfer_b2_n257_m2048', 'g4_chamfer_ties'])
 def test_chamfer_golden(vpn, name):
     gd = load_golden(name)
-    for mode in ('brute', 'pruned', 'mfma', 'mfma32', 'sorted'):
+    for mode in ('brute', 'pruned', 'mfma', 'mfma32', 'sorted', 'mfma16'):
         d1, i1, d2, i2 = vpn.chamfer_nn(g(gd['p1']), g(gd['p2']), mode=mode)
         assert torch.equal(i1.cpu(), gd['idx1']) and torch.equal(i2.cpu(), gd['idx2'])
     assert torch.equal(i1.cpu(), gd['idx1']) and torch.equal(i2.cpu(), gd['idx2'])
@@ -292,10 +292,31 @@ def test_chamfer_modes_agree_on_random_shapes(vpn):
         elif kind == 3 and N > 1:                            # duplicated points inside a cloud
             p1[:, N // 2:] = p1[:, :N - N // 2]
         a1, b1, a2, b2 = vpn.chamfer_nn(g(p1), g(p2), mode='brute')
-        for mode in ('mfma', 'mfma32', 'sorted', 'pruned'):
+        for mode in ('mfma', 'mfma32', 'sorted', 'pruned', 'mfma16'):
             d1, i1, d2, i2 = vpn.chamfer_nn(g(p1), g(p2), mode=mode)
             ok = torch.equal(d1, a1) and torch.equal(i1, b1) and torch.equal(d2, a2) and torch.equal(i2, b2)
             assert ok, 'case %d (B=%d N=%d M=%d kind=%d): %s differs from brute force' % (case, B, N, M, kind, mode)
+
+
+def test_chamfer_fp16_filter_domain(vpn):
+    """The fp16 matrix-pipe filter (mode 'mfma16', the default for large clouds) scales coordinates by 2^11 and
+    needs |p|^2 <= 64: clouds outside that range, tiny clouds (pieces in the fp16 subnormal range), clouds far from
+    the origin and mixed magnitudes must all still be bit-exact (out of range = every query goes to the exact fix-up)."""
+    gen = torch.Generator().manual_seed(606)
+    B, N, M = 2, 1500, 700
+    base1, base2 = torch.rand(B, N, 3, generator=gen) - 0.5, torch.rand(B, M, 3, generator=gen) - 0.5
+    for scale, shift in ((1.0, 0.0), (50.0, 0.0), (1.0, 30.0), (1e-4, 0.0), (1e-7, 0.0), (7.9, 0.0), (3.0, 6.5), (1e6, 0.0)):
+        p1, p2 = base1 * scale + shift, base2 * scale + shift
+        a1, b1, a2, b2 = vpn.chamfer_nn(g(p1), g(p2), mode='brute')
+        d1, i1, d2, i2 = vpn.chamfer_nn(g(p1), g(p2), mode='mfma16')
+        assert torch.equal(d1, a1) and torch.equal(i1, b1) and torch.equal(d2, a2) and torch.equal(i2, b2), (scale, shift)
+    # one sample in range, one not: the flag is per sample and per query
+    p1 = torch.stack([base1[0], base1[1] * 40.0])
+    p2 = torch.stack([base2[0], base2[1] * 40.0])
+    _chamfer_exact(vpn, p1, p2, torch_sqrt_too=False)
+    p2[0, 5] = torch.tensor([9.0, 0.0, 0.0])                 # a single far target / query
+    p1[0, 7] = torch.tensor([0.0, -20.0, 0.0])
+    _chamfer_exact(vpn, p1, p2, torch_sqrt_too=False)
 
 
 def test_chamfer_lattice_ties(vpn):
@@ -382,7 +403,7 @@ def test_chamfer_full_size_properties(vpn):
     e1, j1, e2, j2 = vpn.chamfer_nn(p1, p2, mode='brute')
     assert torch.equal(d1, e1) and torch.equal(i1, j1) and torch.equal(d2, e2) and torch.equal(i2, j2), \
         'pruned and brute-force scans disagree'
-    for mode in ('mfma', 'sorted'):
+    for mode in ('mfma', 'sorted', 'mfma16'):
         f1, k1, f2, k2 = vpn.chamfer_nn(p1, p2, mode=mode)
         assert torch.equal(f1, e1) and torch.equal(k1, j1) and torch.equal(f2, e2) and torch.equal(k2, j2), \
             '%s-filtered and brute-force scans disagree' % mode
@@ -392,7 +413,7 @@ def test_chamfer_full_size_properties(vpn):
     u = torch.randn(B, N, 3, generator=gen)
     q1 = g(c.repeat_interleave(N // 32, 1) + 0.08 * u / u.norm(dim=-1, keepdim=True))
     a1, b1, a2, b2 = vpn.chamfer_nn(q1, p2, mode='brute')
-    for mode in ('mfma', 'sorted'):
+    for mode in ('mfma', 'sorted', 'mfma16'):
         f1, k1, f2, k2 = vpn.chamfer_nn(q1, p2, mode=mode)
         assert torch.equal(f1, a1) and torch.equal(k1, b1) and torch.equal(f2, a2) and torch.equal(k2, b2), \
             '%s-filtered and brute-force scans disagree on clustered clouds' % mode

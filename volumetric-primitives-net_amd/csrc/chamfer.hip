@@ -655,6 +655,53 @@ __device__ inline void split3_bf16(float x, unsigned short p[3]) {
     p[2] = (unsigned short)(__float_as_uint(r2) >> 16);
 }
 
+// ---- fp16 variant of the filter (PREC == 2): fp16 has 11 significant bits against bf16's 8, so TWO pieces per
+// coordinate carry 22 bits and the three leading cross terms b1a1, b1a2, b2a1 per coordinate (9) plus three pieces of
+// |b|^2 fill 12 of the 16 K slots of ONE v_mfma_f32_32x32x16_f16 per 32x32 block: 32 matrix-pipe cycles instead of
+// 48, 32-byte rows instead of 48 (feature kernel writes and tile fetches shrink by a third, one 16-byte operand read
+// per lane and block instead of 16 + 8).  fp16 has a narrow exponent range, so the coordinates are scaled by
+// S = 2^11 (exact) before the split: |coordinate| <= 8 keeps S x below the fp16 maximum and S^2 |b|^2 within three
+// fp16 pieces times fp16-representable powers of two; a cloud or query outside that range (|p|^2 > 64, or not finite)
+// makes the query UNDECIDED, i.e. it is resolved exactly by the fix-up kernel: correct for any input, fast for
+// normalised shapes.  Error bound CM_EPS_F16 in near_error / the epilogue; DESIGN.md 4.1 has the derivation.
+constexpr float CM_S16 = 2048.0f;                            // coordinate scale of the fp16 rows (2^11)
+constexpr float CM_INV_S16SQ = 1.0f / (2048.0f * 2048.0f);   // 2^-22: filter values come out scaled by S^2
+constexpr float CM_DOMAIN16 = 64.0f;                         // |p|^2 bound of the fp16 filter (|coordinate| <= 8)
+// dropped terms b2a2 + rb a + b ra: <= 3 * 2^-22 |A||B| = 24 * 2^-24 |a||b|; accumulation of 12 exact products in fp32:
+// <= 12 * 2^-24 (2|a||b| + |b|^2); rounding of |b|^2 itself: 3 * 2^-24 |b|^2  ->  (24/2 + 12) = 24 per 2|a||b|, 15 per |b|^2:
+// 26 covers both.  The pieces' absolute floor (fp16 subnormal spacing; the matrix pipe keeps subnormal inputs --
+// tools/ubench/mfma_f16_denorm.hip -- but the bound below also covers a flush) adds 2^-24 (|a|_1 + |b|_1).
+constexpr float CM_EPS_F16 = 26.0f * 5.9604644775390625e-08f;
+constexpr int CM_ROWB16 = 32;            // bytes per fp16 row in HBM (16 K slots); LDS stride stays 48 B (bank-conflict free)
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+// X = h[0] + h[1] + r with |r| <= 2^-22 |X| + 2^-25 (fp16 pieces, round to nearest)
+__device__ inline void split2_f16(float X, _Float16 h[2]) {
+    h[0] = (_Float16)X;
+    h[1] = (_Float16)(X - (float)h[0]);
+}
+
+// one 32-byte row: K slots  x (b1 b1 b2), y (...), z (...), S^2 |p|^2 as p1 2^15 + p2 2^4 + p3, 4 zeros
+__device__ inline void write_row16(unsigned short* H, size_t row, float x, float y, float z, float n) {
+    _Float16 hx[2], hy[2], hz[2], pn[3];
+    split2_f16(CM_S16 * x, hx); split2_f16(CM_S16 * y, hy); split2_f16(CM_S16 * z, hz);
+    if (n < 1.0e30f) {
+        const float ns = (CM_S16 * CM_S16) * n;
+        pn[0] = (_Float16)(ns * 3.0517578125e-05f);                     // 2^-15
+        const float r1 = ns - (float)pn[0] * 32768.0f;
+        pn[1] = (_Float16)(r1 * 0.0625f);                               // 2^-4
+        pn[2] = (_Float16)(r1 - (float)pn[1] * 16.0f);
+    } else {                                                            // padding sentinel: 65504 * 2^15 / S^2 = 512 > any t in range
+        pn[0] = (_Float16)65504.0f; pn[1] = (_Float16)0.0f; pn[2] = (_Float16)0.0f;
+    }
+    auto bits = [](_Float16 v) { return (unsigned)__builtin_bit_cast(unsigned short, v); };
+    auto pk = [&](_Float16 lo, _Float16 hi) { return bits(lo) | (bits(hi) << 16); };
+    const _Float16 zero = (_Float16)0.0f;
+    uint4* dst = reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(H) + row * CM_ROWB16);
+    dst[0] = make_uint4(pk(hx[0], hx[0]), pk(hx[1], hy[0]), pk(hy[0], hy[1]), pk(hz[0], hz[0]));
+    dst[1] = make_uint4(pk(hz[1], pn[0]), pk(pn[1], pn[2]), pk(zero, zero), pk(zero, zero));
+}
+
 // feature planes F[b][4][Np] = (x, y, z, |p|^2) (padded with a never-winning sentinel) and
 // H[b][Np][24] bf16 rows (48 B) for the bf16 filter: per coordinate the target pieces (b1 b1 b2 b1 b3 b2) that pair
 // with the query pieces (a1 a2 a1 a3 a1 a2), then the three pieces of |p|^2 (paired with 1.0), then zeros.
@@ -684,6 +731,7 @@ constexpr int CFEAT_PTS = 4;                       // points per lane in flight
 struct FeatJob {          // one cloud: slices [0, ysplit) of a sample's workgroups belong to it
     const float* pts; int N, Np, ysplit;
     float* F; unsigned int* nmax; unsigned short* H; int* undecided;
+    int rows16;           // rows as 32-byte fp16 pieces (PREC 2) instead of 48-byte bf16 pieces (PREC 1)
 };
 
 // One launch converts both clouds of a Chamfer call.  1-D grid of B * (j0.ysplit + j1.ysplit) workgroups, decoded
@@ -704,6 +752,7 @@ __global__ __launch_bounds__(CFEAT_THREADS) void chamfer_feat_kernel(const FeatJ
     unsigned int* __restrict__ nmax = other ? j1.nmax : j0.nmax;
     unsigned short* __restrict__ H = other ? j1.H : j0.H;
     int* __restrict__ undecided = other ? j1.undecided : j0.undecided;
+    const bool rows16 = (other ? j1.rows16 : j0.rows16) != 0;
     const int by = sy - (other ? j0.ysplit : 0);
     if (by == 0 && threadIdx.x == 0) undecided[b] = 0;     // this sample's list: the scan that follows appends to it
     if (by == 0 && (int)threadIdx.x >= ysplit && threadIdx.x < CFEAT_SLOTS) nmax[b * CFEAT_SLOTS + threadIdx.x] = 0u;
@@ -730,7 +779,10 @@ __global__ __launch_bounds__(CFEAT_THREADS) void chamfer_feat_kernel(const FeatJ
                 nv = fmaxf(nv, n);
             }
             f[j] = x; f[Np + j] = y; f[2 * Np + j] = z; f[3 * Np + j] = n;
-            if (H) write_row(H, (size_t)b * Np + j, x, y, z, n);
+            if (H) {
+                if (rows16) write_row16(H, (size_t)b * Np + j, x, y, z, n);
+                else write_row(H, (size_t)b * Np + j, x, y, z, n);
+            }
         }
     }
     nv = wave_max_u(nv);
@@ -813,11 +865,21 @@ __global__ __launch_bounds__(CF_THREADS) void chamfer_fixup_kernel(const FixJob 
 #pragma unroll
             for (int c = 0; c < CF_Q; ++c) ent[c] = list[min(k0 + c, count - 1)];
         }
+        float thr[CF_Q];
 #pragma unroll
         for (int c = 0; c < CF_Q; ++c) {
             const int4 e = (k0 + c < count) ? ent[c] : ent[0];        // a short last group repeats a listed query
             q[c] = e.x; qx[c] = __int_as_float(e.y); qy[c] = __int_as_float(e.z); qz[c] = __int_as_float(e.w);
             best[c] = __builtin_inff(); second[c] = __builtin_inff(); bi[c] = 0x7fffffff;
+            // The filter kernel left dist = sqrt(m2), m2 = the EXACT minimum over its best block: the true minimum is
+            // <= m2, so only targets with d2 <= m2 (1 + 1e-6) can win or tie.  They are found with a contracted (FMA)
+            // d2, 6 full-rate instructions per pair, compared once per 4 targets; the exact, separately rounded
+            // evaluation with the tie bookkeeping (13 instructions per pair, 5 of them half-rate) runs only for the
+            // groups of 4 targets in which some lane of the wave has a candidate (~5 % of them).  The FMA value is
+            // within 4e-7 relative of the exact one and dist^2 within 1.2e-7 of m2: 1e-5 covers both with room.
+            const float dq = out_dist[(size_t)b * Nq + min(max(q[c], 0), Nq - 1)];
+            thr[c] = (dq * dq) * (1.0f + 1.0e-5f);
+            thr[c] = thr[c] >= 0.0f ? thr[c] : __builtin_inff();       // NaN distance: examine everything exactly
         }
         // float4 plane loads: 4 consecutive targets per load, CF_UNROLL x 3 loads in flight per lane (the planes are
         // padded to Ntp, a multiple of 64, with sentinel rows that never win; loads are clamped inside them)
@@ -839,6 +901,18 @@ __global__ __launch_bounds__(CF_THREADS) void chamfer_fixup_kernel(const FixJob 
                 const float xs[4] = {x[u].x, x[u].y, x[u].z, x[u].w}, ys[4] = {y[u].x, y[u].y, y[u].z, y[u].w};
                 const float zs[4] = {z[u].x, z[u].y, z[u].z, z[u].w};
                 const int os[4] = {o[u].x, o[u].y, o[u].z, o[u].w};
+                bool cand = false;
+#pragma unroll
+                for (int c = 0; c < CF_Q; ++c) {
+                    float dt[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float dx = qx[c] - xs[e], dy = qy[c] - ys[e], dz = qz[c] - zs[e];
+                        dt[e] = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                    }
+                    cand |= fminf(fminf(fminf(dt[0], dt[1]), dt[2]), dt[3]) <= thr[c];
+                }
+                if (!__builtin_amdgcn_ballot_w64(cand)) continue;      // wave-uniform: nobody has a candidate in these 4 targets
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     // rows past Nt (padding, clamped loads) are pushed to +inf by an additive penalty: written as a
@@ -902,8 +976,11 @@ __global__ __launch_bounds__(CF_THREADS) void chamfer_fixup_kernel(const FixJob 
             // store address must not depend on that alone (an ablation build that dropped the `count` guard above
             // faulted on a stale entry: DESIGN.md Finding 4)
             qc = min(max(qc, 0), Nq - 1);
-            out_dist[(size_t)b * Nq + qc] = sc;
-            out_idx[(size_t)b * Nq + qc] = min(min(redi[c][0], redi[c][1]), min(redi[c][2], redi[c][3]));
+            const int found = min(min(redi[c][0], redi[c][1]), min(redi[c][2], redi[c][3]));
+            if (found != 0x7fffffff) {                 // nothing found only for NaN / infinite inputs: the filter's answer stays
+                out_dist[(size_t)b * Nq + qc] = sc;
+                out_idx[(size_t)b * Nq + qc] = found;
+            }
         }
         __syncthreads();                                   // redf / redi are rewritten by the next group
     }
@@ -935,10 +1012,11 @@ __device__ inline float min16(const f16v& v) {
 // needs the query's norm and m2 only, not the largest norm of the cloud -- for a query near the centre of the cloud
 // the band shrinks ~2x and with it the number of undecided queries.  (Rigour: DESIGN.md 4.1; the factors 1 + 2e-6
 // cover the fp32 rounding of the two square roots and of the sum.)
-__device__ inline float near_error(float eps, float na, float m2, float E_cloud) {
+__device__ inline float near_error(float eps, float abs_eps, float na, float m2, float E_cloud) {
     const float rb = (sqrtf(na) + sqrtf(m2)) * (1.0f + 2.0e-6f);
     const float nbn = rb * rb;
-    const float En = eps * (2.0f * sqrtf(na * nbn) + nbn + na) * (1.0f + 1.0e-6f);
+    // abs_eps (|a|_1 + |b|_1) <= abs_eps sqrt(3) (|a| + |b|): the fp16 pieces' absolute floor (0 for the other filters)
+    const float En = (eps * (2.0f * sqrtf(na * nbn) + nbn + na) + abs_eps * 1.7320509f * (sqrtf(na) + rb)) * (1.0f + 1.0e-6f);
     return fminf(En, E_cloud);
 }
 
@@ -1010,7 +1088,85 @@ __global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_kernel(const ScanJob
     }
     const float* Fb = F + (size_t)b * 4 * Ntp;
     const f16v zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if constexpr (PREC == 1) {
+    if constexpr (PREC == 2) {
+        // ---- fp16 filter: ONE v_mfma_f32_32x32x16_f16 per 32x32 block (12 of 16 K slots used), rows of 32 bytes
+        __shared__ __attribute__((aligned(16))) unsigned char tileH[2][CM_TILE16 * CM_ROWB];      // LDS stride 48 B per row
+        const unsigned char* Hb = reinterpret_cast<const unsigned char*>(H) + (size_t)b * Ntp * CM_ROWB16;
+        h8 bq;                                       // this lane's query: K slots [8 half, +8)
+        {
+            _Float16 qx[2], qy[2], qz[2];
+            split2_f16(-2.0f * CM_S16 * ax, qx); split2_f16(-2.0f * CM_S16 * ay, qy); split2_f16(-2.0f * CM_S16 * az, qz);
+            // K slot k of the query row: per coordinate the pieces (A1 A2 A1) against the target's (b1 b1 b2), then the
+            // multipliers of the three pieces of S^2 |b|^2, then zeros.  Compile-time indices: the row lives in registers.
+            auto slot = [&](int k) -> _Float16 {
+                if (k < 9) {
+                    const int c = k / 3, t = k % 3;
+                    const _Float16 v0 = c == 0 ? qx[0] : (c == 1 ? qy[0] : qz[0]);
+                    const _Float16 v1 = c == 0 ? qx[1] : (c == 1 ? qy[1] : qz[1]);
+                    return t == 1 ? v1 : v0;
+                }
+                return k == 9 ? (_Float16)32768.0f : (k == 10 ? (_Float16)16.0f : (k == 11 ? (_Float16)1.0f : (_Float16)0.0f));
+            };
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bq[e] = half ? slot(8 + e) : slot(e);
+        }
+        constexpr int F4 = CM_TILE16 * CM_ROWB16 / 16 / CM_BLOCK;      // float4 per lane per tile
+        static_assert(F4 == 2, "tile fetch is written for 2 float4 per lane");
+        // tile t0 = rows [t0, t0 + CM_TILE16): one contiguous 8-KB run in HBM; float4 f of it is half (f & 1) of row f >> 1
+        // and goes to LDS byte (f >> 1) * 48 + (f & 1) * 16.  No bounds checks: the row buffer is sized for 48-byte rows.
+        const float4* Hq = reinterpret_cast<const float4*>(Hb) + threadIdx.x;
+        struct Pre { float4 a, b; };
+        auto fetch = [&](int t0) -> Pre {
+            const float4* p = Hq + t0 * (CM_ROWB16 / 16);
+            return Pre{p[0], p[CM_BLOCK]};
+        };
+        const int f0 = threadIdx.x, f1 = threadIdx.x + CM_BLOCK;
+        const int o0 = (f0 >> 1) * CM_ROWB + (f0 & 1) * 16, o1 = (f1 >> 1) * CM_ROWB + (f1 & 1) * 16;
+        auto stash = [&](int buf, const Pre& v) {
+            *reinterpret_cast<float4*>(&tileH[buf][o0]) = v.a;
+            *reinterpret_cast<float4*>(&tileH[buf][o1]) = v.b;
+        };
+        auto rd = [&](const unsigned char* T, int blkk) -> float4 {
+            return *reinterpret_cast<const float4*>(T + blkk * 32 * CM_ROWB);
+        };
+        auto block = [&](const float4& o) {
+            return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, o), bq, zero, 0, 0, 0);
+        };
+        static_assert(CM_TILE16 == 256, "the tile loop below is unrolled for 8 blocks per tile");
+#define CM_PAIR(oa, ob, JA, JB)                                                                \
+    {                                                                                          \
+        const f16v accA = block(oa), accB = block(ob);                                         \
+        const float mA = min16(accA), mB = min16(accB);                                        \
+        CM_UPDATE_C(mA, JA)                                                                    \
+        CM_UPDATE_C(mB, JB)                                                                    \
+    }
+        Pre pre = fetch(0);
+        stash(0, pre);
+        __syncthreads();
+        int buf = 0, blkc = 0;
+        for (int t0 = 0; t0 < Ntp; t0 += CM_TILE16, buf ^= 1) {
+            const bool more = t0 + CM_TILE16 < Ntp;
+            if (more) pre = fetch(t0 + CM_TILE16);     // in flight during the MFMA loop, stored to LDS after it
+            const int nblk = min(CM_TILE16, Ntp - t0) >> 5;          // 2, 4, 6 or 8 (Ntp is a multiple of 64)
+            const unsigned char* T = &tileH[buf][jq * CM_ROWB + half * 16];
+            const float before = best;
+            float4 a0 = rd(T, 0), a1 = rd(T, 1), b0 = rd(T, 2), b1 = rd(T, 3);
+            CM_PAIR(a0, a1, 0, 1)
+            if (nblk > 2) {
+                a0 = rd(T, 4); a1 = rd(T, 5);
+                CM_PAIR(b0, b1, 2, 3)
+                if (nblk > 4) {
+                    b0 = rd(T, 6); b1 = rd(T, 7);
+                    CM_PAIR(a0, a1, 4, 5)
+                    if (nblk > 6) CM_PAIR(b0, b1, 6, 7)
+                }
+            }
+            blk = best < before ? t0 + (blkc << 5) : blk;            // the tile improved this lane's minimum
+            if (more) stash(buf ^ 1, pre);
+            __syncthreads();
+        }
+#undef CM_PAIR
+    } else     if constexpr (PREC == 1) {
         // ---- bf16 filter: v_mfma_f32_32x32x16_bf16 (K slots 0..15) + v_mfma_f32_32x32x8_bf16 (K slots 16..23) per 32x32
         //      block, on the matrix pipe beside the VALU
         __shared__ __attribute__((aligned(16))) unsigned char tileH[2][CM_TILE16 * CM_ROWB];
@@ -1209,13 +1365,19 @@ __global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_kernel(const ScanJob
 #pragma unroll
     for (int w = 0; w < CFEAT_SLOTS; ++w) nb = fmaxf(nb, __uint_as_float(nmax[b * CFEAT_SLOTS + w]));
     const float na = ax * ax + ay * ay + az * az;
-    const float E = (PREC == 1 ? CM_EPS_BF16 : CM_EPS) * (2.0f * sqrtf(na * nb) + nb + na);
+    float E = (PREC == 2 ? CM_EPS_F16 : (PREC == 1 ? CM_EPS_BF16 : CM_EPS)) * (2.0f * sqrtf(na * nb) + nb + na);
+    if (PREC == 2) {
+        E += 5.9604644775390625e-08f * 1.7320509f * (sqrtf(na) + sqrtf(nb));    // absolute floor of the fp16 pieces
+        Bv *= CM_INV_S16SQ; V2 *= CM_INV_S16SQ;                                 // the fp16 filter works on S x: values scaled by S^2
+    }
     // m2 is exact, so the runner-up is compared with it rather than with the filtered value of the best block:
     // only the runner-up's own filter error E remains (the band was 2E before; this halves the undecided queries).
     // 4e-6 m2 covers the rounding of m2 and of |a|^2 and the width of a sqrt bucket.
     const float band = E + 4.0e-6f * (m2 + na);                     // any target of the cloud (consistency of the best block)
-    const float band_near = near_error(PREC == 1 ? CM_EPS_BF16 : CM_EPS, na, m2, E) + 4.0e-6f * (m2 + na);   // possible winners
-    const bool ambiguous = !(V2 > (m2 - na) + band_near) || !(m2 - na <= Bv + band);
+    const float band_near = near_error(PREC == 2 ? CM_EPS_F16 : (PREC == 1 ? CM_EPS_BF16 : CM_EPS), PREC == 2 ? 5.9604644775390625e-08f : 0.0f,
+                                       na, m2, E) + 4.0e-6f * (m2 + na);   // possible winners
+    bool ambiguous = !(V2 > (m2 - na) + band_near) || !(m2 - na <= Bv + band);
+    if (PREC == 2) ambiguous |= !(nb <= CM_DOMAIN16 && na <= CM_DOMAIN16);     // outside the fp16 filter's range: exact fix-up
     const float s = sqrtf(m2);
     // lowest index attaining the minimum; a different d2 can only share the sqrt if it lies within a few ulp
     // of it, which is rare: only then are the sqrt values compared
@@ -1540,7 +1702,7 @@ __global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_pruned_kernel(
     }
     m2 = fminf(m2, __shfl_xor(m2, 32, 64));
     const float band = E + 4.0e-6f * (m2 + na);
-    const float band_near = near_error(CM_EPS_BF16, na, m2, E) + 4.0e-6f * (m2 + na);
+    const float band_near = near_error(CM_EPS_BF16, 0.0f, na, m2, E) + 4.0e-6f * (m2 + na);
     const bool ambiguous = !(V2 > (m2 - na) + band_near) || !(m2 - na <= Bv + band);
     const float s = sqrtf(m2);
     const float lim = m2 * (1.0f + 1.0e-6f);
@@ -1592,12 +1754,13 @@ static MfmaWs mfma_carve(float* F, int B, int Nt, int Nq) {
 // both directions: features of both clouds (one launch) -> filtered scan of p1 against p2 and of p2 against p1 ->
 // exact fix-up of the undecided queries of both (one launch)
 static int mfma_both(const float* p1, const float* p2, int B, int N, int M, float* ws, float* d1, int32_t* i1, float* d2,
-                     int32_t* i2, bool fp32_filter, hipStream_t s) {
+                     int32_t* i2, int prec, hipStream_t s) {              // prec 0: fp32 MFMA, 1: bf16 x 3, 2: fp16 x 2
+    const bool fp32_filter = prec == 0;
     const MfmaWs w2 = mfma_carve(ws, B, M, N);                            // p2 = targets of direction 1
     const MfmaWs w1 = mfma_carve(ws + mfma_ws_floats(B, M, N), B, N, M);  // p1 = targets of direction 2
     auto split = [](int Ntp) { const int y = (Ntp + CFEAT_WGPTS - 1) / CFEAT_WGPTS; return y > CFEAT_SLOTS ? CFEAT_SLOTS : y; };
-    const FeatJob f2{p2, M, w2.Ntp, split(w2.Ntp), w2.F, w2.nmax, fp32_filter ? nullptr : w2.H, w2.undecided};
-    const FeatJob f1{p1, N, w1.Ntp, split(w1.Ntp), w1.F, w1.nmax, fp32_filter ? nullptr : w1.H, w1.undecided};
+    const FeatJob f2{p2, M, w2.Ntp, split(w2.Ntp), w2.F, w2.nmax, fp32_filter ? nullptr : w2.H, w2.undecided, prec == 2};
+    const FeatJob f1{p1, N, w1.Ntp, split(w1.Ntp), w1.F, w1.nmax, fp32_filter ? nullptr : w1.H, w1.undecided, prec == 2};
     VPN_LAUNCH(chamfer_feat_kernel, dim3(B * (f2.ysplit + f1.ysplit)), dim3(CFEAT_THREADS), 0, s, f2, f1, B);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
@@ -1608,10 +1771,12 @@ static int mfma_both(const float* p1, const float* p2, int B, int N, int M, floa
         const bool long_first = (long long)N > (long long)M;       // direction 2 scans the N targets: more work per workgroup
         const ScanJob& ja = long_first ? s2 : s1;
         const ScanJob& jb = long_first ? s1 : s2;
-        if (fp32_filter)
+        if (prec == 0)
             VPN_LAUNCH(chamfer_nn_mfma_kernel<0>, dim3(ja.G + jb.G), dim3(CM_BLOCK), 0, s, ja, jb, B);
-        else
+        else if (prec == 1)
             VPN_LAUNCH(chamfer_nn_mfma_kernel<1>, dim3(ja.G + jb.G), dim3(CM_BLOCK), 0, s, ja, jb, B);
+        else
+            VPN_LAUNCH(chamfer_nn_mfma_kernel<2>, dim3(ja.G + jb.G), dim3(CM_BLOCK), 0, s, ja, jb, B);
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
     }
@@ -1678,7 +1843,7 @@ static int chamfer_mode() {
     static int mode = -1;
     if (mode < 0) {
         const char* e = getenv("VPN_CHAMFER_MODE");
-        mode = !e ? 0 : (e[0] == 'b' ? 1 : (e[0] == 'p' ? 2 : (e[0] == 'm' ? (strstr(e, "32") ? 4 : 3) : (e[0] == 's' ? 5 : 0))));
+        mode = !e ? 0 : (e[0] == 'b' ? 1 : (e[0] == 'p' ? 2 : (e[0] == 'm' ? (strstr(e, "32") ? 4 : (strstr(e, "16") ? 6 : 3)) : (e[0] == 's' ? 5 : 0))));
     }
     return mode;
 }
@@ -1775,15 +1940,15 @@ extern "C" int vpn_chamfer_fwd_ws(const float* p1, const float* p2, int B, int N
     if (mode == 0) mode = chamfer_mode();
     // automatic: the MFMA-filtered scan for large clouds (measured 1.3x the brute-force scan at C3), brute force
     // for small ones or without a workspace; the box-pruned scan stays opt-in
-    if (mode == 0) mode = (workspace && (long)N * M >= 512L * 512L) ? 3 : 1;
+    if (mode == 0) mode = (workspace && (long)N * M >= 512L * 512L) ? 6 : 1;
     hipStream_t s = (hipStream_t)stream;
     if (mode == 1 || !workspace) {
         int rc = nn_dispatch(p1, p2, B, N, M, dist1, idx1, s);
         if (rc) return rc;
         return nn_dispatch(p2, p1, B, M, N, dist2, idx2, s);
     }
-    if (mode == 3 || mode == 4) {
-        return mfma_both(p1, p2, B, N, M, (float*)workspace, dist1, idx1, dist2, idx2, mode == 4, s);
+    if (mode == 3 || mode == 4 || mode == 6) {
+        return mfma_both(p1, p2, B, N, M, (float*)workspace, dist1, idx1, dist2, idx2, mode == 4 ? 0 : (mode == 3 ? 1 : 2), s);
     }
     if (mode == 5) return mfma_sorted_both(p1, p2, B, N, M, (float*)workspace, dist1, idx1, dist2, idx2, s);
     float* cur = (float*)workspace;

@@ -263,7 +263,7 @@ class ChamferFunction(Function):
         return g1, g2, None, None
 
 
-CHAMFER_MODES = {'auto': 0, 'brute': 1, 'pruned': 2, 'mfma': 3, 'mfma32': 4, 'sorted': 5}
+CHAMFER_MODES = {'auto': 0, 'brute': 1, 'pruned': 2, 'mfma': 3, 'mfma32': 4, 'sorted': 5, 'mfma16': 6}
 
 
 def chamfer_nn(p1, p2, mode='auto'):
