@@ -204,7 +204,8 @@ __device__ inline void prim_backward(const float4 r0, const PixPrim& q, float gz
 // which the backward and finishing kernels read back instead of repeating the test.
 
 // does primitive (pixel box bb, conic qa/qb) touch the 16x16 tile at (c0, r0)?
-__device__ inline bool prim_hits_tile(const float4 bb, const float4 qa, const float4 qb, int c0, int r0, int H, int W) {
+__device__ inline bool prim_hits_tile(const float4 bb, const float4 qa, const float4 qb, int c0, int r0, int H, int W,
+                                      int R_TW = vpn::R_TW, int R_TH = vpn::R_TH) {       // also used for the 8x8 quadrants
     const int jmin = __float_as_int(bb.x), jmax = __float_as_int(bb.y);
     const int imin = __float_as_int(bb.z), imax = __float_as_int(bb.w);
     bool vis = (jmin <= c0 + R_TW - 1) && (jmax >= c0) && (imin <= r0 + R_TH - 1) && (imax >= r0);
@@ -239,10 +240,17 @@ __global__ __launch_bounds__(256) void raster_prep_kernel(const float* __restric
 // tile come from the binning mask (wave-uniform: the loop is scalar control flow) and their ray coefficients are
 // read straight from the record array with wave-uniform addresses.
 
+// Lane l owns one pixel in each 8x8 QUADRANT of the tile: slot s = quadrant (s & 1, s >> 1), position (l & 7, l >> 3)
+// inside it.  A primitive is evaluated per quadrant only where it can reach it (second, 8x8 level of the cull).
 struct Tile {
-    int b, tile, c0, r0, col, rbase;
-    float px, py[R_PPL];
+    int b, tile, c0, r0;
+    int colq[2], rowq[2];       // this lane's column in quadrant column 0 / 1, row in quadrant row 0 / 1
+    float pxq[2], pyq[2];
     bool valid;
+    __device__ int col(int s) const { return colq[s & 1]; }
+    __device__ int row(int s) const { return rowq[s >> 1]; }
+    __device__ float px(int s) const { return pxq[s & 1]; }
+    __device__ float py(int s) const { return pyq[s >> 1]; }
 };
 
 // One wave (= one workgroup) per tile, 1-D grid of ntile * B workgroups: id = p * B + b with p running over the tiles
@@ -263,11 +271,13 @@ __device__ inline Tile make_tile(int H, int W, int tiles_x, int tiles_y, int B) 
     T.valid = true;
     T.tile = ty * tiles_x + tx;
     T.c0 = tx * R_TW; T.r0 = ty * R_TH;
-    T.col = T.c0 + (lane & 15); T.rbase = T.r0 + (lane >> 4);
-    T.px = ((2.0f * ((float)T.col + 0.5f) / (float)W) - 1.0f) * (R_TAN_HALF_FOV * (float)W / (float)H);
 #pragma unroll
-    for (int s = 0; s < R_PPL; ++s)
-        T.py[s] = (1.0f - (2.0f * ((float)(T.rbase + 4 * s) + 0.5f) / (float)H)) * R_TAN_HALF_FOV;
+    for (int h = 0; h < 2; ++h) {
+        T.colq[h] = T.c0 + 8 * h + (lane & 7);
+        T.rowq[h] = T.r0 + 8 * h + (lane >> 3);
+        T.pxq[h] = ((2.0f * ((float)T.colq[h] + 0.5f) / (float)W) - 1.0f) * (R_TAN_HALF_FOV * (float)W / (float)H);
+        T.pyq[h] = (1.0f - (2.0f * ((float)T.rowq[h] + 0.5f) / (float)H)) * R_TAN_HALF_FOV;
+    }
     return T;
 }
 
@@ -290,6 +300,7 @@ __device__ inline unsigned long long uniform64(unsigned long long v) {
 }
 
 constexpr int R_SLOT = 4;            // float4 per staged primitive: (o~|kind, Mr|k, Mu, Mf)
+constexpr int R_LDS_F4 = 64 * R_SLOT + 64 * R_CULL;   // per wave: 64 staged records + their culling records (7 KB)
 
 // Mask word w of this tile and staging of its visible primitives in one go: lane i fetches the whole record of
 // primitive 64 w + i (7 float4, one round trip), tests it against the tile, and if visible stores its ray coefficients
@@ -314,9 +325,25 @@ __device__ inline unsigned long long stage_word(const Tile& T, const float4* __r
         const int slot = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
         b.w = __int_as_float(k);
         srec[slot * R_SLOT + 0] = a; srec[slot * R_SLOT + 1] = b; srec[slot * R_SLOT + 2] = c; srec[slot * R_SLOT + 3] = d;
+        float4* scull = srec + 64 * R_SLOT + slot * R_CULL;
+        scull[0] = rk[4]; scull[1] = rk[5]; scull[2] = rk[6];
     }
     __builtin_amdgcn_wave_barrier();
     return m;
+}
+
+// Second level of the cull: which of the tile's four 8x8 quadrants can staged primitive j reach?  Lane l tests
+// (slot l >> 2, quadrant l & 3) of 16 slots per pass; the ballot holds 4 bits per slot.  Returns the ballot of pass
+// `pass` (slots 16 pass .. 16 pass + 15), wave-uniform.
+__device__ inline unsigned long long quadrant_bits(const Tile& T, const float4* srec, int n, int pass, int H, int W) {
+    const int lane = threadIdx.x & 63;
+    const int slot = pass * 16 + (lane >> 2), qd = lane & 3;
+    bool vis = false;
+    if (slot < n) {
+        const float4* scull = srec + 64 * R_SLOT + slot * R_CULL;
+        vis = prim_hits_tile(scull[0], scull[1], scull[2], T.c0 + 8 * (qd & 1), T.r0 + 8 * (qd >> 1), H, W, 8, 8);
+    }
+    return __ballot(vis);
 }
 
 // Fused image losses: SilhouetteLoss (L1 / MSE mean against the GT silhouette, modules/loss/silhouette.py:11,22) and
@@ -345,13 +372,17 @@ __device__ inline unsigned long long tile_forward(const Tile& T, const float4* _
         const unsigned long long m = stage_word(T, rec_b, w, K, H, W, srec, nullptr, mrow);
         if (w == 0) m0 = m;
         const int n = __builtin_popcountll(m);
+        unsigned long long qb = 0ull;
         for (int j = 0; j < n; ++j) {
+            if ((j & 15) == 0) qb = quadrant_bits(T, srec, n, j >> 4, H, W);
+            const unsigned qm = (unsigned)(qb >> (4 * (j & 15))) & 15u;
             const float4 q0 = srec[j * R_SLOT], q1 = srec[j * R_SLOT + 1], q2 = srec[j * R_SLOT + 2], q3 = srec[j * R_SLOT + 3];
             auto body = [&](auto kind_c) {
 #pragma unroll
                 for (int s = 0; s < R_PPL; ++s) {
+                    if (!(qm & (1u << s))) continue;            // wave-uniform: the primitive cannot reach this quadrant
                     PixPrim q;
-                    eval_prim<decltype(kind_c)::value>(q0, q1, q2, q3, T.px, T.py[s], inv_sigma, inv_gamma, zref, q);
+                    eval_prim<decltype(kind_c)::value>(q0, q1, q2, q3, T.px(s), T.py(s), inv_sigma, inv_gamma, zref, q);
                     P[s] *= q.c;
                     S0[s] += q.wgt;
                     S1[s] += q.wgt * q.z;
@@ -380,7 +411,10 @@ __device__ inline void tile_backward(const Tile& T, const float4* __restrict__ r
     const int lane = threadIdx.x & 63;
     for (int w = 0; w < words; ++w) {
         const int n = __builtin_popcountll(staged ? m0 : stage_word(T, rec_b, w, K, H, W, srec, mrow, nullptr));
+        unsigned long long qb = 0ull;
         for (int j = 0; j < n; ++j) {
+            if ((j & 15) == 0) qb = quadrant_bits(T, srec, n, j >> 4, H, W);
+            const unsigned qm = (unsigned)(qb >> (4 * (j & 15))) & 15u;
             const float4 q0 = srec[j * R_SLOT], q1 = srec[j * R_SLOT + 1], q2 = srec[j * R_SLOT + 2], q3 = srec[j * R_SLOT + 3];
             const int k = __builtin_amdgcn_readfirstlane(__float_as_int(q1.w));
             float v[16];
@@ -390,8 +424,9 @@ __device__ inline void tile_backward(const Tile& T, const float4* __restrict__ r
                 constexpr int KIND = decltype(kind_c)::value;
 #pragma unroll
                 for (int s = 0; s < R_PPL; ++s) {
+                    if (!(qm & (1u << s))) continue;
                     PixPrim q;
-                    eval_prim<KIND>(q0, q1, q2, q3, T.px, T.py[s], inv_sigma, inv_gamma, zref, q);
+                    eval_prim<KIND>(q0, q1, q2, q3, T.px(s), T.py(s), inv_sigma, inv_gamma, zref, q);
                     // composite backward
                     const float gw = gZbar[s] * (q.z - zbar[s]) * invS[s];
                     float gz = gZbar[s] * q.wgt * invS[s];
@@ -402,8 +437,8 @@ __device__ inline void tile_backward(const Tile& T, const float4* __restrict__ r
                     float go[3], gd[3];
                     prim_backward<KIND>(q0, q, gz, gm2, go, gd);
                     v[0] += go[0]; v[1] += go[1]; v[2] += go[2];
-                    v[3] += T.px * gd[0]; v[4] += T.px * gd[1]; v[5] += T.px * gd[2];
-                    v[6] += T.py[s] * gd[0]; v[7] += T.py[s] * gd[1]; v[8] += T.py[s] * gd[2];
+                    v[3] += T.px(s) * gd[0]; v[4] += T.px(s) * gd[1]; v[5] += T.px(s) * gd[2];
+                    v[6] += T.py(s) * gd[0]; v[7] += T.py(s) * gd[1]; v[8] += T.py(s) * gd[2];
                     v[9] += gd[0]; v[10] += gd[1]; v[11] += gd[2];
                 }
             };
@@ -429,7 +464,7 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(const float4* __restrict
     const int ntile = tiles_x * tiles_y, lane = threadIdx.x & 63;
     const float vz0 = __int_as_float(vzero());
     const float inv_sigma = 1.0f / (sigma + vz0), inv_gamma = 1.0f / (gamma + vz0), zref = cam[T.b * 3] + vz0;
-    __shared__ __attribute__((aligned(16))) float4 srec[64 * R_SLOT];
+    __shared__ __attribute__((aligned(16))) float4 srec[R_LDS_F4];
     float P[R_PPL], S0[R_PPL], S1[R_PPL];
     tile_forward(T, rec + (size_t)T.b * K * R_REC, masks + ((size_t)T.b * ntile + T.tile) * words, words, K, H, W, srec,
                  inv_sigma, inv_gamma, zref, P, S0, S1);
@@ -437,13 +472,13 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(const float4* __restrict
     float lsil = 0.0f, ldep = 0.0f;
 #pragma unroll
     for (int s = 0; s < R_PPL; ++s) {
-        const int row = T.rbase + 4 * s;
-        if (T.col < W && row < H) {
+        const int row = T.row(s), col = T.col(s);
+        if (col < W && row < H) {
             const float A = 1.0f - P[s];
             const float S = S0[s] + R_DELTA_S0;
             const float zbar = S1[s] * R_RCP(S);
             const float D = z_far + A * (zbar - z_far);
-            const size_t pix = (size_t)row * W + T.col;
+            const size_t pix = (size_t)row * W + col;
             if (MODE == 0) {
                 alpha[T.b * hw + pix] = A;
                 depth[T.b * hw + pix] = D;
@@ -485,10 +520,10 @@ __global__ __launch_bounds__(64, 4) void raster_bwd_kernel(const float4* __restr
     float gAtot[R_PPL], gZbar[R_PPL], P[R_PPL], zbar[R_PPL], invS[R_PPL];
 #pragma unroll
     for (int s = 0; s < R_PPL; ++s) {
-        const int row = T.rbase + 4 * s;
+        const int row = T.row(s), col = T.col(s);
         gAtot[s] = 0.0f; gZbar[s] = 0.0f; P[s] = 1.0f; zbar[s] = 0.0f; invS[s] = 0.0f;
-        if (T.col < W && row < H) {
-            const size_t pix = (size_t)row * W + T.col;
+        if (col < W && row < H) {
+            const size_t pix = (size_t)row * W + col;
             P[s] = aux[(T.b * 3 + 0) * hw + pix];
             zbar[s] = aux[(T.b * 3 + 1) * hw + pix];
             invS[s] = R_RCP(aux[(T.b * 3 + 2) * hw + pix]);
@@ -511,7 +546,7 @@ __global__ __launch_bounds__(64, 4) void raster_bwd_kernel(const float4* __restr
             gZbar[s] = gD * (1.0f - P[s]);
         }
     }
-    __shared__ __attribute__((aligned(16))) float4 srec[64 * R_SLOT];
+    __shared__ __attribute__((aligned(16))) float4 srec[R_LDS_F4];
     tile_backward(T, rec + (size_t)T.b * K * R_REC, mrow, words, K, ntile, H, W, srec, false, 0ull, inv_sigma,
                   inv_gamma, zref, P, zbar, invS, gAtot, gZbar, partial);
 }
@@ -522,7 +557,10 @@ __global__ __launch_bounds__(64, 4) void raster_bwd_kernel(const float4* __restr
 // once, and there is one launch (and one tail) instead of two.  The gradient partials are those of d total / d(ray
 // coefficients) for an upstream gradient of 1: d total is linear in it, raster_bwd_finish_kernel multiplies by the
 // actual upstream gradient when backward runs.
-__global__ __launch_bounds__(64, 4) void raster_total_kernel(const float4* __restrict__ rec,
+#ifndef R_TOTAL_WAVES
+#define R_TOTAL_WAVES 4
+#endif
+__global__ __launch_bounds__(64, R_TOTAL_WAVES) void raster_total_kernel(const float4* __restrict__ rec,
                                                            unsigned long long* __restrict__ masks,
                                                            const float* __restrict__ cam, int B, int K, int H, int W,
                                                            int tiles_x, int tiles_y, int words, float sigma, float gamma,
@@ -539,22 +577,22 @@ __global__ __launch_bounds__(64, 4) void raster_total_kernel(const float4* __res
     float gs[R_PPL], gd[R_PPL];
 #pragma unroll
     for (int s = 0; s < R_PPL; ++s) {
-        const int row = T.rbase + 4 * s;
-        const bool in = T.col < W && row < H;
-        const size_t pix = in ? (size_t)row * W + T.col : 0;
+        const int row = T.row(s), col = T.col(s);
+        const bool in = col < W && row < H;
+        const size_t pix = in ? (size_t)row * W + col : 0;
         gs[s] = (la.gt_sil && in) ? la.gt_sil[T.b * hw + pix] : 0.0f;
         gd[s] = (la.gt_depth && in) ? la.gt_depth[T.b * hw + pix] : 0.0f;
     }
-    __shared__ __attribute__((aligned(16))) float4 srec[64 * R_SLOT];
+    __shared__ __attribute__((aligned(16))) float4 srec[R_LDS_F4];
     float P[R_PPL], S0[R_PPL], S1[R_PPL];
     const unsigned long long m0 = tile_forward(T, rec_b, mrow, words, K, H, W, srec, inv_sigma, inv_gamma, zref, P, S0, S1);
     float gAtot[R_PPL], gZbar[R_PPL], zbar[R_PPL], invS[R_PPL];
     float lsil = 0.0f, ldep = 0.0f;
 #pragma unroll
     for (int s = 0; s < R_PPL; ++s) {
-        const int row = T.rbase + 4 * s;
+        const int row = T.row(s), col = T.col(s);
         gAtot[s] = 0.0f; gZbar[s] = 0.0f; zbar[s] = 0.0f; invS[s] = 0.0f;
-        if (T.col < W && row < H) {
+        if (col < W && row < H) {
             const float A = 1.0f - P[s];
             const float S = S0[s] + R_DELTA_S0;
             invS[s] = R_RCP(S);

@@ -205,12 +205,29 @@ __global__ __launch_bounds__(SAMP_BLOCK) void sample_chamfer_bwd_kernel(
     float acc[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) acc[i] = 0.0f;
+    // The canonical coefficient c of a point (p = R (c * v) + t) is RECOVERED from the point the forward pass wrote,
+    // c = R^T (p - t) / v: 12 instructions instead of redrawing the Philox uniforms and redoing acos / sin / cos
+    // (~300: two thirds of this kernel's instructions).  It differs from the forward's c by rounding only (1e-7
+    // relative; the gradient is a 1e-4 contract).  A degenerate extent (|v_a| < 1e-20, never produced by the network:
+    // vpnet_one_resnet.py:71,84) falls back to the exact recomputation, uniformly for the workgroup.
+    const float tx = prm[7], ty = prm[8], tz = prm[9];
+    const bool recover = fabsf(P.v[0]) > 1e-20f && fabsf(P.v[1]) > 1e-20f && fabsf(P.v[2]) > 1e-20f;
+    const float iv0 = recover ? 1.0f / P.v[0] : 0.0f, iv1 = recover ? 1.0f / P.v[1] : 0.0f, iv2 = recover ? 1.0f / P.v[2] : 0.0f;
     auto add = [&](int pl, float gx, float gy, float gz) {              // point pl of this primitive gets gradient g
-        float uu[3];
-        if (ub) { uu[0] = ub[pl * 3]; uu[1] = ub[pl * 3 + 1]; uu[2] = ub[pl * 3 + 2]; }
-        else philox_uniform3(seed, sample_base + (uint64_t)b, (uint32_t)k, (uint32_t)pl, uu);
         float c[3];
-        canonical_coeff(P, pl, uu, c);
+        if (recover) {
+            const int i = k * n + pl;
+            const float dx = A[i * 3] - tx, dy = A[i * 3 + 1] - ty, dz = A[i * 3 + 2] - tz;
+            const Mat3& R = P.pose.R;
+            c[0] = (R.m[0][0] * dx + R.m[1][0] * dy + R.m[2][0] * dz) * iv0;
+            c[1] = (R.m[0][1] * dx + R.m[1][1] * dy + R.m[2][1] * dz) * iv1;
+            c[2] = (R.m[0][2] * dx + R.m[1][2] * dy + R.m[2][2] * dz) * iv2;
+        } else {
+            float uu[3];
+            if (ub) { uu[0] = ub[pl * 3]; uu[1] = ub[pl * 3 + 1]; uu[2] = ub[pl * 3 + 2]; }
+            else philox_uniform3(seed, sample_base + (uint64_t)b, (uint32_t)k, (uint32_t)pl, uu);
+            canonical_coeff(P, pl, uu, c);
+        }
         const float g[3] = {gx, gy, gz};
 #pragma unroll
         for (int r = 0; r < 3; ++r) {

@@ -190,14 +190,30 @@ __device__ inline void raster_finish_wave(const float* __restrict__ params, cons
     float v[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) v[i] = 0.0f;
-    for (int tile = lane; tile < ntile; tile += 64) {
-        const unsigned long long m = masks[((size_t)b * ntile + tile) * words + (k >> 6)];
-        if (!((m >> (k & 63)) & 1ull)) continue;                                   // nothing was written for this pair
-        const float4* src = reinterpret_cast<const float4*>(partial + ((size_t)bk * ntile + tile) * 12);
-        const float4 a = src[0], c = src[1], d = src[2];
-        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
-        v[4] += c.x; v[5] += c.y; v[6] += c.z; v[7] += c.w;
-        v[8] += d.x; v[9] += d.y; v[10] += d.z; v[11] += d.w;
+    // 4 tiles per lane and round: the 4 mask words are loaded together, then the (up to) 12 float4 of the pairs
+    // that exist -- two memory round trips per 256 tiles instead of eight
+    for (int t0 = 0; t0 < ntile; t0 += 256) {
+        bool has[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int tile = t0 + u * 64 + lane;
+            const unsigned long long m = tile < ntile ? masks[((size_t)b * ntile + tile) * words + (k >> 6)] : 0ull;
+            has[u] = (m >> (k & 63)) & 1ull;                                       // nothing was written for the other pairs
+        }
+        float4 pa[4], pc[4], pd[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float4* src = reinterpret_cast<const float4*>(partial + ((size_t)bk * ntile + (t0 + u * 64 + lane)) * 12);
+            pa[u] = pc[u] = pd[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (has[u]) { pa[u] = src[0]; pc[u] = src[1]; pd[u] = src[2]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (!has[u]) continue;
+            v[0] += pa[u].x; v[1] += pa[u].y; v[2] += pa[u].z; v[3] += pa[u].w;
+            v[4] += pc[u].x; v[5] += pc[u].y; v[6] += pc[u].z; v[7] += pc[u].w;
+            v[8] += pd[u].x; v[9] += pd[u].y; v[10] += pd[u].z; v[11] += pd[u].w;
+        }
     }
     const float tot = wave_reduce16(v);
     // gather the 12 totals into lane 0
