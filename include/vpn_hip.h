@@ -82,7 +82,7 @@ int vpn_sample_bwd(const float* params, const int32_t* kinds, const float* u,
  * none) followed by vpn_sample_bwd, without the [B,K*n,3] point gradient in between and in a fixed summation
  * order.  points [B,K*n,3] = what vpn_sample_fwd produced from the same (params, kinds, u | seed, sample_base);
  * dist/idx from vpn_chamfer_fwd*(points, gt_points); grad_loss_b [B] as in vpn_chamfer_bwd.
- * M <= 15360 (VPN_E_TOOBIG beyond: use the two separate calls). */
+ * M <= 7680 (VPN_E_TOOBIG beyond: use the two separate calls). */
 int vpn_sample_chamfer_bwd(const float* params, const int32_t* kinds, const float* u,
                            uint64_t seed, const uint64_t* seed_dev, uint64_t sample_base, int B, int K, int n,
                            const float* points, const float* gt_points, int M,

@@ -638,7 +638,7 @@ def test_hot_path_loss_single_node(vpn):
 
 
 def test_hot_path_large_gt_cloud_falls_back(vpn):
-    """GT clouds beyond the fused backward's LDS match lists (M > 15360) take the two-kernel backward: same result
+    """GT clouds beyond the fused backward's LDS match lists (M > 7680) take the two-kernel backward: same result
     as the module composition."""
     gen = torch.Generator().manual_seed(34)
     B, K, n, M, H, W = 1, 4, 64, 16000, 32, 32

@@ -766,7 +766,8 @@ __global__ __launch_bounds__(CFEAT_THREADS) void chamfer_feat_kernel(const FeatJ
 #pragma unroll
         for (int u = 0; u < CFEAT_PTS; ++u) {
             const int j = min(j0p + u * CFEAT_THREADS, N - 1);
-            xs[u] = pb[j * 3]; ys[u] = pb[j * 3 + 1]; zs[u] = pb[j * 3 + 2];
+            const F3 v3 = ld3(pb + j * 3);
+            xs[u] = v3.x; ys[u] = v3.y; zs[u] = v3.z;
         }
 #pragma unroll
         for (int u = 0; u < CFEAT_PTS; ++u) {
@@ -1055,7 +1056,8 @@ __global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_kernel(const ScanJob
     const float* qb = qpts + (size_t)b * Nq * 3;
     const int qi = (bx * 4 + wave) * 32 + jq;
     const int qc = min(qi, Nq - 1);
-    const float ax = qb[qc * 3], ay = qb[qc * 3 + 1], az = qb[qc * 3 + 2];
+    const F3 a3 = ld3(qb + qc * 3);
+    const float ax = a3.x, ay = a3.y, az = a3.z;
     // B operand (K x N): lane supplies B[k = lane/32][n = lane%32]
     const float bq0 = half ? -2.0f * ay : -2.0f * ax;
     const float bq1 = half ? 1.0f : -2.0f * az;

@@ -105,9 +105,8 @@ __global__ __launch_bounds__(SAMP_BLOCK) void sample_fwd_kernel(
         canonical_coeff(P, p, uu, c);
         float x = c[0] * P.v[0], y = c[1] * P.v[1], z = c[2] * P.v[2];
         const Mat3& R = P.pose.R;
-        out[p * 3 + 0] = (R.m[0][0] * x + R.m[0][1] * y + R.m[0][2] * z) + tx;   // rotate.py:22-23, translate.py:8
-        out[p * 3 + 1] = (R.m[1][0] * x + R.m[1][1] * y + R.m[1][2] * z) + ty;
-        out[p * 3 + 2] = (R.m[2][0] * x + R.m[2][1] * y + R.m[2][2] * z) + tz;
+        st3(out + p * 3, (R.m[0][0] * x + R.m[0][1] * y + R.m[0][2] * z) + tx,   // rotate.py:22-23, translate.py:8
+            (R.m[1][0] * x + R.m[1][1] * y + R.m[1][2] * z) + ty, (R.m[2][0] * x + R.m[2][1] * y + R.m[2][2] * z) + tz);
     }
 }
 
@@ -191,11 +190,22 @@ __global__ __launch_bounds__(SAMP_BLOCK) void sample_chamfer_bwd_kernel(
     float w1, float w2, float* __restrict__ grad_params, const RasterFinish rf) {
     __shared__ PrimLds P;
     __shared__ float red[SAMP_BLOCK / 64][12];
+    __shared__ float fin[SAMP_BLOCK / 64][12];
     __shared__ float rgrad[10];
     if (seed_dev) seed += *seed_dev;
     const int k = blockIdx.x, b = blockIdx.y, N = K * n;
     const float* prm = params + ((size_t)b * K + k) * VPN_PARAM_STRIDE;
-    if (threadIdx.x == 0) load_prim(P, prm, kinds[k], n);
+    // The raster's finishing step for the same primitive (its gradient partials were written by the forward launch of
+    // the training step) rides in this launch: every wave gathers a quarter of the tiles FIRST -- those loads depend on
+    // nothing, their latency hides behind everything below -- and thread 64 applies the chain rule at the end while
+    // thread 0 does the sampler's.
+    if (threadIdx.x == 0) load_prim(P, prm, kinds[k], n);               // first: everybody waits for it at the barrier
+    if (rf.partial) {
+        float fv[16];
+        raster_finish_gather(b * K + k, K, rf.ntile, rf.words, rf.masks, rf.partial, (int)(threadIdx.x >> 6) * 64, SAMP_BLOCK, fv);
+        const float tot = wave_reduce16(fv);
+        if ((threadIdx.x & 3) == 0 && (threadIdx.x & 63) < 48) fin[threadIdx.x >> 6][(threadIdx.x & 63) >> 2] = tot;
+    }
     __syncthreads();
     const float* ub = u ? u + ((size_t)b * K + k) * n * 3 : nullptr;
     const float* A = points + (size_t)b * N * 3;
@@ -217,7 +227,8 @@ __global__ __launch_bounds__(SAMP_BLOCK) void sample_chamfer_bwd_kernel(
         float c[3];
         if (recover) {
             const int i = k * n + pl;
-            const float dx = A[i * 3] - tx, dy = A[i * 3 + 1] - ty, dz = A[i * 3 + 2] - tz;
+            const F3 a = ld3(A + i * 3);
+            const float dx = a.x - tx, dy = a.y - ty, dz = a.z - tz;
             const Mat3& R = P.pose.R;
             c[0] = (R.m[0][0] * dx + R.m[1][0] * dy + R.m[2][0] * dz) * iv0;
             c[1] = (R.m[0][1] * dx + R.m[1][1] * dy + R.m[2][1] * dz) * iv1;
@@ -239,16 +250,17 @@ __global__ __launch_bounds__(SAMP_BLOCK) void sample_chamfer_bwd_kernel(
     for (int pl = threadIdx.x; pl < n; pl += SAMP_BLOCK) {              // own nearest neighbour
         const int i = k * n + pl, j = idx1[(size_t)b * N + i];
         const float coef = ca / dist1[(size_t)b * N + i];
-        add(pl, coef * (A[i * 3] - G2[j * 3]), coef * (A[i * 3 + 1] - G2[j * 3 + 1]), coef * (A[i * 3 + 2] - G2[j * 3 + 2]));
+        const F3 a = ld3(A + i * 3), g = ld3(G2 + j * 3);
+        add(pl, coef * (a.x - g.x), coef * (a.y - g.y), coef * (a.z - g.z));
     }
     // being a GT point's nearest neighbour: about M/K of the M entries concern this primitive, spread so that almost
     // every pass over 256 entries has a lane with a match — handled in place, the heavy body (dependent loads,
     // Philox) ran M/256 times with one or two active lanes.  So each wave first compacts its matches into LDS
     // (ballot prefix: a fixed order) and then handles them densely.
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    extern __shared__ int match[];                                      // [SAMP_BLOCK/64][cap]
+    extern __shared__ int2 match[];                                     // [SAMP_BLOCK/64][cap] of (GT point, predicted point)
     const int cap = (M + SAMP_BLOCK - 1) / SAMP_BLOCK * 64;             // entries one wave looks at
-    int* mine = match + wave * cap;
+    int2* mine = match + wave * cap;
     int cnt = 0;
     // 8 passes at a time: their loads are issued together (each pass used to wait out its own L2 round trip)
     for (int e0 = 0; e0 < M; e0 += 8 * SAMP_BLOCK) {
@@ -263,34 +275,34 @@ __global__ __launch_bounds__(SAMP_BLOCK) void sample_chamfer_bwd_kernel(
             if (e0 + u * SAMP_BLOCK >= M) break;
             const bool hit = iv[u] >= k * n && iv[u] < (k + 1) * n;
             const unsigned long long m = __ballot(hit);
-            if (hit) mine[cnt + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = e0 + u * SAMP_BLOCK + threadIdx.x;
+            if (hit) mine[cnt + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = make_int2(e0 + u * SAMP_BLOCK + (int)threadIdx.x, iv[u]);
             cnt += __builtin_popcountll(m);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");             // the wave reads its own LDS writes below
     __builtin_amdgcn_wave_barrier();
     for (int l = lane; l < cnt; l += 64) {
-        const int e = mine[l], i = idx2[(size_t)b * M + e];
+        const int e = mine[l].x, i = mine[l].y;                         // the index was read during the scan: no second look-up
         const float coef = cb / dist2[(size_t)b * M + e];
-        add(i - k * n, coef * (A[i * 3] - G2[e * 3]), coef * (A[i * 3 + 1] - G2[e * 3 + 1]), coef * (A[i * 3 + 2] - G2[e * 3 + 2]));
+        const F3 a = ld3(A + i * 3), g = ld3(G2 + e * 3);
+        add(i - k * n, coef * (a.x - g.x), coef * (a.y - g.y), coef * (a.z - g.z));
     }
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
         float s = wave_sum(acc[i]);
         if (lane == 0) red[wave][i] = s;
     }
-    // the raster's finishing step for the same primitive (its gradient partials were written by the forward launch
-    // of the training step): done by wave 1 while wave 0 runs the sampler's chain rule; saves a launch of its own
-    if (rf.partial && wave == 1) {
-        float r[10];
-        raster_finish_wave(params, rf.cam, b * K + k, K, rf.ntile, rf.words, rf.masks, rf.partial, r);
-        if (lane == 0) {
-            const float sc = rf.scale ? *rf.scale : 1.0f;
-#pragma unroll
-            for (int i = 0; i < 10; ++i) rgrad[i] = sc * r[i];
-        }
-    }
     __syncthreads();
+    if (rf.partial && threadIdx.x == 64) {                              // raster chain rule, beside thread 0's below
+        float G[12], r[10];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) G[i] = (fin[0][i] + fin[1][i]) + (fin[2][i] + fin[3][i]);
+        raster_finish_chain(params, rf.cam, b * K + k, K, G, r);
+        const float sc = rf.scale ? *rf.scale : 1.0f;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) rgrad[i] = sc * r[i];
+    }
+    float res[10];
     if (threadIdx.x == 0) {
         float G[3][3], gt3[3];
         for (int r = 0; r < 3; ++r) {
@@ -310,8 +322,12 @@ __global__ __launch_bounds__(SAMP_BLOCK) void sample_chamfer_bwd_kernel(
             for (int r = 0; r < 3; ++r) gR[r][a] = G[r][a] * P.v[a];
         }
         pose_backward(P.pose, prm[3], prm[4], prm[5], gR, gq);
+        res[0] = gv[0]; res[1] = gv[1]; res[2] = gv[2]; res[3] = gq[0]; res[4] = gq[1]; res[5] = gq[2]; res[6] = gq[3];
+        res[7] = gt3[0]; res[8] = gt3[1]; res[9] = gt3[2];
+    }
+    if (rf.partial) __syncthreads();                                    // rgrad (thread 64) -> thread 0; uniform condition
+    if (threadIdx.x == 0) {
         float* o = grad_params + ((size_t)b * K + k) * VPN_PARAM_STRIDE;
-        const float res[10] = {gv[0], gv[1], gv[2], gq[0], gq[1], gq[2], gq[3], gt3[0], gt3[1], gt3[2]};
 #pragma unroll
         for (int i = 0; i < 10; ++i) o[i] = rf.partial ? res[i] + rgrad[i] : res[i];
     }
@@ -660,8 +676,8 @@ static int launch_scb(const float* params, const int32_t* kinds, const float* u,
         return VPN_E_BADARG;
     if (B <= 0 || K <= 0 || n <= 0 || M <= 0) return VPN_E_BADARG;
     if (B > 65535 || (long long)K * n > 0x7fffffffLL / 3) return VPN_E_TOOBIG;
-    const size_t lds = (size_t)((M + SAMP_BLOCK - 1) / SAMP_BLOCK) * 64 * (SAMP_BLOCK / 64) * sizeof(int);   // = M rounded up
-    if (lds > 60 * 1024) return VPN_E_TOOBIG;                           // 15 k GT points; beyond: vpn_chamfer_bwd + vpn_sample_bwd
+    const size_t lds = (size_t)((M + SAMP_BLOCK - 1) / SAMP_BLOCK) * 64 * (SAMP_BLOCK / 64) * sizeof(int2);  // = 8 B per GT point
+    if (lds > 60 * 1024) return VPN_E_TOOBIG;                           // 7680 GT points; beyond: vpn_chamfer_bwd + vpn_sample_bwd
     VPN_LAUNCH(sample_chamfer_bwd_kernel, dim3(K, B), dim3(SAMP_BLOCK), lds, (hipStream_t)stream, params, kinds, u, seed,
                seed_dev, sample_base, K, n, points, gt_points, M, dist1, idx1, dist2, idx2, grad_loss_b, w1, w2, grad_params, rf);
     VPN_LAUNCH_CHECK();

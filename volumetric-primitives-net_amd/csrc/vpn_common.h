@@ -109,6 +109,12 @@ __device__ inline void philox_uniform3(uint64_t seed, uint64_t gb, uint32_t k, u
     u[2] = (float)(o[2] >> 8) * 5.9604644775390625e-08f;
 }
 
+// ---- xyz triples as ONE 12-byte access (global_load/store_dwordx3): three dword accesses of a gathered point are
+// three L2 requests, and a kernel whose 2048 workgroups all gather at once is bound by the L2 request rate
+struct F3 { float x, y, z; };
+__device__ inline F3 ld3(const float* p) { return *reinterpret_cast<const F3*>(p); }
+__device__ inline void st3(float* p, float x, float y, float z) { *reinterpret_cast<F3*>(p) = F3{x, y, z}; }
+
 // ---- wave64 reductions
 __device__ inline float wave_sum(float v) {
 #pragma unroll

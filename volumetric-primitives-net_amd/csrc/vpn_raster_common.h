@@ -178,32 +178,28 @@ struct RasterFinish {     // what a kernel outside raster.hip needs to run the f
     int ntile = 0, words = 0;
 };
 
-// Finishing step of the raster backward for primitive bk = b * K + k, executed by ONE WAVE: sum the per-tile
-// partials of the tiles whose mask holds k (lane = tile, fixed order), reduce, and apply the chain rule from the 12
-// ray coefficients to (v,q,t).  Lane 0 returns r[10] = d loss / d(v0 v1 v2 q0 q1 q2 q3 t0 t1 t2) for an upstream
-// gradient of 1.
-__device__ inline void raster_finish_wave(const float* __restrict__ params, const float* __restrict__ cam, int bk, int K,
-                                          int ntile, int words, const unsigned long long* __restrict__ masks,
-                                          const float* __restrict__ partial, float r[10]) {
+// Finishing step of the raster backward for primitive bk = b * K + k.
+// (1) gather: lane sums the partials of the tiles  first + lane + stride * i  whose mask holds k (fixed order);
+__device__ inline void raster_finish_gather(int bk, int K, int ntile, int words, const unsigned long long* __restrict__ masks,
+                                            const float* __restrict__ partial, int first, int stride, float v[16]) {
     const int lane = threadIdx.x & 63;
     const int b = bk / K, k = bk - b * K;
-    float v[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) v[i] = 0.0f;
     // 4 tiles per lane and round: the 4 mask words are loaded together, then the (up to) 12 float4 of the pairs
-    // that exist -- two memory round trips per 256 tiles instead of eight
-    for (int t0 = 0; t0 < ntile; t0 += 256) {
+    // that exist -- two memory round trips per round instead of eight
+    for (int t0 = first; t0 < ntile; t0 += 4 * stride) {
         bool has[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int tile = t0 + u * 64 + lane;
-            const unsigned long long m = tile < ntile ? masks[((size_t)b * ntile + tile) * words + (k >> 6)] : 0ull;
+            const int tile = t0 + u * stride + lane;
+            const unsigned long long m = (tile < ntile && t0 + u * stride < ntile) ? masks[((size_t)b * ntile + tile) * words + (k >> 6)] : 0ull;
             has[u] = (m >> (k & 63)) & 1ull;                                       // nothing was written for the other pairs
         }
         float4 pa[4], pc[4], pd[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const float4* src = reinterpret_cast<const float4*>(partial + ((size_t)bk * ntile + (t0 + u * 64 + lane)) * 12);
+            const float4* src = reinterpret_cast<const float4*>(partial + ((size_t)bk * ntile + (t0 + u * stride + lane)) * 12);
             pa[u] = pc[u] = pd[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (has[u]) { pa[u] = src[0]; pc[u] = src[1]; pd[u] = src[2]; }
         }
@@ -215,12 +211,13 @@ __device__ inline void raster_finish_wave(const float* __restrict__ params, cons
             v[8] += pd[u].x; v[9] += pd[u].y; v[10] += pd[u].z; v[11] += pd[u].w;
         }
     }
-    const float tot = wave_reduce16(v);
-    // gather the 12 totals into lane 0
-    float G[12];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) G[i] = __shfl(tot, i * 4, 64);
-    if (lane != 0) return;
+}
+
+// (2) chain rule from the 12 summed ray-coefficient gradients G to r[10] = d loss / d(v0 v1 v2 q0 q1 q2 q3 t0 t1 t2)
+// (one thread, upstream gradient 1).
+__device__ inline void raster_finish_chain(const float* __restrict__ params, const float* __restrict__ cam, int bk, int K,
+                                           const float G[12], float r[10]) {
+    const int b = bk / K;
     const float* prm = params + (size_t)bk * VPN_PARAM_STRIDE;
     const Camera C = make_camera(cam + b * 3);
     const Pose P = make_pose(prm[3], prm[4], prm[5], prm[6]);
@@ -247,6 +244,21 @@ __device__ inline void raster_finish_wave(const float* __restrict__ params, cons
     pose_backward(P, prm[3], prm[4], prm[5], gR, gq);
     r[0] = gv[0]; r[1] = gv[1]; r[2] = gv[2]; r[3] = gq[0]; r[4] = gq[1]; r[5] = gq[2]; r[6] = gq[3];
     r[7] = gt[0]; r[8] = gt[1]; r[9] = gt[2];
+}
+
+// both steps by ONE WAVE (64 consecutive tiles per round); lane 0 returns r
+__device__ inline void raster_finish_wave(const float* __restrict__ params, const float* __restrict__ cam, int bk, int K,
+                                          int ntile, int words, const unsigned long long* __restrict__ masks,
+                                          const float* __restrict__ partial, float r[10]) {
+    const int lane = threadIdx.x & 63;
+    float v[16];
+    raster_finish_gather(bk, K, ntile, words, masks, partial, 0, 64, v);
+    const float tot = wave_reduce16(v);
+    float G[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) G[i] = __shfl(tot, i * 4, 64);
+    if (lane != 0) return;
+    raster_finish_chain(params, cam, bk, K, G, r);
 }
 
 }  // namespace vpn

@@ -449,7 +449,7 @@ class RasterTotalFunction(Function):
 
 
 _PATTERNS = {}
-FUSED_BWD_MAX_GT = 15360      # vpn_sample_chamfer_bwd keeps per-wave match lists of the GT points in LDS (include/vpn_hip.h)
+FUSED_BWD_MAX_GT = 7680       # vpn_sample_chamfer_bwd keeps per-wave match lists of the GT points in LDS (include/vpn_hip.h)
 _SIDE = {}
 # optionally run the raster branch of HotPathLossFunction on a second HIP stream (VPN_CONCURRENT=1)
 CONCURRENT_BRANCHES = os.environ.get('VPN_CONCURRENT', '0') == '1'   # measured: no gain at C3 (each kernel already fills the GPU)
