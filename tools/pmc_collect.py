@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 src = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, 'gpurun_out')
 # kernels that stream their input with 16-byte-per-lane loads (float4 rows / planes)
-WIDE_READERS = ('chamfer_nn_mfma_kernel', 'chamfer_fixup_kernel', 'raster_loss_reduce_kernel')
+WIDE_READERS = ("chamfer_nn_mfma_kernel", "chamfer_fixup_kernel")
 
 
 def short(name):
