@@ -219,22 +219,6 @@ __device__ inline bool prim_hits_tile(const float4 bb, const float4 qa, const fl
     return vis;
 }
 
-// records of all (image, primitive) pairs: one lane each (also zeroes the arrival counter of the loss finalisation)
-__global__ __launch_bounds__(256) void raster_prep_kernel(const float* __restrict__ params,
-                                                          const int32_t* __restrict__ kinds,
-                                                          const float* __restrict__ cam, int BK, int K, int H, int W,
-                                                          float sigma, float4* __restrict__ rec, int* __restrict__ zero_me) {
-    const int bk = blockIdx.x * 256 + threadIdx.x;
-    if (zero_me && bk < 4) zero_me[bk] = 0;
-    if (bk >= BK) return;
-    const int b = bk / K, k = bk - b * K;
-    float4 r[R_REC];
-    make_record(params + (size_t)bk * VPN_PARAM_STRIDE, kinds[k] == VPN_SPHERE ? VPN_SPHERE : VPN_CUBOID, cam, b, H, W, sigma, r);
-    float4* out = rec + (size_t)bk * R_REC;
-#pragma unroll
-    for (int i = 0; i < R_REC; ++i) out[i] = r[i];
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // Tile kernels.  ONE WAVEFRONT (= one workgroup) PER 16x16 PIXEL TILE.  Lane l owns column l & 15 and rows (l >> 4) + 4 s, s = 0..3.  The visible primitives of the
 // tile come from the binning mask (wave-uniform: the loop is scalar control flow) and their ray coefficients are
@@ -627,7 +611,7 @@ __global__ __launch_bounds__(64, R_TOTAL_WAVES) void raster_total_kernel(const f
 
 // one wave per (b,k): raster_finish_wave (vpn_raster_common.h), then write / accumulate the gradient
 __global__ __launch_bounds__(256) void raster_bwd_finish_kernel(const float* __restrict__ params,
-                                                                const float* __restrict__ cam, int BK, int K,
+                                                                const float4* __restrict__ rec, int BK, int K,
                                                                 int ntile, int words,
                                                                 const unsigned long long* __restrict__ masks,
                                                                 const float* __restrict__ partial,
@@ -637,7 +621,7 @@ __global__ __launch_bounds__(256) void raster_bwd_finish_kernel(const float* __r
     const int bk = blockIdx.x * 4 + wave;
     if (bk >= BK) return;
     float r[10];
-    raster_finish_wave(params, cam, bk, K, ntile, words, masks, partial, r);
+    raster_finish_wave(params, rec, bk, K, ntile, words, masks, partial, r);
     if (lane != 0) return;
     const float sc = scale ? *scale : 1.0f;
     float* o = gparams + (size_t)bk * VPN_PARAM_STRIDE;
@@ -773,13 +757,13 @@ static inline const unsigned long long* masks_of(const void* records, int B, int
     return reinterpret_cast<const unsigned long long*>(reinterpret_cast<const char*>(records) + rec_bytes(B, K));
 }
 
+// the record kernel lives in sampler.hip: records written by the sampler's forward launch (hot path) and by this
+// stand-alone launch come from ONE compiled definition, so the pose the fused backward reads back is the sampler's own
+namespace vpn { int launch_raster_prep(const float* params, const int32_t* kinds, const float* cam, int B, int K, int H, int W,
+                                       float sigma, void* records, int* zero_me, hipStream_t s); }
 static int launch_prep(const float* params, const int32_t* kinds, const float* cam, int B, int K, int H, int W,
                        float sigma, void* records, int* zero_me, hipStream_t s) {
-    const int BK = B * K;
-    VPN_LAUNCH(raster_prep_kernel, dim3((BK + 255) / 256), dim3(256), 0, s, params, kinds, cam, BK, K, H, W, sigma,
-               (float4*)records, zero_me);
-    VPN_LAUNCH_CHECK();
-    return 0;
+    return vpn::launch_raster_prep(params, kinds, cam, B, K, H, W, sigma, records, zero_me, s);
 }
 
 extern "C" int vpn_raster_fwd(const float* params, const int32_t* kinds, const float* cam, int B, int K, int H,
@@ -847,7 +831,7 @@ static int launch_finish(const float* params, const float* cam, int B, int K, in
                          const void* workspace, const float* scale, float* grad_params, int accumulate, hipStream_t s) {
     const Grid G = raster_grid(B, K, H, W);
     const int BK = B * K;
-    VPN_LAUNCH(raster_bwd_finish_kernel, dim3((BK + 3) / 4), dim3(256), 0, s, params, cam, BK, K, G.ntile, G.words,
+    VPN_LAUNCH(raster_bwd_finish_kernel, dim3((BK + 3) / 4), dim3(256), 0, s, params, (const float4*)records, BK, K, G.ntile, G.words,
                masks_of(records, B, K), (const float*)workspace, scale, grad_params, accumulate);
     VPN_LAUNCH_CHECK();
     return 0;

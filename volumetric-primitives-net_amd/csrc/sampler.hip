@@ -74,6 +74,18 @@ __device__ inline void load_prim(PrimLds& P, const float* prm, int kind, int n) 
     if (P.kind == VPN_CUBOID) cuboid_quota(P.v, n, P.cum);
 }
 
+// the same with the pose the forward launch saved in the raster record (float4 10..13): no sin / cos on the critical path
+__device__ inline void load_prim_saved(PrimLds& P, const float* prm, int kind, int n, const float4* rk) {
+    const float4 p0 = rk[10], p1 = rk[11], p2 = rk[12], p3 = rk[13];
+    Pose& S = P.pose;
+    S.R.m[0][0] = p0.x; S.R.m[0][1] = p0.y; S.R.m[0][2] = p0.z; S.R.m[1][0] = p0.w; S.R.m[1][1] = p1.x; S.R.m[1][2] = p1.y;
+    S.R.m[2][0] = p1.z; S.R.m[2][1] = p1.w; S.R.m[2][2] = p2.x; S.x = p2.y; S.y = p2.z; S.z = p2.w;
+    S.w = p3.x; S.sh = p3.y; S.ch = p3.z; S.inv_len = p3.w;
+    P.v[0] = prm[0]; P.v[1] = prm[1]; P.v[2] = prm[2];
+    P.kind = kind == VPN_SPHERE ? VPN_SPHERE : VPN_CUBOID;
+    if (P.kind == VPN_CUBOID) cuboid_quota(P.v, n, P.cum);
+}
+
 __global__ __launch_bounds__(SAMP_BLOCK) void sample_fwd_kernel(
     const float* __restrict__ params, const int32_t* __restrict__ kinds, const float* __restrict__ u,
     uint64_t seed, const uint64_t* __restrict__ seed_dev, uint64_t sample_base, int K, int n,
@@ -199,7 +211,10 @@ __global__ __launch_bounds__(SAMP_BLOCK) void sample_chamfer_bwd_kernel(
     // the training step) rides in this launch: every wave gathers a quarter of the tiles FIRST -- those loads depend on
     // nothing, their latency hides behind everything below -- and thread 64 applies the chain rule at the end while
     // thread 0 does the sampler's.
-    if (threadIdx.x == 0) load_prim(P, prm, kinds[k], n);               // first: everybody waits for it at the barrier
+    if (threadIdx.x == 0) {                                             // first: everybody waits for it at the barrier
+        if (rf.rec) load_prim_saved(P, prm, kinds[k], n, rf.rec + ((size_t)b * K + k) * R_REC);
+        else load_prim(P, prm, kinds[k], n);
+    }
     if (rf.partial) {
         float fv[16];
         raster_finish_gather(b * K + k, K, rf.ntile, rf.words, rf.masks, rf.partial, (int)(threadIdx.x >> 6) * 64, SAMP_BLOCK, fv);
@@ -297,7 +312,7 @@ __global__ __launch_bounds__(SAMP_BLOCK) void sample_chamfer_bwd_kernel(
         float G[12], r[10];
 #pragma unroll
         for (int i = 0; i < 12; ++i) G[i] = (fin[0][i] + fin[1][i]) + (fin[2][i] + fin[3][i]);
-        raster_finish_chain(params, rf.cam, b * K + k, K, G, r);
+        raster_finish_chain(params, rf.rec, b * K + k, K, G, r);
         const float sc = rf.scale ? *rf.scale : 1.0f;
 #pragma unroll
         for (int i = 0; i < 10; ++i) rgrad[i] = sc * r[i];
@@ -571,6 +586,32 @@ __global__ __launch_bounds__(TR_BLOCK) void camera_transform_kernel(
     }
 }
 
+// records of all (image, primitive) pairs: one lane each (also zeroes the arrival counter of the loss finalisation)
+__global__ __launch_bounds__(256) void raster_prep_kernel(const float* __restrict__ params,
+                                                          const int32_t* __restrict__ kinds,
+                                                          const float* __restrict__ cam, int BK, int K, int H, int W,
+                                                          float sigma, float4* __restrict__ rec, int* __restrict__ zero_me) {
+    const int bk = blockIdx.x * 256 + threadIdx.x;
+    if (zero_me && bk < 4) zero_me[bk] = 0;
+    if (bk >= BK) return;
+    const int b = bk / K, k = bk - b * K;
+    float4 r[R_REC];
+    make_record(params + (size_t)bk * VPN_PARAM_STRIDE, kinds[k] == VPN_SPHERE ? VPN_SPHERE : VPN_CUBOID, cam, b, H, W, sigma, r);
+    float4* out = rec + (size_t)bk * R_REC;
+#pragma unroll
+    for (int i = 0; i < R_REC; ++i) out[i] = r[i];
+}
+
+
+int launch_raster_prep(const float* params, const int32_t* kinds, const float* cam, int B, int K, int H, int W,
+                       float sigma, void* records, int* zero_me, hipStream_t s) {
+    const int BK = B * K;
+    VPN_LAUNCH(raster_prep_kernel, dim3((BK + 255) / 256), dim3(256), 0, s, params, kinds, cam, BK, K, H, W, sigma,
+               (float4*)records, zero_me);
+    VPN_LAUNCH_CHECK();
+    return 0;
+}
+
 }  // namespace vpn
 
 using namespace vpn;
@@ -703,7 +744,7 @@ extern "C" int vpn_hotpath_bwd(const float* params, const int32_t* kinds, const 
                                const float* grad_total, float* grad_params, void* stream) {
     if (!cam || !records || !workspace || H <= 0 || W <= 0) return VPN_E_BADARG;
     RasterFinish rf;
-    rf.cam = cam;
+    rf.rec = (const float4*)records;
     rf.ntile = ((W + R_TW - 1) / R_TW) * ((H + R_TH - 1) / R_TH);
     rf.words = (K + 63) / 64;
     rf.masks = reinterpret_cast<const unsigned long long*>(reinterpret_cast<const char*>(records) + (size_t)B * K * R_REC * sizeof(float4));

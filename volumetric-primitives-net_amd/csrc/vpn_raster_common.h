@@ -15,7 +15,7 @@ constexpr float R_EPS_D = 1e-9f;
 constexpr float R_X_CUT = 16.0f;     // primitives whose coverage logit is below -X_CUT on a tile are skipped: coverage < 1.2e-7
 constexpr int R_TW = 16, R_TH = 16;  // pixel tile per wave
 constexpr int R_PPL = 4;             // pixels per lane (row groups of 4 rows)
-constexpr int R_REC = 7;             // float4 per primitive record in HBM
+constexpr int R_REC = 14;            // float4 per primitive record in HBM: 7 for the tile kernels, 7 for the finishing step
 constexpr int R_CULL = 3;            // float4 per primitive staged in LDS by the binning kernel (pixel box + conic)
 
 struct Camera {
@@ -69,6 +69,15 @@ __device__ inline void make_record(const float* __restrict__ prm, int kind, cons
     Pose P = make_pose(prm[3], prm[4], prm[5], prm[6]);
     PrimGeo G;
     prim_geometry(C, P.R, v, t, G);
+    // out[7..13]: camera basis and pose as the finishing step of the backward needs them (it used to redo the six
+    // sin / cos of make_camera and make_pose on one lane: ~1000 dependent instructions on its critical path)
+    out[7] = make_float4(C.eye[0], C.eye[1], C.eye[2], C.right[0]);
+    out[8] = make_float4(C.right[1], C.right[2], C.up[0], C.up[1]);
+    out[9] = make_float4(C.up[2], C.fwd[0], C.fwd[1], C.fwd[2]);
+    out[10] = make_float4(P.R.m[0][0], P.R.m[0][1], P.R.m[0][2], P.R.m[1][0]);
+    out[11] = make_float4(P.R.m[1][1], P.R.m[1][2], P.R.m[2][0], P.R.m[2][1]);
+    out[12] = make_float4(P.R.m[2][2], P.x, P.y, P.z);
+    out[13] = make_float4(P.w, P.sh, P.ch, P.inv_len);
     out[0] = make_float4(G.o[0], G.o[1], G.o[2], __int_as_float(kind));
     out[1] = make_float4(G.Mr[0], G.Mr[1], G.Mr[2], 0.f);
     out[2] = make_float4(G.Mu[0], G.Mu[1], G.Mu[2], 0.f);
@@ -171,7 +180,7 @@ struct RasterPrep {       // what a kernel outside raster.hip needs to write the
 };
 
 struct RasterFinish {     // what a kernel outside raster.hip needs to run the finishing step (partial == nullptr: nothing to do)
-    const float* cam = nullptr;
+    const float4* rec = nullptr;       // the records (camera basis and pose live in float4 7..13 of each)
     const unsigned long long* masks = nullptr;
     const float* partial = nullptr;
     const float* scale = nullptr;      // device scalar: upstream gradient of the fused total (nullptr = 1)
@@ -215,12 +224,18 @@ __device__ inline void raster_finish_gather(int bk, int K, int ntile, int words,
 
 // (2) chain rule from the 12 summed ray-coefficient gradients G to r[10] = d loss / d(v0 v1 v2 q0 q1 q2 q3 t0 t1 t2)
 // (one thread, upstream gradient 1).
-__device__ inline void raster_finish_chain(const float* __restrict__ params, const float* __restrict__ cam, int bk, int K,
+__device__ inline void raster_finish_chain(const float* __restrict__ params, const float4* __restrict__ rec, int bk, int K,
                                            const float G[12], float r[10]) {
-    const int b = bk / K;
     const float* prm = params + (size_t)bk * VPN_PARAM_STRIDE;
-    const Camera C = make_camera(cam + b * 3);
-    const Pose P = make_pose(prm[3], prm[4], prm[5], prm[6]);
+    const float4* rk = rec + (size_t)bk * R_REC + 7;                  // camera basis and pose saved by make_record
+    const float4 c0 = rk[0], c1 = rk[1], c2 = rk[2], p0 = rk[3], p1 = rk[4], p2 = rk[5], p3 = rk[6];
+    Camera C;
+    C.eye[0] = c0.x; C.eye[1] = c0.y; C.eye[2] = c0.z; C.right[0] = c0.w; C.right[1] = c1.x; C.right[2] = c1.y;
+    C.up[0] = c1.z; C.up[1] = c1.w; C.up[2] = c2.x; C.fwd[0] = c2.y; C.fwd[1] = c2.z; C.fwd[2] = c2.w; C.dist = 0.0f;
+    Pose P;
+    P.R.m[0][0] = p0.x; P.R.m[0][1] = p0.y; P.R.m[0][2] = p0.z; P.R.m[1][0] = p0.w; P.R.m[1][1] = p1.x; P.R.m[1][2] = p1.y;
+    P.R.m[2][0] = p1.z; P.R.m[2][1] = p1.w; P.R.m[2][2] = p2.x; P.x = p2.y; P.y = p2.z; P.z = p2.w;
+    P.w = p3.x; P.sh = p3.y; P.ch = p3.z; P.inv_len = p3.w;
     const float vv[3] = {prm[0], prm[1], prm[2]};
     const float t[3] = {prm[7], prm[8], prm[9]};
     PrimGeo Ge;
@@ -247,7 +262,7 @@ __device__ inline void raster_finish_chain(const float* __restrict__ params, con
 }
 
 // both steps by ONE WAVE (64 consecutive tiles per round); lane 0 returns r
-__device__ inline void raster_finish_wave(const float* __restrict__ params, const float* __restrict__ cam, int bk, int K,
+__device__ inline void raster_finish_wave(const float* __restrict__ params, const float4* __restrict__ rec, int bk, int K,
                                           int ntile, int words, const unsigned long long* __restrict__ masks,
                                           const float* __restrict__ partial, float r[10]) {
     const int lane = threadIdx.x & 63;
@@ -258,7 +273,7 @@ __device__ inline void raster_finish_wave(const float* __restrict__ params, cons
 #pragma unroll
     for (int i = 0; i < 12; ++i) G[i] = __shfl(tot, i * 4, 64);
     if (lane != 0) return;
-    raster_finish_chain(params, cam, bk, K, G, r);
+    raster_finish_chain(params, rec, bk, K, G, r);
 }
 
 }  // namespace vpn
