@@ -68,24 +68,37 @@ def load_pmc(workload_key):
         return {}
 
 
+def load_isa_mix():
+    """Static issue-class mix of the raster kernels (tools/isa_mix.py -> profiles/r02_isa_mix.json)."""
+    try:
+        return json.load(open(os.path.join(ROOT, 'profiles', 'r02_isa_mix.json')))
+    except (OSError, ValueError):
+        return {}
+
+
 def valu_issue_roofline(name, pmc, launch_us):
-    """Executed-work roofline of a VALU-bound kernel: wave-instructions actually issued (PMC) x their issue cost
-    (2 cycles per wave64 instruction on a SIMD-32, 4 for the quarter-rate transcendentals: MI355X_MICROARCH.md
-    'vector-instruction ISSUE cost' halves of the one-wave figures) / (launch time x SIMDs x clock)."""
+    """Executed-work roofline of a VALU-bound kernel: wave-instructions actually issued (PMC SQ_INSTS_VALU) x their
+    issue cost / (launch time x SIMDs x clock).  Two prices: (a) every instruction at the plain rate the guide gives
+    (2 cycles per wave64 instruction per SIMD) -- a lower bound of the utilisation; (b) class-weighted with the
+    kernel's static ISA mix and the issue costs MEASURED on this chip (tools/ubench/valu_rates2.hip: plain 2.5,
+    v_min/max/cmp/cndmask/DPP/SGPR-operand 4.3, transcendental 8.3 cycles; gfx950 has no counter that splits
+    SQ_INSTS_VALU by class)."""
     k = pmc.get(name)
     if not k or 'SQ_INSTS_VALU' not in k:
         return None
     valu = k['SQ_INSTS_VALU']
-    trans = k.get('SQ_INSTS_VALU_TRANS', 0.0)
-    cycles = 2.0 * (valu - trans) + 4.0 * trans
     clock = 2.4e9
-    frac = cycles / (launch_us * 1e-6 * clock * N_SIMD)
-    out = {'valu_wave_insts': valu, 'trans_wave_insts': trans, 'issue_cycles': cycles,
-           'frac_of_valu_issue_peak_at_2.4GHz': round(frac, 4)}
+    avail = launch_us * 1e-6 * clock * N_SIMD
+    out = {'valu_wave_insts': valu, 'issue_cycles_plain_price': 2.0 * valu,
+           'frac_of_valu_issue_peak_at_2.4GHz': round(2.0 * valu / avail, 4)}
+    mix = load_isa_mix().get(name)
+    if mix:
+        out['isa_mix'] = {c: round(v, 3) for c, v in mix['mix'].items()}
+        out['cycles_per_valu_measured_classes'] = round(mix['cycles_per_valu'], 2)
+        out['frac_of_measured_valu_issue_capacity'] = round(valu * mix['cycles_per_valu'] / avail, 4)
     if 'GRBM_GUI_ACTIVE' in k:      # sum over the 8 XCDs of active cycles -> the clock the launch actually ran at
         eff = k['GRBM_GUI_ACTIVE'] / 8.0 / (launch_us * 1e-6)
         out['effective_clock_GHz'] = round(eff / 1e9, 3)
-        out['frac_of_valu_issue_peak_at_effective_clock'] = round(cycles / (launch_us * 1e-6 * eff * N_SIMD), 4)
     for c in ('SQ_INSTS_SALU', 'SQ_WAVES', 'SQ_WAIT_INST_ANY', 'SQ_WAVE_CYCLES', 'SQ_BUSY_CYCLES'):
         if c in k:
             out[c] = k[c]

@@ -122,7 +122,11 @@ int vpn_chamfer_nn(const float* queries, const float* targets, int B, int Nq, in
  *           |b|^2 - 2a.b for 32x32 pairs, the candidates are re-evaluated with the exact separately-rounded
  *           d2 (a rigorous error band decides when a second block or a full exact rescan is needed);
  *   mode 4  the same filter with fp32-input MFMA;
- *   mode 0  automatic (mode 3 for large clouds when a workspace is given, else mode 1). */
+ *   mode 5  mode 3 over Morton-sorted clouds with per-block boxes (target blocks that cannot hold a nearer point skipped);
+ *   mode 6  the filter with ONE fp16 MFMA per 32x32 block: coordinates scaled by 2^11 and split into two fp16
+ *           pieces (32-byte rows); queries or clouds with |p|^2 > 64 are outside its domain and are finished by
+ *           the exact rescan (results unchanged, only slower);
+ *   mode 0  automatic (mode 6 for large clouds when a workspace is given, else mode 1). */
 size_t vpn_chamfer_workspace(int B, int N, int M);
 /* workspace_bytes: size of `workspace`; VPN_E_BADARG if a mode that uses it is given fewer than
  * vpn_chamfer_workspace(B,N,M) bytes or a pointer that is not 16-byte aligned (the filtered scans fetch row

@@ -81,7 +81,10 @@ __device__ inline bool emd_group_sync(unsigned* counter, unsigned& passed, int G
         unsigned spins = 0;
         while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < passed) {
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > EMD_SPIN_LIMIT || __hip_atomic_load(counter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            // the give-up flag of the group is polled every 256th spin only: a second L2 round trip per spin would
+            // lengthen every barrier of every round
+            if (++spins > EMD_SPIN_LIMIT ||
+                ((spins & 255u) == 0 && __hip_atomic_load(counter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
                 __hip_atomic_store(counter + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // tell the others
                 *gave_up = 1;
                 break;

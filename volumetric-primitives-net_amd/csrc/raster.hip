@@ -10,15 +10,16 @@
 // pinned to reference-derived data by tests/test_raster_geometry.py).
 //
 // Work decomposition (CDNA4):
-//   * binning kernel (once per call): per (image, primitive) the pose from q, the camera-space ray
-//     coefficients (o~, Mr, Mu, Mf), the exact culling conic and its pixel box -> a 7 x float4 record
-//     [B,K,7]; then per (image, 16x16 tile) a bit mask of the primitives that can touch the tile (pixel box,
-//     then exact conic-vs-rectangle; a primitive is dropped only where its coverage logit is below -X_CUT:
-//     coverage < 1.2e-7).  Forward, backward and the finishing kernel share the masks;
-//   * tile kernels: ONE WAVEFRONT PER 16x16 PIXEL TILE, four independent waves per workgroup (a 32x32 pixel
-//     block: no LDS, no barrier).  The tile's primitive list is the mask (scalar control flow); the ray
-//     coefficients are read with wave-uniform addresses.  Lane l owns column l&15 and rows (l>>4)+4s,
-//     s=0..3: backward accumulates its 4 pixels in registers before the cross-lane reduction;
+//   * records (raster_prep_kernel in sampler.hip, or the sampler's own forward launch in the hot-path step): per
+//     (image, primitive) the pose from q, the camera-space ray coefficients (o~, Mr, Mu, Mf), the exact culling
+//     conic and its pixel box, then the camera basis and the pose for the backward chain rule -> R_REC float4
+//     [B,K,14] (vpn_raster_common.h);
+//   * tile kernels: ONE WAVEFRONT = ONE WORKGROUP PER 16x16 PIXEL TILE, 1-D grid in centre-out tile order with the
+//     images interleaved (the heavy tiles start first, every XCD gets the same mix).  The wave first builds the
+//     tile's primitive mask itself (lane = primitive: pixel box, then exact conic-vs-rectangle; a primitive is
+//     dropped only where its coverage logit is below -X_CUT: coverage < 1.2e-7), stages the records of the
+//     visible primitives in its own LDS slice and loops over them with scalar control flow.  Lane l owns one
+//     pixel in each 8x8 quadrant of the tile; a primitive is evaluated per quadrant only where it can reach it;
 //   * raster_total_kernel: forward AND backward of the training step's image losses in one pass (state in
 //     registers, no `aux`, GT read once); raster_fwd / raster_bwd kernels: the general two-call form (images or
 //     two separately weighted losses), with the per-pixel state saved in `aux`;
@@ -220,9 +221,9 @@ __device__ inline bool prim_hits_tile(const float4 bb, const float4 qa, const fl
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Tile kernels.  ONE WAVEFRONT (= one workgroup) PER 16x16 PIXEL TILE.  Lane l owns column l & 15 and rows (l >> 4) + 4 s, s = 0..3.  The visible primitives of the
-// tile come from the binning mask (wave-uniform: the loop is scalar control flow) and their ray coefficients are
-// read straight from the record array with wave-uniform addresses.
+// Tile kernels.  ONE WAVEFRONT (= one workgroup) PER 16x16 PIXEL TILE.  The visible primitives of the tile come from
+// the tile mask the wave builds itself (wave-uniform: the loop is scalar control flow); their records are staged in
+// the wave's LDS slice and read from there with vector loads (an SGPR operand makes a VALU instruction slow-class).
 
 // Lane l owns one pixel in each 8x8 QUADRANT of the tile: slot s = quadrant (s & 1, s >> 1), position (l & 7, l >> 3)
 // inside it.  A primitive is evaluated per quadrant only where it can reach it (second, 8x8 level of the cull).
@@ -382,7 +383,7 @@ __device__ inline unsigned long long tile_forward(const Tile& T, const float4* _
 
 // backward over the tile's visible primitives: per pixel x primitive analytic gradient w.r.t. the 12 ray
 // coefficients, summed over the lane's 4 pixels, reduced over the wave and written as 48 contiguous bytes of
-// partial[b][k][tile] -- only for the (primitive, tile) pairs of the binning mask; raster_bwd_finish_kernel reads
+// partial[b][k][tile] -- only for the (primitive, tile) pairs of the tile masks; raster_bwd_finish_kernel reads
 // exactly those.  No atomics: bitwise reproducible.  `staged`: srec already holds the records of mask word 0 = m0
 // (one-pass kernel with K <= 64); mrow: masks stored by an EARLIER launch, or null to repeat the test (a wave does not
 // read back the mask words it stored itself a moment ago).

@@ -1,4 +1,4 @@
-// vpn_raster_common.h — pieces of the primitive raster shared by raster.hip (binning, tile kernels) and
+// vpn_raster_common.h — pieces of the primitive raster shared by raster.hip (tile kernels) and
 // sampler.hip (the hot-path kernels that fold the raster's per-primitive work into the sampler's launches):
 // camera, per-primitive records, the wave reduction and the finishing chain rule.  gfx950 only.
 #pragma once
@@ -16,7 +16,7 @@ constexpr float R_X_CUT = 16.0f;     // primitives whose coverage logit is below
 constexpr int R_TW = 16, R_TH = 16;  // pixel tile per wave
 constexpr int R_PPL = 4;             // pixels per lane (row groups of 4 rows)
 constexpr int R_REC = 14;            // float4 per primitive record in HBM: 7 for the tile kernels, 7 for the finishing step
-constexpr int R_CULL = 3;            // float4 per primitive staged in LDS by the binning kernel (pixel box + conic)
+constexpr int R_CULL = 3;            // float4 per primitive staged in LDS for the tile mask (pixel box + conic)
 
 struct Camera {
     float eye[3], right[3], up[3], fwd[3];

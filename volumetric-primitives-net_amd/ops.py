@@ -475,7 +475,7 @@ class HotPathLossFunction(Function):
     """One training-step loss of the reference's hot path in a single autograd node (train.py:243-262):
         total = w_cd * ChamferDistanceLoss(sample(params), gt_points; cd_w1, cd_w2) + w_sil * SilhouetteLoss
                 + w_depth * L1(depth)
-    Forward: sampler -> Chamfer scans; binning -> raster forward+backward pass (image losses and their gradient
+    Forward: sampler (+ raster records) -> Chamfer scans -> raster forward+backward pass (image losses and their gradient
     partials in one launch) -> loss finalisation (per-sample Chamfer losses, image losses, total).  Backward:
     Chamfer + sampler backward (writes d/dparams) -> raster finishing kernel (adds to it).  No intermediate ever goes
     through an ATen kernel.  Returns three scalars (silhouette loss, depth loss, total); only the total is
