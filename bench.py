@@ -203,6 +203,9 @@ def main():
     ap.add_argument('--dist-selftest', action='store_true',
                     help='run the multi-rank code path (RCCL group, gradient collective) even with one rank')
     ap.add_argument('--cpu-sample', type=int, default=32, help='images in the CPU baseline sample')
+    ap.add_argument('--rehearse', action='store_true',
+                    help='rehearsal of the N>1 code path on a ONE-GPU box: every rank uses cuda:0 and the process group '
+                         'is gloo instead of RCCL (which refuses two ranks on one device); not a measurement')
     args = ap.parse_args()
     if args.no_extras:
         args.no_cpu_baseline = args.no_c2 = True
@@ -216,13 +219,18 @@ def main():
             sys.exit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d'
                      % (args.gpus, args.gpus))
         args.gpus = world
+    if args.rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     multi = world > 1 or args.dist_selftest
     if multi:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if args.rehearse:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     import vpn_amd
     from vpn_amd import _lib
@@ -448,7 +456,7 @@ def main():
         coll = 'none'
         if multi:
             nbytes = (Bg * K * 10 + 1) * 4 if args.collective == 'allreduce' else (B * K * 10 + 4) * 4
-            coll = 'rccl %s, %d B per rank per step' % ('all-reduce (sum) of the global gradient buffer'
+            coll = '%s %s, %d B per rank per step' % ('REHEARSAL over gloo, all ranks on one GPU:' if args.rehearse else 'rccl', 'all-reduce (sum) of the global gradient buffer'
                                                        if args.collective == 'allreduce' else 'all-gather', nbytes)
         name = 'C3' if not args.global_batch else ('C4' if (Bg, K, H) == (256, 32, 256) else 'C3-shape')
         out = {
