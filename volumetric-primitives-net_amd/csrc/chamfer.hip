@@ -394,6 +394,15 @@ __device__ inline float wave_max_u(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+__device__ inline unsigned wave_max_bits(unsigned v) {
+#define VPN_DPPU(v, ctrl, rmask) (unsigned)__builtin_amdgcn_update_dpp((int)(v), (int)(v), ctrl, rmask, 0xf, false)
+    v = max(v, VPN_DPPU(v, 0x111, 0xf)); v = max(v, VPN_DPPU(v, 0x112, 0xf));
+    v = max(v, VPN_DPPU(v, 0x114, 0xf)); v = max(v, VPN_DPPU(v, 0x118, 0xf));
+    v = max(v, VPN_DPPU(v, 0x142, 0xa)); v = max(v, VPN_DPPU(v, 0x143, 0xc));
+#undef VPN_DPPU
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 __device__ inline unsigned spread4(unsigned v) {   // bit i -> bit 3i
     return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6);
 }
@@ -1013,13 +1022,19 @@ __device__ inline float min16(const f16v& v) {
 // needs the query's norm and m2 only, not the largest norm of the cloud -- for a query near the centre of the cloud
 // the band shrinks ~2x and with it the number of undecided queries.  (Rigour: DESIGN.md 4.1; the factors 1 + 2e-6
 // cover the fp32 rounding of the two square roots and of the sum.)
-__device__ inline float near_error(float eps, float abs_eps, float na, float m2, float E_cloud) {
-    const float rb = (sqrtf(na) + sqrtf(m2)) * (1.0f + 2.0e-6f);
+// sna, sm2: UPPER bounds of sqrt(na), sqrt(m2) good to ~1e-6 relative (sqrt_up below, or IEEE sqrt): a correctly
+// rounded sqrt is a ~12-instruction sequence here and this runs once per query in an issue-bound kernel.
+__device__ inline float near_error(float eps, float abs_eps, float na, float sna, float sm2, float E_cloud) {
+    const float rb = (sna + sm2) * (1.0f + 2.0e-6f);
     const float nbn = rb * rb;
-    // abs_eps (|a|_1 + |b|_1) <= abs_eps sqrt(3) (|a| + |b|): the fp16 pieces' absolute floor (0 for the other filters)
-    const float En = (eps * (2.0f * sqrtf(na * nbn) + nbn + na) + abs_eps * 1.7320509f * (sqrtf(na) + rb)) * (1.0f + 1.0e-6f);
+    // sqrt(na nbn) = sqrt(na) rb <= sna rb;  abs_eps (|a|_1 + |b|_1) <= abs_eps sqrt(3) (|a| + |b|): the fp16 pieces'
+    // absolute floor (0 for the other filters)
+    const float En = (eps * (2.0f * sna * rb + nbn + na) + abs_eps * 1.7320509f * (sna + rb)) * (1.0f + 2.0e-6f);
     return fminf(En, E_cloud);
 }
+// upper bound of sqrt(x), x >= 0: v_sqrt_f32 is good to 1 ulp (6e-8); the factor covers it and the roundings of the
+// products it enters, the constant a flushed denormal input (sqrt of a denormal < 1.1e-19)
+__device__ inline float sqrt_up(float x) { return __builtin_amdgcn_sqrtf(x) * (1.0f + 4.0e-7f) + 1.0e-18f; }
 
 struct ScanJob {          // one direction of a Chamfer call
     const float* qpts; const float* F; const unsigned short* H; const unsigned int* nmax;
@@ -1353,43 +1368,63 @@ __global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_kernel(const ScanJob
             const float xs[4] = {X[v].x, X[v].y, X[v].z, X[v].w}, ys[4] = {Y[v].x, Y[v].y, Y[v].z, Y[v].w};
             const float zs[4] = {Z[v].x, Z[v].y, Z[v].z, Z[v].w};
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const int e = v * 4 + w;
-                d2[e] = dist2_exact(ax, ay, az, xs[w], ys[w], zs[w]) + ((base + e < Nt) ? 0.0f : __builtin_inff());   // no branch
-                m2 = fminf(m2, d2[e]);
-            }
+            for (int w = 0; w < 4; ++w) d2[v * 4 + w] = dist2_exact(ax, ay, az, xs[w], ys[w], zs[w]);
         }
+        // padding targets (coordinates 0) are masked only by the waves whose best block reaches into the padding:
+        // three instructions per target that the other waves (all of them when Nt is a multiple of 32) skip
+        if (__ballot(base + 16 > Nt)) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) d2[e] += (base + e < Nt) ? 0.0f : __builtin_inff();
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) m2 = fminf(m2, d2[e]);
     }
     m2 = fminf(m2, __shfl_xor(m2, 32, 64));
     // t = d2 - |a|^2 within E; exact d2 within 4e-7 relative: a block whose filtered minimum lies outside `band`
     // can neither win nor tie.  Otherwise the query is undecided here and goes to the fix-up list.
-    float nb = 0.0f;
-#pragma unroll
-    for (int w = 0; w < CFEAT_SLOTS; ++w) nb = fmaxf(nb, __uint_as_float(nmax[b * CFEAT_SLOTS + w]));
+    static_assert(CFEAT_SLOTS <= 64, "one slot per lane");
+    // norms are >= 0: their bit patterns order like unsigned integers (v_max_u32 takes the DPP operand directly and
+    // needs no NaN quieting; a NaN norm has the largest pattern and so survives, as it must)
+    const float nb = __uint_as_float(wave_max_bits(lane < CFEAT_SLOTS ? nmax[b * CFEAT_SLOTS + lane] : 0u));
     const float na = ax * ax + ay * ay + az * az;
-    float E = (PREC == 2 ? CM_EPS_F16 : (PREC == 1 ? CM_EPS_BF16 : CM_EPS)) * (2.0f * sqrtf(na * nb) + nb + na);
+    const float sna = sqrt_up(na), snb = sqrt_up(nb);                           // bounds only: no IEEE sqrt sequences
+    float E = (PREC == 2 ? CM_EPS_F16 : (PREC == 1 ? CM_EPS_BF16 : CM_EPS)) * (2.0f * sna * snb + nb + na) * (1.0f + 1.0e-6f);
     if (PREC == 2) {
-        E += 5.9604644775390625e-08f * 1.7320509f * (sqrtf(na) + sqrtf(nb));    // absolute floor of the fp16 pieces
+        E += 5.9604644775390625e-08f * 1.7320509f * (sna + snb);               // absolute floor of the fp16 pieces
         Bv *= CM_INV_S16SQ; V2 *= CM_INV_S16SQ;                                 // the fp16 filter works on S x: values scaled by S^2
     }
     // m2 is exact, so the runner-up is compared with it rather than with the filtered value of the best block:
     // only the runner-up's own filter error E remains (the band was 2E before; this halves the undecided queries).
     // 4e-6 m2 covers the rounding of m2 and of |a|^2 and the width of a sqrt bucket.
+    const float s = sqrtf(m2);                                      // IEEE: this one is the result
     const float band = E + 4.0e-6f * (m2 + na);                     // any target of the cloud (consistency of the best block)
     const float band_near = near_error(PREC == 2 ? CM_EPS_F16 : (PREC == 1 ? CM_EPS_BF16 : CM_EPS), PREC == 2 ? 5.9604644775390625e-08f : 0.0f,
-                                       na, m2, E) + 4.0e-6f * (m2 + na);   // possible winners
+                                       na, sna, s * (1.0f + 1.0e-7f), E) + 4.0e-6f * (m2 + na);   // possible winners
     bool ambiguous = !(V2 > (m2 - na) + band_near) || !(m2 - na <= Bv + band);
     if (PREC == 2) ambiguous |= !(nb <= CM_DOMAIN16 && na <= CM_DOMAIN16);     // outside the fp16 filter's range: exact fix-up
-    const float s = sqrtf(m2);
     // lowest index attaining the minimum; a different d2 can only share the sqrt if it lies within a few ulp
     // of it, which is rare: only then are the sqrt values compared
     const float lim = m2 * (1.0f + 1.0e-6f);
-    int idx = 0x7fffffff;
-    bool near_tie = false;
+    int li = 16;                                                    // position inside this lane's 16 targets (inline constants)
 #pragma unroll
-    for (int e = 15; e >= 0; --e) {
-        if (d2[e] == m2) idx = K + half * 16 + e;
-        near_tie |= (d2[e] != m2) && (d2[e] <= lim);
+    for (int e = 15; e >= 0; --e)
+        if (d2[e] == m2) li = e;
+    int idx = li < 16 ? K + half * 16 + li : 0x7fffffff;
+    // near tie: some d2 with m2 < d2 <= lim.  d2 >= 0, so the bit patterns order like the values: the smallest
+    // (bits(d2) - bits(m2) - 1) as an unsigned number is below bits(lim) - bits(m2) exactly then (equal values wrap
+    // to 0xffffffff; a NaN d2 has a larger pattern than any finite lim).  One subtraction per target and a min3 tree
+    // instead of three compares and two mask operations per target.
+    bool near_tie;
+    {
+        const unsigned mb1 = __float_as_uint(m2) + 1u;
+        unsigned g[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) g[e] = __float_as_uint(d2[e]) - mb1;
+        auto umin3 = [](unsigned a, unsigned b, unsigned c) { return min(min(a, b), c); };
+        const unsigned t0 = umin3(g[0], g[1], g[2]), t1 = umin3(g[3], g[4], g[5]), t2 = umin3(g[6], g[7], g[8]);
+        const unsigned t3 = umin3(g[9], g[10], g[11]), t4 = umin3(g[12], g[13], g[14]);
+        const unsigned gm = umin3(umin3(t0, t1, t2), umin3(t3, t4, g[15]), 0xffffffffu);
+        near_tie = m2 < __builtin_inff() && gm < __float_as_uint(lim) - __float_as_uint(m2);
     }
     if (__ballot(near_tie)) {
 #pragma unroll
@@ -1704,9 +1739,9 @@ __global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_pruned_kernel(
     }
     m2 = fminf(m2, __shfl_xor(m2, 32, 64));
     const float band = E + 4.0e-6f * (m2 + na);
-    const float band_near = near_error(CM_EPS_BF16, 0.0f, na, m2, E) + 4.0e-6f * (m2 + na);
-    const bool ambiguous = !(V2 > (m2 - na) + band_near) || !(m2 - na <= Bv + band);
     const float s = sqrtf(m2);
+    const float band_near = near_error(CM_EPS_BF16, 0.0f, na, sqrt_up(na), s * (1.0f + 1.0e-7f), E) + 4.0e-6f * (m2 + na);
+    const bool ambiguous = !(V2 > (m2 - na) + band_near) || !(m2 - na <= Bv + band);
     const float lim = m2 * (1.0f + 1.0e-6f);
     int idx = 0x7fffffff;
     bool near_tie = false;
