@@ -1017,6 +1017,23 @@ __device__ inline float min16(const f16v& v) {
     return vmin3(vmin3(a, b, c), g, g);
 }
 
+// the same over the 32 accumulators of two blocks: 16 instructions (10 compiler-visible first-level v_min3, then 6)
+__device__ inline float min32(const f16v& u, const f16v& v) {
+    const float a = __builtin_fminf(__builtin_fminf(u[0], u[1]), u[2]);
+    const float b = __builtin_fminf(__builtin_fminf(u[3], u[4]), u[5]);
+    const float c = __builtin_fminf(__builtin_fminf(u[6], u[7]), u[8]);
+    const float d = __builtin_fminf(__builtin_fminf(u[9], u[10]), u[11]);
+    const float e = __builtin_fminf(__builtin_fminf(u[12], u[13]), u[14]);
+    const float a2 = __builtin_fminf(__builtin_fminf(v[0], v[1]), v[2]);
+    const float b2 = __builtin_fminf(__builtin_fminf(v[3], v[4]), v[5]);
+    const float c2 = __builtin_fminf(__builtin_fminf(v[6], v[7]), v[8]);
+    const float d2 = __builtin_fminf(__builtin_fminf(v[9], v[10]), v[11]);
+    const float e2 = __builtin_fminf(__builtin_fminf(v[12], v[13]), v[14]);
+    const float g = vmin3(d, e, u[15]), g2 = vmin3(d2, e2, v[15]);
+    const float h = vmin3(a, b, c), h2 = vmin3(a2, b2, c2);
+    return vmin3(vmin3(h, g, h2), g2, g2);
+}
+
 // Filter error of the targets that can still WIN OR TIE once the exact minimum m2 of the best block is known: such a
 // target b has exact d2(a, b) <= m2 (1 + 1e-6), hence |b| <= |a| + sqrt(m2) (triangle inequality): its error bound
 // needs the query's norm and m2 only, not the largest norm of the cloud -- for a query near the centre of the cloud
@@ -1150,12 +1167,14 @@ __global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_kernel(const ScanJob
             return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, o), bq, zero, 0, 0, 0);
         };
         static_assert(CM_TILE16 == 256, "the tile loop below is unrolled for 8 blocks per tile");
-#define CM_PAIR(oa, ob, JA, JB)                                                                \
+// The tracked unit is a PAIR of blocks (64 targets): one 16-instruction tree over both accumulators and one
+// 4-instruction update per pair, 10 VALU instructions per block instead of 12 in a loop bound by VALU issue; the
+// exact finish then works on the winning half-wave's 32 rows of the pair (CM_CELL below).
+#define CM_PAIR(oa, ob, J)                                                                     \
     {                                                                                          \
         const f16v accA = block(oa), accB = block(ob);                                         \
-        const float mA = min16(accA), mB = min16(accB);                                        \
-        CM_UPDATE_C(mA, JA)                                                                    \
-        CM_UPDATE_C(mB, JB)                                                                    \
+        const float mAB = min32(accA, accB);                                                   \
+        CM_UPDATE_C(mAB, J)                                                                    \
     }
         Pre pre = fetch(0);
         stash(0, pre);
@@ -1168,17 +1187,17 @@ __global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_kernel(const ScanJob
             const unsigned char* T = &tileH[buf][jq * CM_ROWB + half * 16];
             const float before = best;
             float4 a0 = rd(T, 0), a1 = rd(T, 1), b0 = rd(T, 2), b1 = rd(T, 3);
-            CM_PAIR(a0, a1, 0, 1)
+            CM_PAIR(a0, a1, 0)
             if (nblk > 2) {
                 a0 = rd(T, 4); a1 = rd(T, 5);
-                CM_PAIR(b0, b1, 2, 3)
+                CM_PAIR(b0, b1, 1)
                 if (nblk > 4) {
                     b0 = rd(T, 6); b1 = rd(T, 7);
-                    CM_PAIR(a0, a1, 4, 5)
-                    if (nblk > 6) CM_PAIR(b0, b1, 6, 7)
+                    CM_PAIR(a0, a1, 2)
+                    if (nblk > 6) CM_PAIR(b0, b1, 3)
                 }
             }
-            blk = best < before ? t0 + (blkc << 5) : blk;            // the tile improved this lane's minimum
+            blk = best < before ? t0 + (blkc << 6) : blk;            // the tile improved this lane's minimum
             if (more) stash(buf ^ 1, pre);
             __syncthreads();
         }
@@ -1334,50 +1353,59 @@ __global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_kernel(const ScanJob
         __syncthreads();                            // everybody done with `buf`, next tile landed
     }
     }
-    // merge the two half-waves that share a query (they saw disjoint halves of every block): the best block K and
-    // the exact smallest block minimum V2 among all the other blocks
-    int K;
+    // The tracked unit (cell) is what ONE half-wave saw of CM_CELL consecutive targets: lane (jq, half) holds the
+    // accumulator rows 8 g + 4 half + r (g = 0 .. CM_CELL/8 - 1, r = 0..3) of every block.  The winner is the cell with
+    // the smallest filtered minimum over both half-waves of the query; V2 = the smallest filtered minimum over ALL other
+    // cells (the loser's best, the winner's second).  Only the winner cell is evaluated exactly, its CM_CELL/2 targets
+    // split over the two lanes of the query: half of the exact work of evaluating the whole block (or pair of blocks).
+    constexpr int CM_CELL = PREC == 2 ? 64 : 32;       // targets per tracked unit: the fp16 loop tracks pairs of blocks
+    constexpr int NT = CM_CELL / 4;                    // exact evaluations per lane
+    int K, hw;
     float Bv, V2;
     {
         const float ob = __shfl_xor(best, 32, 64), os = __shfl_xor(second, 32, 64);
         const int ok = __shfl_xor(blk, 32, 64);
-        Bv = fminf(best, ob);
-        K = (ob < best || (ob == best && ok < blk)) ? ok : blk;
-        V2 = fminf(K == blk ? second : best, K == ok ? os : ob);
+        // lexicographic (value, block, half): both lanes of the query reach the same verdict
+        const bool mine = best < ob || (best == ob && (blk < ok || (blk == ok && half == 0)));
+        Bv = mine ? best : ob;
+        K = mine ? blk : ok;
+        hw = mine ? half : half ^ 1;
+        V2 = mine ? fminf(second, ob) : fminf(os, best);
     }
-    // exact finish: the 32 targets of block K (16 per lane of the pair).  This lane's 16 targets are contiguous in
-    // the (padded) feature planes: 4 float4 per coordinate
-    float d2[16];
+    float d2[NT];
     float m2 = __builtin_inff();
 #ifdef VPN_CHAMFER_DEBUG
-    if (K < 0 || K + 32 > Ntp || (K & 31)) atomicAdd(&g_dbg[7], 1ull);    // the block index the gather below trusts
+    if (K < 0 || K + CM_CELL > Ntp || (K & (CM_CELL - 1))) atomicAdd(&g_dbg[7], 1ull);    // the cell index the gather below trusts
 #endif
-    // K is a multiple of 32 below Ntp by construction (tile base + block number inside the tile); the clamp costs one
-    // instruction per query and keeps the gather inside the padded planes whatever happened upstream
-    K = min(max(K, 0), Ntp - 32);
+    // K is a multiple of CM_CELL below Ntp by construction (tile base + unit number inside the tile; Ntp is a multiple
+    // of 64); the clamp costs one instruction per query and keeps the gather inside the padded planes whatever
+    // happened upstream
+    K = min(max(K, 0), Ntp - CM_CELL);
+    // this lane's targets: groups g = half * NT/4 + j (j < NT/4) of 4 consecutive targets at K + 8 g + 4 hw
+    const int base = K + half * (2 * NT) + 4 * hw;
     {
-        const int base = K + half * 16;
-        const float4* px4 = reinterpret_cast<const float4*>(Fb + base);
-        const float4* py4 = reinterpret_cast<const float4*>(Fb + (size_t)Ntp + base);
-        const float4* pz4 = reinterpret_cast<const float4*>(Fb + 2 * (size_t)Ntp + base);
-        float4 X[4], Y[4], Z[4];
+        float4 X[NT / 4], Y[NT / 4], Z[NT / 4];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) { X[v] = px4[v]; Y[v] = py4[v]; Z[v] = pz4[v]; }
+        for (int v = 0; v < NT / 4; ++v) {
+            X[v] = *reinterpret_cast<const float4*>(Fb + base + 8 * v);
+            Y[v] = *reinterpret_cast<const float4*>(Fb + (size_t)Ntp + base + 8 * v);
+            Z[v] = *reinterpret_cast<const float4*>(Fb + 2 * (size_t)Ntp + base + 8 * v);
+        }
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
+        for (int v = 0; v < NT / 4; ++v) {
             const float xs[4] = {X[v].x, X[v].y, X[v].z, X[v].w}, ys[4] = {Y[v].x, Y[v].y, Y[v].z, Y[v].w};
             const float zs[4] = {Z[v].x, Z[v].y, Z[v].z, Z[v].w};
 #pragma unroll
             for (int w = 0; w < 4; ++w) d2[v * 4 + w] = dist2_exact(ax, ay, az, xs[w], ys[w], zs[w]);
         }
-        // padding targets (coordinates 0) are masked only by the waves whose best block reaches into the padding:
-        // three instructions per target that the other waves (all of them when Nt is a multiple of 32) skip
-        if (__ballot(base + 16 > Nt)) {
+        // padding targets (coordinates 0) are masked only by the waves whose winner cell reaches into the padding:
+        // three instructions per target that the other waves (all of them when Nt is a multiple of 64) skip
+        if (__ballot(K + CM_CELL > Nt)) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) d2[e] += (base + e < Nt) ? 0.0f : __builtin_inff();
+            for (int e = 0; e < NT; ++e) d2[e] += (base + 8 * (e >> 2) + (e & 3) < Nt) ? 0.0f : __builtin_inff();
         }
 #pragma unroll
-        for (int e = 0; e < 16; ++e) m2 = fminf(m2, d2[e]);
+        for (int e = 0; e < NT; ++e) m2 = fminf(m2, d2[e]);
     }
     m2 = fminf(m2, __shfl_xor(m2, 32, 64));
     // t = d2 - |a|^2 within E; exact d2 within 4e-7 relative: a block whose filtered minimum lies outside `band`
@@ -1405,11 +1433,11 @@ __global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_kernel(const ScanJob
     // lowest index attaining the minimum; a different d2 can only share the sqrt if it lies within a few ulp
     // of it, which is rare: only then are the sqrt values compared
     const float lim = m2 * (1.0f + 1.0e-6f);
-    int li = 16;                                                    // position inside this lane's 16 targets (inline constants)
+    int li = NT;                                                    // position inside this lane's targets (inline constants)
 #pragma unroll
-    for (int e = 15; e >= 0; --e)
-        if (d2[e] == m2) li = e;
-    int idx = li < 16 ? K + half * 16 + li : 0x7fffffff;
+    for (int e = NT - 1; e >= 0; --e)
+        if (d2[e] == m2) li = e;                                    // target index grows with e: the lowest wins
+    int idx = li < NT ? base + 8 * (li >> 2) + (li & 3) : 0x7fffffff;
     // near tie: some d2 with m2 < d2 <= lim.  d2 >= 0, so the bit patterns order like the values: the smallest
     // (bits(d2) - bits(m2) - 1) as an unsigned number is below bits(lim) - bits(m2) exactly then (equal values wrap
     // to 0xffffffff; a NaN d2 has a larger pattern than any finite lim).  One subtraction per target and a min3 tree
@@ -1417,19 +1445,16 @@ __global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_kernel(const ScanJob
     bool near_tie;
     {
         const unsigned mb1 = __float_as_uint(m2) + 1u;
-        unsigned g[16];
+        unsigned gm = 0xffffffffu;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) g[e] = __float_as_uint(d2[e]) - mb1;
-        auto umin3 = [](unsigned a, unsigned b, unsigned c) { return min(min(a, b), c); };
-        const unsigned t0 = umin3(g[0], g[1], g[2]), t1 = umin3(g[3], g[4], g[5]), t2 = umin3(g[6], g[7], g[8]);
-        const unsigned t3 = umin3(g[9], g[10], g[11]), t4 = umin3(g[12], g[13], g[14]);
-        const unsigned gm = umin3(umin3(t0, t1, t2), umin3(t3, t4, g[15]), 0xffffffffu);
+        for (int e = 0; e < NT; e += 2)                              // the compiler forms v_min3_u32
+            gm = min(gm, min(__float_as_uint(d2[e]) - mb1, __float_as_uint(d2[e + 1]) - mb1));
         near_tie = m2 < __builtin_inff() && gm < __float_as_uint(lim) - __float_as_uint(m2);
     }
     if (__ballot(near_tie)) {
 #pragma unroll
-        for (int e = 15; e >= 0; --e)
-            if (d2[e] <= lim && sqrtf(d2[e]) == s) idx = min(idx, K + half * 16 + e);
+        for (int e = NT - 1; e >= 0; --e)
+            if (d2[e] <= lim && sqrtf(d2[e]) == s) idx = min(idx, base + 8 * (e >> 2) + (e & 3));
     }
     idx = min(idx, __shfl_xor(idx, 32, 64));
     if (half == 0 && qi < Nq) {
