@@ -227,7 +227,9 @@ int vpn_raster_total_bwd(const float* params, const float* cam, int B, int K, in
                          float* grad_params, int accumulate, void* stream);
 /* Backward of the whole training step in ONE launch: vpn_sample_chamfer_bwd and vpn_raster_total_bwd together
  * (both are one workgroup per (sample, primitive)):
- *   grad_params = d(Chamfer term)/d params [as vpn_sample_chamfer_bwd] + (*grad_total) * d(total_img)/d params. */
+ *   grad_params = d(Chamfer term)/d params [as vpn_sample_chamfer_bwd] + (*grad_total) * d(total_img)/d params.
+ * grad_loss_b may be NULL: then d total / d loss_b = *grad_total for every sample, and the caller folds the constant
+ * factors of the batch mean into the weights (w1 = cd_w1 * w_cd / B, w2 = cd_w2 * w_cd / B): no kernel in between. */
 int vpn_hotpath_bwd(const float* params, const int32_t* kinds, const float* u,
                     uint64_t seed, const uint64_t* seed_dev, uint64_t sample_base, int B, int K, int n,
                     const float* points, const float* gt_points, int M,

@@ -225,7 +225,7 @@ __global__ __launch_bounds__(SAMP_BLOCK) void sample_chamfer_bwd_kernel(
     const float* ub = u ? u + ((size_t)b * K + k) * n * 3 : nullptr;
     const float* A = points + (size_t)b * N * 3;
     const float* G2 = gt + (size_t)b * M * 3;
-    const float gl = grad_loss_b[b];
+    const float gl = grad_loss_b ? grad_loss_b[b] : rf.scale[0];       // NULL (hot path): the upstream gradient of the total itself
     const float ca = gl * w1 / (float)N, cb = gl * w2 / (float)M;       // means over N and M (chamfer_distance.py:25-28)
     float acc[12];
 #pragma unroll
@@ -713,8 +713,9 @@ static int launch_scb(const float* params, const int32_t* kinds, const float* u,
                       const float* gt_points, int M, const float* dist1, const int32_t* idx1,
                       const float* dist2, const int32_t* idx2, const float* grad_loss_b, float w1,
                       float w2, float* grad_params, const RasterFinish& rf, void* stream) {
-    if (!params || !kinds || !points || !gt_points || !dist1 || !idx1 || !dist2 || !idx2 || !grad_loss_b || !grad_params)
+    if (!params || !kinds || !points || !gt_points || !dist1 || !idx1 || !dist2 || !idx2 || !grad_params)
         return VPN_E_BADARG;
+    if (!grad_loss_b && !rf.scale) return VPN_E_BADARG;
     if (B <= 0 || K <= 0 || n <= 0 || M <= 0) return VPN_E_BADARG;
     if (B > 65535 || (long long)K * n > 0x7fffffffLL / 3) return VPN_E_TOOBIG;
     const size_t lds = (size_t)((M + SAMP_BLOCK - 1) / SAMP_BLOCK) * 64 * (SAMP_BLOCK / 64) * sizeof(int2);  // = 8 B per GT point

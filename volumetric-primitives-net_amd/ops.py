@@ -435,12 +435,15 @@ class RasterTotalFunction(Function):
         ctx.meta = (B, K, H, W)
         sil, dep, tot, _ = losses.unbind(0)
         ctx.mark_non_differentiable(sil, dep)
+        ctx.set_materialize_grads(False)       # no zero-filled gradients for the two reported values
         return sil, dep, tot
 
     @staticmethod
     def backward(ctx, _g_sil, _g_dep, grad_total):
         params, cam, rec, ws = ctx.saved_tensors
         B, K, H, W = ctx.meta
+        if grad_total is None:
+            return (None,) * 13
         g = _f32c(grad_total).reshape(1)
         grad_params = torch.empty_like(params)
         _lib.call('vpn_raster_total_bwd', _lib.ptr(params), _lib.ptr(cam), B, K, H, W, _lib.ptr(rec), _lib.ptr(ws),
@@ -546,29 +549,34 @@ class HotPathLossFunction(Function):
         empty = torch.empty(0, device=dev)
         seed_t = seed if isinstance(seed, torch.Tensor) else empty
         ctx.save_for_backward(params, kinds, cam, gt_points, points, d1, i1, d2, i2, rec, rws, pattern, seed_t)
-        ctx.meta = (B, K, n, M, H, W, seed_host, seed_dev is not None, int(sample_base), cd_w1, cd_w2)
+        ctx.meta = (B, K, n, M, H, W, seed_host, seed_dev is not None, int(sample_base), cd_w1, cd_w2, float(w_cd) / B)
         sil, dep, tot, _ = losses.unbind(0)
         ctx.mark_non_differentiable(sil, dep)
+        ctx.set_materialize_grads(False)       # no zero-filled gradients for the two reported (non-differentiable) values
         return sil, dep, tot
 
     @staticmethod
     def backward(ctx, _g_sil, _g_dep, grad_total):
         (params, kinds, cam, gt_points, points, d1, i1, d2, i2, rec, rws, pattern, seed_t) = ctx.saved_tensors
-        B, K, n, M, H, W, seed, has_seed_dev, base, cd_w1, cd_w2 = ctx.meta
+        B, K, n, M, H, W, seed, has_seed_dev, base, cd_w1, cd_w2, w_cd_over_b = ctx.meta
         N = K * n
         s = _lib.stream()
         seed_dev = _lib.ptr(seed_t) if has_seed_dev else None
+        if grad_total is None:                                  # the total was not used (set_materialize_grads(False))
+            return (None,) * 20
         grad_total = _f32c(grad_total).reshape(1)
-        gvec = pattern * grad_total                             # one small kernel: d total / d loss_b [B]
         # Chamfer backward and sampler backward in one launch: the [B,N,3] point gradient never exists
         grad_params = torch.empty_like(params)
         if M <= FUSED_BWD_MAX_GT:          # ... and the raster's finishing step rides in the same launch
+            # d total / d loss_b = (w_cd / B) * grad_total for every sample: the constant goes into the two Chamfer
+            # weights and the kernel reads grad_total itself (no ATen kernel between autograd and the launch)
             _lib.call('vpn_hotpath_bwd', _lib.ptr(params), _lib.ptr(kinds), None, seed, seed_dev, base, B, K, n,
                       _lib.ptr(points), _lib.ptr(gt_points), M, _lib.ptr(d1), _lib.ptr(i1), _lib.ptr(d2), _lib.ptr(i2),
-                      _lib.ptr(gvec), cd_w1, cd_w2, _lib.ptr(cam), H, W, _lib.ptr(rec), _lib.ptr(rws),
+                      None, cd_w1 * w_cd_over_b, cd_w2 * w_cd_over_b, _lib.ptr(cam), H, W, _lib.ptr(rec), _lib.ptr(rws),
                       _lib.ptr(grad_total), _lib.ptr(grad_params), s)
             return (grad_params,) + (None,) * 19
         else:                                                   # GT clouds beyond the fused kernel's LDS match lists
+            gvec = pattern * grad_total                         # d total / d loss_b [B]
             grad_points = torch.empty_like(points)
             _lib.call('vpn_chamfer_bwd', _lib.ptr(points), _lib.ptr(gt_points), _lib.ptr(d1), _lib.ptr(i1), _lib.ptr(d2),
                       _lib.ptr(i2), _lib.ptr(gvec), B, N, M, cd_w1, cd_w2, _lib.ptr(grad_points), None, s)
