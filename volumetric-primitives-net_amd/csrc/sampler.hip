@@ -302,10 +302,12 @@ __global__ __launch_bounds__(SAMP_BLOCK) void sample_chamfer_bwd_kernel(
         const F3 a = ld3(A + i * 3), g = ld3(G2 + e * 3);
         add(i - k * n, coef * (a.x - g.x), coef * (a.y - g.y), coef * (a.z - g.z));
     }
+    {   // 12 sums per wave with ONE transposing butterfly (17 cross-lane moves) instead of 12 x 6
+        float v16[16];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
-        float s = wave_sum(acc[i]);
-        if (lane == 0) red[wave][i] = s;
+        for (int i = 0; i < 16; ++i) v16[i] = i < 12 ? acc[i] : 0.0f;
+        const float tot = wave_reduce16(v16);                           // lane L: wave total of value L >> 2
+        if ((lane & 3) == 0 && lane < 48) red[wave][lane >> 2] = tot;
     }
     __syncthreads();
     if (rf.partial && threadIdx.x == 64) {                              // raster chain rule, beside thread 0's below
