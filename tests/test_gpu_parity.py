@@ -319,6 +319,34 @@ def test_chamfer_fp16_filter_domain(vpn):
     _chamfer_exact(vpn, p1, p2, torch_sqrt_too=False)
 
 
+def test_chamfer_filter_adversarial_near_ties(vpn):
+    """Stress of the filters' error bands: every query has a ring of targets whose distances differ from each other by
+    a few ulp of d2 (relative 1e-7 .. 1e-5, below and around what a 16-bit-piece filter can resolve), placed in
+    DIFFERENT 32-target blocks, at several offsets from the origin (the filter computes |b|^2 - 2 a.b: cancellation
+    grows with the norms) and at several scales.  Whatever the filter decides or hands to the fix-up, the result must be
+    the brute-force bits; a band that is too narrow shows up here as a wrong index."""
+    gen = torch.Generator().manual_seed(20250)
+    B, Nq, per = 2, 320, 6
+    for scale, shift in ((1.0, 0.0), (1.0, 2.5), (0.25, 0.4), (3.0, 1.0), (0.02, 0.0)):
+        q = (torch.rand(B, Nq, 3, generator=gen) - 0.5) * scale + shift
+        dirs = torch.randn(B, Nq, per, 3, generator=gen)
+        dirs = dirs / dirs.norm(dim=-1, keepdim=True)
+        r0 = (0.02 + 0.2 * torch.rand(B, Nq, 1, generator=gen)) * scale
+        eps = torch.tensor([0.0, 1.2e-7, 3.0e-7, 1.0e-6, 3.0e-6, 1.0e-5])[:per]
+        t = q[:, :, None, :] + dirs * (r0[..., None] * (1.0 + eps)[None, None, :, None])
+        # ring member j of every query goes to slab j of the target cloud: the near-tied targets of a query sit in
+        # different blocks (and tiles); a random permutation inside each slab decorrelates block and query number
+        t = t.permute(0, 2, 1, 3).contiguous()                    # [B, per, Nq, 3]
+        for j in range(per):
+            t[:, j] = t[:, j, torch.randperm(Nq, generator=gen)]
+        t = t.reshape(B, per * Nq, 3)
+        for p1, p2 in ((q, t), (t, q)):
+            ref = vpn.chamfer_nn(g(p1), g(p2), mode='brute')
+            for mode in ('mfma16', 'mfma', 'mfma32', 'sorted'):
+                got = vpn.chamfer_nn(g(p1), g(p2), mode=mode)
+                assert all(torch.equal(x, y) for x, y in zip(got, ref)), (scale, shift, mode)
+
+
 def test_chamfer_lattice_ties(vpn):
     """Points on a coarse lattice: masses of exactly equal distances -> lowest index must win."""
     gen = torch.Generator().manual_seed(5)

@@ -76,10 +76,18 @@ __device__ inline bool emd_group_sync(unsigned* counter, unsigned& passed, int G
     __asm__ volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
     passed += G;
+    // -DEMD_STRICT_ORDER: release / acquire on the counter, i.e. the form the HIP memory model asks for (the compiler
+    // adds an L2 write-back before the add and an invalidate after the load: ~70 us per barrier, G > 1 then loses to
+    // G = 1).  The default relies on the hardware argument above: all shared state is sc1-accessed and acknowledged.
+#ifdef EMD_STRICT_ORDER
+    constexpr int EMD_ADD_ORDER = __ATOMIC_RELEASE, EMD_POLL_ORDER = __ATOMIC_ACQUIRE;
+#else
+    constexpr int EMD_ADD_ORDER = __ATOMIC_RELAXED, EMD_POLL_ORDER = __ATOMIC_RELAXED;
+#endif
     if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(counter, 1u, EMD_ADD_ORDER, __HIP_MEMORY_SCOPE_AGENT);
         unsigned spins = 0;
-        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < passed) {
+        while (__hip_atomic_load(counter, EMD_POLL_ORDER, __HIP_MEMORY_SCOPE_AGENT) < passed) {
             __builtin_amdgcn_s_sleep(1);
             // the give-up flag of the group is polled every 256th spin only: a second L2 round trip per spin would
             // lengthen every barrier of every round
