@@ -458,7 +458,10 @@ def main():
             nbytes = (Bg * K * 10 + 1) * 4 if args.collective == 'allreduce' else (B * K * 10 + 4) * 4
             coll = '%s %s, %d B per rank per step' % ('REHEARSAL over gloo, all ranks on one GPU:' if args.rehearse else 'rccl', 'all-reduce (sum) of the global gradient buffer'
                                                        if args.collective == 'allreduce' else 'all-gather', nbytes)
-        name = 'C3' if not args.global_batch else ('C4' if (Bg, K, H) == (256, 32, 256) else 'C3-shape')
+        if args.global_batch:
+            name = 'C4' if (Bg, K, n, M, H) == (256, 32, 256, 2048, 256) else 'custom strong-scaling shape'
+        else:
+            name = 'C3' if is_c3 else 'custom shape'
         out = {
             'metric': 'render+Chamfer fwd+bwd images/sec', 'value': round(value, 1), 'unit': 'images/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
