@@ -31,7 +31,9 @@ out = {}
 for wl in ('c3', 'c2'):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for d in sorted(glob.glob(os.path.join(src, '%s_%s_pmc*' % (tag, wl)))):
-        for f in glob.glob(d + '/*/*counter_collection.csv'):
+        # gpurun merges every call's output into gpurun_out/: a pass directory may hold files of earlier runs of
+        # the same tag; only the newest one describes the current kernels
+        for f in sorted(glob.glob(d + '/*/*counter_collection.csv'), key=os.path.getmtime)[-1:]:
             for r in csv.DictReader(open(f)):
                 acc[short(r['Kernel_Name'])][r['Counter_Name']].append(float(r['Counter_Value']))
     if not acc:
@@ -50,7 +52,7 @@ for wl in ('c3', 'c2'):
             lines.append('   %-28s n=%-4d mean=%.4g' % (cn, len(v), sum(v) / len(v)))
     out[wl] = ker
     open(os.path.join(ROOT, 'profiles', '%s_%s_pmc.txt' % (tag, wl)), 'w').write('\n'.join(lines) + '\n')
-    st = glob.glob(os.path.join(src, '%s_%s_stats' % (tag, wl), '*', '*kernel_stats.csv'))
+    st = sorted(glob.glob(os.path.join(src, '%s_%s_stats' % (tag, wl), '*', '*kernel_stats.csv')), key=os.path.getmtime)[::-1]
     if st:
         shutil.copy(st[0], os.path.join(ROOT, 'profiles', '%s_%s_kernel_stats.csv' % (tag, wl)))
         with open(os.path.join(ROOT, 'profiles', '%s_%s_kernel_stats.txt' % (tag, wl)), 'w') as fh:
