@@ -443,14 +443,22 @@ def main():
                                  'hbm_GBps': round(gbs, 2), 'hbm_frac': round(gbs / HBM_PEAK_GBS, 5),
                                  'traffic': traffic_of(name, pmc), 'executed_work': valu_issue_roofline(name, pmc, us)}
 
+    # The legs below are reported NEXT to the headline: a failure in one of them (host out of memory in the CPU leg, ...)
+    # must not cost the line itself, so it is reported as {"error": ...} in its place
+    def guarded(fn, *a):
+        try:
+            return fn(*a)
+        except Exception as e:        # noqa: BLE001 -- reported, not swallowed
+            return {'error': '%s: %s' % (type(e).__name__, e)}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(params_all[:args.cpu_sample].detach().cpu(), gt_all[:args.cpu_sample].cpu(),
-                           p2_all[:args.cpu_sample].detach().cpu(), K, n, H, W, sigma, gamma, z_far, kinds, cam, vpn_amd)
+        cpu = guarded(cpu_baseline, params_all[:args.cpu_sample].detach().cpu(), gt_all[:args.cpu_sample].cpu(),
+                      p2_all[:args.cpu_sample].detach().cpu(), K, n, H, W, sigma, gamma, z_far, kinds, cam, vpn_amd)
 
     c2 = None
     if rank == 0 and world == 1 and not args.no_c2:
-        c2 = raster_only(vpn_amd, _lib, dev, 32, 16, 128, args.steps, args.warmup, args.windows, 'c2')
+        c2 = guarded(raster_only, vpn_amd, _lib, dev, 32, 16, 128, args.steps, args.warmup, args.windows, 'c2')
 
     if rank == 0:
         coll = 'none'
@@ -479,7 +487,7 @@ def main():
         if c2 is not None:
             out['c2'] = c2
         if world == 1 and not args.no_extras:      # row f1, outside the metric: the auction EMD loss of the same step
-            out['emd'] = emd_extra(B, M, dev, vpn_amd, cpu is not None)
+            out['emd'] = guarded(emd_extra, B, M, dev, vpn_amd, cpu is not None and 'error' not in cpu)
         print(json.dumps(out), flush=True)
     if multi:
         dist.destroy_process_group()
