@@ -443,6 +443,20 @@ def main():
                                  'hbm_GBps': round(gbs, 2), 'hbm_frac': round(gbs / HBM_PEAK_GBS, 5),
                                  'traffic': traffic_of(name, pmc), 'executed_work': valu_issue_roofline(name, pmc, us)}
 
+    # whole step against the HBM roofline (north_star asks for it): PMC-measured bytes of every kernel of the step / step time
+    step_hbm = None
+    if pmc:
+        per = {k: traffic_of(k, pmc) for k in kern}
+        if all(v is not None for v in per.values()):
+            tot = sum(v * round(kern[k][0] / ksteps) for k, v in per.items())
+            gbs = tot / (ev['median'] * 1e-3) / 1e9
+            alg = sum(alg_bytes.get(k, 0) * round(kern[k][0] / ksteps) for k in kern)
+            step_hbm = {'traffic_bytes_per_step': int(tot), 'achieved_GBps': round(gbs, 1), 'peak_GBps': HBM_PEAK_GBS,
+                        'frac': round(gbs / HBM_PEAK_GBS, 4), 'algorithmic_bytes_per_step': int(alg),
+                        'note': 'sum over the kernels of one step of FETCH_SIZE (x2 for the 16-B-per-lane streams) + '
+                                'WRITE_SIZE from profiles/r02_pmc.json, over the hipEvent median step time: the step is '
+                                'issue-bound (VALU / matrix pipe), not HBM-bound'}
+
     # The legs below are reported NEXT to the headline: a failure in one of them (host out of memory in the CPU leg, ...)
     # must not cost the line itself, so it is reported as {"error": ...} in its place
     def guarded(fn, *a):
@@ -482,6 +496,8 @@ def main():
             'hip_event_ms_per_step': {k: (round(v, 5) if isinstance(v, float) else v) for k, v in ev.items()},
             'roofline': roofline, 'raster_roofline': raster_roof, 'kernel_us': kernel_us, 'entry_us': entry_us,
         }
+        if step_hbm is not None:
+            out['step_hbm'] = step_hbm
         if cpu is not None:
             out['cpu_baseline'] = cpu
         if c2 is not None:

@@ -42,7 +42,7 @@ for wl in ('c3', 'c2'):
     lines = ['# rocprofv3 --kernel-trace --pmc <counters> -- python3 bench.py --steps 10 --warmup 3 --no-extras --no-graph '
              '--workload %s  (separate passes, tools/profile_all.sh; mean per dispatch)' % wl]
     for k, c in sorted(acc.items()):
-        if not (k.startswith(('chamfer', 'raster', 'sample')) or 'total_loss' in k):
+        if not k.startswith(('chamfer', 'raster', 'sample', 'loss_')):
             continue
         ker[k] = {cn: sum(v) / len(v) for cn, v in c.items()}
         ker[k]['dispatches'] = max(len(v) for v in c.values())
