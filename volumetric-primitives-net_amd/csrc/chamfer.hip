@@ -1253,17 +1253,11 @@ __global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_kernel(const ScanJob
         struct Ops { float4 lo; float2 hi; };
         auto rd = [&](const unsigned char* T, int blkk) -> Ops {
             const unsigned char* p = T + blkk * 32 * CM_ROWB;
-#ifdef CM_ABL_NO_HI      // ablation (wrong results): what the 8-byte operand read costs
-            return Ops{*reinterpret_cast<const float4*>(p), make_float2(0.f, 0.f)};
-#else
             return Ops{*reinterpret_cast<const float4*>(p), *reinterpret_cast<const float2*>(p + 32 - 8 * half)};
-#endif
         };
         auto block = [&](const Ops& o) {
             f16v acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, o.lo), bqA, zero, 0, 0, 0);
-#ifndef CM_ABL_NO_X8     // ablation (wrong results): what the second MFMA of a block costs
             acc = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(bs4, o.hi), bqB, acc, 0, 0, 0);
-#endif
             return acc;
         };
         static_assert(CM_TILE16 == 256, "the tile loop below is unrolled for 8 blocks per tile");
