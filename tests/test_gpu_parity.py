@@ -697,6 +697,45 @@ def test_hot_path_odd_shapes_with_filtered_chamfer(vpn, shape):
     assert rel_err(pg.grad.cpu(), pc.grad) <= RTOL
 
 
+def test_hot_path_random_shapes_equal_module_composition(vpn):
+    """20 random shapes (odd batch sizes, 1..70 primitives of mixed kinds, ragged point / pixel counts, cameras off axis):
+    the one-node hot path (sampler writing the raster records, one-pass raster, fused backward with the raster finish
+    inside) must agree with the same loss assembled from the separate modules (stand-alone record kernel, two-call
+    raster, Chamfer module with its own backward) -- two independent launch paths over the same kernels' arithmetic."""
+    gen = torch.Generator().manual_seed(777)
+    dev = torch.device(DEV)
+    for case in range(20):
+        B = int(torch.randint(1, 6, (1,), generator=gen))
+        K = int(torch.randint(1, 71, (1,), generator=gen)) if case % 5 == 0 else int(torch.randint(1, 12, (1,), generator=gen))
+        n = int(torch.randint(1, 90, (1,), generator=gen))
+        M = int(torch.randint(1, 700, (1,), generator=gen))
+        H = int(torch.randint(1, 70, (1,), generator=gen))
+        W = int(torch.randint(1, 70, (1,), generator=gen))
+        params = rand_params(gen, B, K)
+        kinds = sorted((int(x) for x in torch.randint(0, 2, (K,), generator=gen)), reverse=True)
+        kt = vpn.kinds_tensor(kinds, dev)
+        gt_pts = g(torch.rand(B, M, 3, generator=gen) - 0.5)
+        gt_sil = g((torch.rand(B, 1, H, W, generator=gen) > 0.5).float())
+        gt_dep = g(2.0 - torch.rand(B, H, W, generator=gen))
+        cam = g(torch.cat([0.9 + 0.4 * torch.rand(B, 1, generator=gen), 40.0 * torch.rand(B, 1, generator=gen) - 20.0,
+                           360.0 * torch.rand(B, 1, generator=gen)], 1))
+        w = [float(x) for x in 0.2 + torch.rand(3, generator=gen)]
+        mse = bool(case & 1)
+        pg = g(params).requires_grad_(True)
+        out = vpn.HotPathLossFunction.apply(pg, kt, cam, gt_pts, gt_sil, gt_dep, n, 900 + case, 3, H, W, 0.05, 0.1, 2.0,
+                                            w[0], w[1], w[2], 0.5, 2.0, mse)
+        out[2].backward()
+        pm = g(params).requires_grad_(True)
+        pts = vpn.Sampling.sample_primitives(pm, kt, n, seed=900 + case, sample_base=3)
+        img = vpn.RasterLossFunction.apply(pm, kt, cam, gt_sil, gt_dep, H, W, 0.05, 0.1, 2.0, mse)
+        tot = w[0] * vpn.ChamferDistanceLoss()(pts, gt_pts, w1=0.5, w2=2.0) + w[1] * img[0] + w[2] * img[1]
+        tot.backward()
+        shape = (case, B, K, n, M, H, W)
+        assert rel_err(out[2].detach().cpu(), tot.detach().cpu()) <= 1e-5, shape
+        assert rel_err(out[0].detach().cpu(), img[0].detach().cpu()) <= 1e-5, shape
+        assert rel_err(pg.grad.cpu(), pm.grad.cpu()) <= 2e-5, shape
+
+
 def test_hot_path_large_gt_cloud_falls_back(vpn):
     """GT clouds beyond the fused backward's LDS match lists (M > 7680) take the two-kernel backward: same result
     as the module composition."""
