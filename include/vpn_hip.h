@@ -126,6 +126,8 @@ int vpn_chamfer_nn(const float* queries, const float* targets, int B, int Nq, in
  *   mode 6  the filter with ONE fp16 MFMA per 32x32 block: coordinates scaled by 2^11 and split into two fp16
  *           pieces (32-byte rows); queries or clouds with |p|^2 > 64 are outside its domain and are finished by
  *           the exact rescan (results unchanged, only slower);
+ *   mode 7  mode 6 with the features of both clouds already in the workspace (written by vpn_hotpath_sample_fwd
+ *           for p1 = its points and p2 = its gt_points, earlier on the same stream);
  *   mode 0  automatic (mode 6 for large clouds when a workspace is given, else mode 1). */
 size_t vpn_chamfer_workspace(int B, int N, int M);
 /* workspace_bytes: size of `workspace`; VPN_E_BADARG if a mode that uses it is given fewer than
@@ -214,11 +216,18 @@ int vpn_raster_total_fwd(const float* params, const int32_t* kinds, const float*
                          const float* gt_sil, const float* gt_depth, int sil_mse, float w_sil, float w_dep,
                          void* records, void* loss_ws, void* workspace, int records_ready, void* stream);
 /* vpn_sample_fwd of the training step: the same launch also writes the raster records of the primitives it samples
- * (one workgroup per (sample, primitive) in both) and zeroes the arrival counter of loss_ws. */
+ * (one workgroup per (sample, primitive) in both) and zeroes the arrival counter of loss_ws.
+ * chamfer_ws != NULL (allowed when vpn_hotpath_fused_features(B, K, n, M) is 1): the launch also writes, into that
+ * Chamfer workspace (vpn_chamfer_workspace(B, K*n, M) bytes), the matrix-pipe filter's features of the cloud it
+ * samples and of gt_points [B,M,3]; the caller then runs vpn_chamfer_fwd_ws(points, gt_points, ..., mode 7) on the same
+ * workspace and stream, which skips its feature kernel (the points would be written and immediately re-read).
+ * chamfer_ws == NULL: gt_points / M / chamfer_ws_bytes are ignored. */
 int vpn_hotpath_sample_fwd(const float* params, const int32_t* kinds, const float* u,
                            uint64_t seed, const uint64_t* seed_dev, uint64_t sample_base, int B, int K, int n,
                            float* points, const float* cam, int H, int W, float sigma, void* records, void* loss_ws,
+                           const float* gt_points, int M, void* chamfer_ws, size_t chamfer_ws_bytes,
                            void* stream);
+int vpn_hotpath_fused_features(int B, int K, int n, int M);
 int vpn_loss_finalize(void* loss_ws, int B, int H, int W, const float* dist1, const float* dist2, int N, int M,
                       float cd_w1, float cd_w2, float w_cd, float w_sil, float w_dep, float* losses, float* loss_b,
                       void* stream);

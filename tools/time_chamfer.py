@@ -30,7 +30,7 @@ torch.cuda.synchronize()
 pad = lambda n: (n + 63) & ~63
 p4 = lambda n: (n + 3) & ~3
 wi = ws.view(torch.int32)
-SLOTS = 32
+SLOTS = 64
 off1 = B * 16 * pad(M) + 3072 + B * SLOTS                # direction 1: targets p2 (M), queries p1 (N)
 size1 = off1 + p4(B) + 4 * B * N + B * pad(M) + B * (pad(M) // 32) * 8   # + permutation + block boxes
 off2 = size1 + B * 16 * pad(N) + 3072 + B * SLOTS

@@ -17,6 +17,7 @@
 //   last update (= min over all targets of earlier groups); if its sqrt equals the final
 //   minimum the wave re-scans the earlier targets with the sqrt compare.
 #include "vpn_common.h"
+#include "vpn_chamfer_feat.h"
 #include <stdlib.h>
 #include <string.h>
 
@@ -645,24 +646,11 @@ constexpr float CM_EPS = 8.0f * 5.9604644775390625e-08f;   // 8 * 2^-24: bound o
 // (<= 4.2 * 2^-24 |a||b|), rounding of |b|^2 (3 * 2^-24): 32 * 2^-24 covers all of it
 constexpr float CM_EPS_BF16 = 32.0f * 5.9604644775390625e-08f;
 constexpr int CM_TILE16 = 256;           // targets per LDS tile of bf16 rows
-constexpr int CM_ROWB = 48;              // bytes per bf16 row: K slots 0..15 for v_mfma_f32_32x32x16_bf16, 16..23 for v_mfma_f32_32x32x8_bf16
-                                         // (21 used).  Also the LDS stride: 16 consecutive rows x 16 B hit 64 distinct banks (12 r mod 64)
 constexpr int CM_ROWW = CM_ROWB / 4;     // the same in 4-byte words
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 typedef unsigned short us8 __attribute__((ext_vector_type(8)));
 typedef unsigned short us4 __attribute__((ext_vector_type(4)));
 typedef short bs4 __attribute__((ext_vector_type(4)));      // operand type of v_mfma_f32_32x32x8_bf16
-
-// exact 3-way split of an fp32 into bf16 pieces (truncation): x == p0 + p1 + p2
-__device__ inline void split3_bf16(float x, unsigned short p[3]) {
-    const unsigned u0 = __float_as_uint(x);
-    p[0] = (unsigned short)(u0 >> 16);
-    const float r1 = x - __uint_as_float(u0 & 0xFFFF0000u);
-    const unsigned u1 = __float_as_uint(r1);
-    p[1] = (unsigned short)(u1 >> 16);
-    const float r2 = r1 - __uint_as_float(u1 & 0xFFFF0000u);
-    p[2] = (unsigned short)(__float_as_uint(r2) >> 16);
-}
 
 // ---- fp16 variant of the filter (PREC == 2): fp16 has 11 significant bits against bf16's 8, so TWO pieces per
 // coordinate carry 22 bits and the three leading cross terms b1a1, b1a2, b2a1 per coordinate (9) plus three pieces of
@@ -673,7 +661,6 @@ __device__ inline void split3_bf16(float x, unsigned short p[3]) {
 // fp16 pieces times fp16-representable powers of two; a cloud or query outside that range (|p|^2 > 64, or not finite)
 // makes the query UNDECIDED, i.e. it is resolved exactly by the fix-up kernel: correct for any input, fast for
 // normalised shapes.  Error bound CM_EPS_F16 in near_error / the epilogue; DESIGN.md 4.1 has the derivation.
-constexpr float CM_S16 = 2048.0f;                            // coordinate scale of the fp16 rows (2^11)
 constexpr float CM_INV_S16SQ = 1.0f / (2048.0f * 2048.0f);   // 2^-22: filter values come out scaled by S^2
 constexpr float CM_DOMAIN16 = 64.0f;                         // |p|^2 bound of the fp16 filter (|coordinate| <= 8)
 // dropped terms b2a2 + rb a + b ra: <= 3 * 2^-22 |A||B| = 24 * 2^-24 |a||b|; accumulation of 12 exact products in fp32:
@@ -681,128 +668,19 @@ constexpr float CM_DOMAIN16 = 64.0f;                         // |p|^2 bound of t
 // 26 covers both.  The pieces' absolute floor (fp16 subnormal spacing; the matrix pipe keeps subnormal inputs --
 // tools/ubench/mfma_f16_denorm.hip -- but the bound below also covers a flush) adds 2^-24 (|a|_1 + |b|_1).
 constexpr float CM_EPS_F16 = 26.0f * 5.9604644775390625e-08f;
-constexpr int CM_ROWB16 = 32;            // bytes per fp16 row in HBM (16 K slots); LDS stride stays 48 B (bank-conflict free)
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
-// X = h[0] + h[1] + r with |r| <= 2^-22 |X| + 2^-25 (fp16 pieces, round to nearest)
-__device__ inline void split2_f16(float X, _Float16 h[2]) {
-    h[0] = (_Float16)X;
-    h[1] = (_Float16)(X - (float)h[0]);
-}
-
-// one 32-byte row: K slots  x (b1 b1 b2), y (...), z (...), S^2 |p|^2 as p1 2^15 + p2 2^4 + p3, 4 zeros
-__device__ inline void write_row16(unsigned short* H, size_t row, float x, float y, float z, float n) {
-    _Float16 hx[2], hy[2], hz[2], pn[3];
-    split2_f16(CM_S16 * x, hx); split2_f16(CM_S16 * y, hy); split2_f16(CM_S16 * z, hz);
-    if (n < 1.0e30f) {
-        const float ns = (CM_S16 * CM_S16) * n;
-        pn[0] = (_Float16)(ns * 3.0517578125e-05f);                     // 2^-15
-        const float r1 = ns - (float)pn[0] * 32768.0f;
-        pn[1] = (_Float16)(r1 * 0.0625f);                               // 2^-4
-        pn[2] = (_Float16)(r1 - (float)pn[1] * 16.0f);
-    } else {                                                            // padding sentinel: 65504 * 2^15 / S^2 = 512 > any t in range
-        pn[0] = (_Float16)65504.0f; pn[1] = (_Float16)0.0f; pn[2] = (_Float16)0.0f;
-    }
-    auto bits = [](_Float16 v) { return (unsigned)__builtin_bit_cast(unsigned short, v); };
-    auto pk = [&](_Float16 lo, _Float16 hi) { return bits(lo) | (bits(hi) << 16); };
-    const _Float16 zero = (_Float16)0.0f;
-    uint4* dst = reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(H) + row * CM_ROWB16);
-    dst[0] = make_uint4(pk(hx[0], hx[0]), pk(hx[1], hy[0]), pk(hy[0], hy[1]), pk(hz[0], hz[0]));
-    dst[1] = make_uint4(pk(hz[1], pn[0]), pk(pn[1], pn[2]), pk(zero, zero), pk(zero, zero));
-}
-
-// feature planes F[b][4][Np] = (x, y, z, |p|^2) (padded with a never-winning sentinel) and
-// H[b][Np][24] bf16 rows (48 B) for the bf16 filter: per coordinate the target pieces (b1 b1 b2 b1 b3 b2) that pair
-// with the query pieces (a1 a2 a1 a3 a1 a2), then the three pieces of |p|^2 (paired with 1.0), then zeros.
-// nmax[b][CFEAT_SLOTS]: max |p|^2 of each workgroup's slice (the filter takes the max of the slots: no atomics,
-// no zero-initialised output, no workgroup that scans the whole cloud).
-// one 48-byte row of bf16 pieces: K slots  x (b1 b1 b2 b1 b3 b2), y (...), z (...), |p|^2 (3 pieces), 3 zeros
-__device__ inline void write_row(unsigned short* H, size_t row, float x, float y, float z, float n) {
-    unsigned short px[3], py[3], pz[3], pn[3];
-    split3_bf16(x, px); split3_bf16(y, py); split3_bf16(z, pz); split3_bf16(n, pn);
-    auto pk = [](unsigned short lo, unsigned short hi) { return (unsigned)lo | ((unsigned)hi << 16); };
-    uint4* dst = reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(H) + row * CM_ROWB);
-    dst[0] = make_uint4(pk(px[0], px[0]), pk(px[1], px[0]), pk(px[2], px[1]), pk(py[0], py[0]));
-    dst[1] = make_uint4(pk(py[1], py[0]), pk(py[2], py[1]), pk(pz[0], pz[0]), pk(pz[1], pz[0]));
-    dst[2] = make_uint4(pk(pz[2], pz[1]), pk(pn[0], pn[1]), pk(pn[2], 0), 0u);
-}
-
-constexpr int CFEAT_THREADS = 256;
-#ifndef CFEAT_SLOTS_N
-#define CFEAT_SLOTS_N 32
-#endif
-#ifndef CFEAT_WGPTS
-#define CFEAT_WGPTS 256             // points per feature workgroup (1024: r1; 256: 4x the workgroups, the kernel is latency-bound)
-#endif
-constexpr int CFEAT_SLOTS = CFEAT_SLOTS_N;         // workgroups per cloud and sample, at most
-constexpr int CFEAT_PTS = 4;                       // points per lane in flight
-
-struct FeatJob {          // one cloud: slices [0, ysplit) of a sample's workgroups belong to it
-    const float* pts; int N, Np, ysplit;
-    float* F; unsigned int* nmax; unsigned short* H; int* undecided;
-    int rows16;           // rows as 32-byte fp16 pieces (PREC 2) instead of 48-byte bf16 pieces (PREC 1)
-};
+// feature planes / rows of a cloud and the kernel body that writes them: vpn_chamfer_feat.h (shared with sampler.hip,
+// whose forward launch of the training step writes the features of the cloud it has just sampled)
 
 // One launch converts both clouds of a Chamfer call.  1-D grid of B * (j0.ysplit + j1.ysplit) workgroups, decoded
 // such that sample b runs on XCD b / (B/8) — where the filter kernel will read what is written here (its own remap).
 __global__ __launch_bounds__(CFEAT_THREADS) void chamfer_feat_kernel(const FeatJob j0, const FeatJob j1, int B) {
     __shared__ float red[CFEAT_THREADS / 64];
     int b, sy;
-    {
-        const int id = blockIdx.x, per = B >> 3, ys = j0.ysplit + j1.ysplit;
-        if ((B & 7) == 0) { const int xcd = id & 7, r = id >> 3; b = xcd * per + r % per; sy = r / per; }
-        else { b = id % B; sy = id / B; }
-        (void)ys;
-    }
+    feat_decode(blockIdx.x, B, b, sy);
     const bool other = sy >= j0.ysplit;
-    const float* __restrict__ pts = other ? j1.pts : j0.pts;
-    const int N = other ? j1.N : j0.N, Np = other ? j1.Np : j0.Np, ysplit = other ? j1.ysplit : j0.ysplit;
-    float* __restrict__ F = other ? j1.F : j0.F;
-    unsigned int* __restrict__ nmax = other ? j1.nmax : j0.nmax;
-    unsigned short* __restrict__ H = other ? j1.H : j0.H;
-    int* __restrict__ undecided = other ? j1.undecided : j0.undecided;
-    const bool rows16 = (other ? j1.rows16 : j0.rows16) != 0;
-    const int by = sy - (other ? j0.ysplit : 0);
-    if (by == 0 && threadIdx.x == 0) undecided[b] = 0;     // this sample's list: the scan that follows appends to it
-    if (by == 0 && (int)threadIdx.x >= ysplit && threadIdx.x < CFEAT_SLOTS) nmax[b * CFEAT_SLOTS + threadIdx.x] = 0u;
-    const float* pb = pts + (size_t)b * N * 3;
-    float* f = F + (size_t)b * 4 * Np;
-    float nv = 0.f;
-    const int per = ((Np + ysplit - 1) / ysplit + 63) & ~63;
-    const int jlo = by * per, jhi = min(Np, jlo + per);
-    for (int j0p = jlo + threadIdx.x; j0p < jhi; j0p += CFEAT_PTS * CFEAT_THREADS) {
-        float xs[CFEAT_PTS], ys[CFEAT_PTS], zs[CFEAT_PTS];
-#pragma unroll
-        for (int u = 0; u < CFEAT_PTS; ++u) {
-            const int j = min(j0p + u * CFEAT_THREADS, N - 1);
-            const F3 v3 = ld3(pb + j * 3);
-            xs[u] = v3.x; ys[u] = v3.y; zs[u] = v3.z;
-        }
-#pragma unroll
-        for (int u = 0; u < CFEAT_PTS; ++u) {
-            const int j = j0p + u * CFEAT_THREADS;
-            if (j >= jhi) break;
-            float x = 0.f, y = 0.f, z = 0.f, n = 3.0e38f;
-            if (j < N) {
-                x = xs[u]; y = ys[u]; z = zs[u];
-                n = x * x + y * y + z * z;
-                nv = fmaxf(nv, n);
-            }
-            f[j] = x; f[Np + j] = y; f[2 * Np + j] = z; f[3 * Np + j] = n;
-            if (H) {
-                if (rows16) write_row16(H, (size_t)b * Np + j, x, y, z, n);
-                else write_row(H, (size_t)b * Np + j, x, y, z, n);
-            }
-        }
-    }
-    nv = wave_max_u(nv);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = nv;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float m = red[0];
-        for (int w = 1; w < CFEAT_THREADS / 64; ++w) m = fmaxf(m, red[w]);
-        nmax[b * CFEAT_SLOTS + by] = __float_as_uint(m);
-    }
+    feat_slice(other ? j1 : j0, b, sy - (other ? j0.ysplit : 0), red);
 }
 
 // Queries the filter could not decide (another 32-target block within the error band of the best one: 0.2-2 %
@@ -1793,6 +1671,7 @@ static inline size_t mfma_ws_floats(int B, int Nt, int Nq) {
            + (size_t)B * pad32(Nt) + (size_t)B * (pad32(Nt) / 32) * CS_BOXF;   // + permutation + block boxes (sorted mode); multiple of 4 floats
 }
 
+static inline int feat_split(int Ntp) { const int y = (Ntp + CFEAT_WGPTS - 1) / CFEAT_WGPTS; return y > CFEAT_SLOTS ? CFEAT_SLOTS : y; }
 struct MfmaWs { float* F; unsigned short* H; unsigned int* nmax; int* undecided; int32_t* perm; float* boxes; int Ntp; };
 
 static MfmaWs mfma_carve(float* F, int B, int Nt, int Nq) {
@@ -1810,16 +1689,19 @@ static MfmaWs mfma_carve(float* F, int B, int Nt, int Nq) {
 // both directions: features of both clouds (one launch) -> filtered scan of p1 against p2 and of p2 against p1 ->
 // exact fix-up of the undecided queries of both (one launch)
 static int mfma_both(const float* p1, const float* p2, int B, int N, int M, float* ws, float* d1, int32_t* i1, float* d2,
-                     int32_t* i2, int prec, hipStream_t s) {              // prec 0: fp32 MFMA, 1: bf16 x 3, 2: fp16 x 2
+                     int32_t* i2, int prec, hipStream_t s, bool features_ready = false) {   // prec 0: fp32 MFMA, 1: bf16 x 3, 2: fp16 x 2
     const bool fp32_filter = prec == 0;
     const MfmaWs w2 = mfma_carve(ws, B, M, N);                            // p2 = targets of direction 1
     const MfmaWs w1 = mfma_carve(ws + mfma_ws_floats(B, M, N), B, N, M);  // p1 = targets of direction 2
-    auto split = [](int Ntp) { const int y = (Ntp + CFEAT_WGPTS - 1) / CFEAT_WGPTS; return y > CFEAT_SLOTS ? CFEAT_SLOTS : y; };
+    auto split = [](int Ntp) { return feat_split(Ntp); };
     const FeatJob f2{p2, M, w2.Ntp, split(w2.Ntp), w2.F, w2.nmax, fp32_filter ? nullptr : w2.H, w2.undecided, prec == 2};
     const FeatJob f1{p1, N, w1.Ntp, split(w1.Ntp), w1.F, w1.nmax, fp32_filter ? nullptr : w1.H, w1.undecided, prec == 2};
-    VPN_LAUNCH(chamfer_feat_kernel, dim3(B * (f2.ysplit + f1.ysplit)), dim3(CFEAT_THREADS), 0, s, f2, f1, B);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return (int)e;
+    hipError_t e = hipSuccess;
+    if (!features_ready) {      // mode 7: written by vpn_hotpath_sample_fwd into the same workspace, earlier on this stream
+        VPN_LAUNCH(chamfer_feat_kernel, dim3(B * (f2.ysplit + f1.ysplit)), dim3(CFEAT_THREADS), 0, s, f2, f1, B);
+        e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+    }
     {
         const int gx1 = (N + 127) / 128, gx2 = (M + 127) / 128;
         const ScanJob s1{p1, w2.F, w2.H, w2.nmax, N, M, w2.Ntp, gx1, gx1 * B, d1, i1, w2.undecided};     // p1 against p2
@@ -1841,6 +1723,22 @@ static int mfma_both(const float* p1, const float* p2, int B, int N, int M, floa
     VPN_LAUNCH(chamfer_fixup_kernel, dim3(2 * B * CF_GROUPS), dim3(CF_THREADS), 0, s, x1, x2, B);
     e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
+}
+
+// the two feature jobs of the fp16 filter as mfma_both lays them out (vpn_chamfer_feat.h)
+static int chamfer_mode();
+int chamfer_feat_jobs(void* workspace, size_t workspace_bytes, int B, int N, int M, const float* p1, const float* p2,
+                      FeatJob* job1, FeatJob* job2) {
+    if (!workspace || B <= 0 || N <= 0 || M <= 0 || ((uintptr_t)workspace & 15) != 0) return VPN_E_BADARG;
+    if (workspace_bytes < vpn_chamfer_workspace(B, N, M)) return VPN_E_BADARG;
+    const int forced = chamfer_mode();
+    if (!(forced == 6 || (forced == 0 && (long)N * M >= 512L * 512L))) return VPN_E_BADARG;   // the scan would not be mode 6
+    float* ws = (float*)workspace;
+    const MfmaWs w2 = mfma_carve(ws, B, M, N);
+    const MfmaWs w1 = mfma_carve(ws + mfma_ws_floats(B, M, N), B, N, M);
+    *job2 = FeatJob{p2, M, w2.Ntp, feat_split(w2.Ntp), w2.F, w2.nmax, w2.H, w2.undecided, 1};
+    *job1 = FeatJob{p1, N, w1.Ntp, feat_split(w1.Ntp), w1.F, w1.nmax, w1.H, w1.undecided, 1};
+    return 0;
 }
 
 struct CloudWs { float* sorted; int32_t* perm; float* boxes; int C; };
@@ -2003,8 +1901,9 @@ extern "C" int vpn_chamfer_fwd_ws(const float* p1, const float* p2, int B, int N
         if (rc) return rc;
         return nn_dispatch(p2, p1, B, M, N, dist2, idx2, s);
     }
-    if (mode == 3 || mode == 4 || mode == 6) {
-        return mfma_both(p1, p2, B, N, M, (float*)workspace, dist1, idx1, dist2, idx2, mode == 4 ? 0 : (mode == 3 ? 1 : 2), s);
+    if (mode == 3 || mode == 4 || mode == 6 || mode == 7) {
+        return mfma_both(p1, p2, B, N, M, (float*)workspace, dist1, idx1, dist2, idx2, mode == 4 ? 0 : (mode == 3 ? 1 : 2), s,
+                         mode == 7);
     }
     if (mode == 5) return mfma_sorted_both(p1, p2, B, N, M, (float*)workspace, dist1, idx1, dist2, idx2, s);
     float* cur = (float*)workspace;

@@ -12,6 +12,7 @@
 // over the n points.  Backward: dL/d(v,q,t) only needs G = sum_n g_n c_n^T (3x3) and
 // sum_n g_n, reduced wave-shuffle -> LDS -> one chain-rule pass by lane 0.
 #include "vpn_raster_common.h"
+#include "vpn_chamfer_feat.h"
 
 namespace vpn {
 
@@ -86,13 +87,13 @@ __device__ inline void load_prim_saved(PrimLds& P, const float* prm, int kind, i
     if (P.kind == VPN_CUBOID) cuboid_quota(P.v, n, P.cum);
 }
 
-__global__ __launch_bounds__(SAMP_BLOCK) void sample_fwd_kernel(
+// one workgroup = the n points of primitive k of sample b.  `feat` (training step only): the Chamfer filter's features
+// of the sampled cloud (planes, fp16 rows, the slice's max norm; slot k of the sample) are written with the points --
+// they used to be written by a kernel of their own that re-read the points first.
+__device__ inline void sample_wg(PrimLds& P, float* red, int b, int k,
     const float* __restrict__ params, const int32_t* __restrict__ kinds, const float* __restrict__ u,
-    uint64_t seed, const uint64_t* __restrict__ seed_dev, uint64_t sample_base, int K, int n,
-    float* __restrict__ points, const RasterPrep rp) {
-    __shared__ PrimLds P;
-    if (seed_dev) seed += *seed_dev;
-    const int k = blockIdx.x, b = blockIdx.y;
+    uint64_t seed, uint64_t sample_base, int K, int n,
+    float* __restrict__ points, const RasterPrep& rp, const FeatJob* feat) {
     const float* prm = params + ((size_t)b * K + k) * VPN_PARAM_STRIDE;
     if (threadIdx.x == 0) load_prim(P, prm, kinds[k], n);
     // the training step renders the same primitives: their raster records (pose, ray coefficients, culling conic) are
@@ -109,6 +110,7 @@ __global__ __launch_bounds__(SAMP_BLOCK) void sample_fwd_kernel(
     const float tx = prm[7], ty = prm[8], tz = prm[9];
     const float* ub = u ? u + ((size_t)b * K + k) * n * 3 : nullptr;
     float* out = points + ((size_t)b * K + k) * n * 3;
+    float nv = 0.0f;
     for (int p = threadIdx.x; p < n; p += SAMP_BLOCK) {
         float uu[3];
         if (ub) { uu[0] = ub[p * 3]; uu[1] = ub[p * 3 + 1]; uu[2] = ub[p * 3 + 2]; }
@@ -117,9 +119,43 @@ __global__ __launch_bounds__(SAMP_BLOCK) void sample_fwd_kernel(
         canonical_coeff(P, p, uu, c);
         float x = c[0] * P.v[0], y = c[1] * P.v[1], z = c[2] * P.v[2];
         const Mat3& R = P.pose.R;
-        st3(out + p * 3, (R.m[0][0] * x + R.m[0][1] * y + R.m[0][2] * z) + tx,   // rotate.py:22-23, translate.py:8
-            (R.m[1][0] * x + R.m[1][1] * y + R.m[1][2] * z) + ty, (R.m[2][0] * x + R.m[2][1] * y + R.m[2][2] * z) + tz);
+        const float px = (R.m[0][0] * x + R.m[0][1] * y + R.m[0][2] * z) + tx;   // rotate.py:22-23, translate.py:8
+        const float py = (R.m[1][0] * x + R.m[1][1] * y + R.m[1][2] * z) + ty;
+        const float pz = (R.m[2][0] * x + R.m[2][1] * y + R.m[2][2] * z) + tz;
+        st3(out + p * 3, px, py, pz);
+        if (feat) nv = fmaxf(nv, feat_point(*feat, b, k * n + p, px, py, pz));
     }
+    if (feat) {
+        // the last primitive's workgroup also writes the padding rows [N, Np) of the sample (fewer than 64)
+        if (k == K - 1) for (int j = K * n + (int)threadIdx.x; j < feat->Np; j += SAMP_BLOCK) feat_point(*feat, b, j, 0.f, 0.f, 0.f);
+        feat_finish_slice(*feat, b, k, nv, red);
+    }
+}
+
+__global__ __launch_bounds__(SAMP_BLOCK) void sample_fwd_kernel(
+    const float* __restrict__ params, const int32_t* __restrict__ kinds, const float* __restrict__ u,
+    uint64_t seed, const uint64_t* __restrict__ seed_dev, uint64_t sample_base, int K, int n,
+    float* __restrict__ points, const RasterPrep rp) {
+    __shared__ PrimLds P;
+    if (seed_dev) seed += *seed_dev;
+    sample_wg(P, nullptr, blockIdx.y, blockIdx.x, params, kinds, u, seed, sample_base, K, n, points, rp, nullptr);
+}
+
+// Forward launch of the training step with the Chamfer features inside: 1-D grid of B * (K + gt.ysplit) workgroups
+// decoded like the feature kernel's (sample b on XCD b / (B/8)): slices [0, K) are the sampler's workgroups (primitive =
+// slice, also the slot of the max norm: K <= CFEAT_SLOTS), slices [K, K + gt.ysplit) convert the ground-truth cloud.
+__global__ __launch_bounds__(SAMP_BLOCK) void sample_feat_fwd_kernel(
+    const float* __restrict__ params, const int32_t* __restrict__ kinds, const float* __restrict__ u,
+    uint64_t seed, const uint64_t* __restrict__ seed_dev, uint64_t sample_base, int B, int K, int n,
+    float* __restrict__ points, const RasterPrep rp, const FeatJob pred, const FeatJob gt) {
+    __shared__ PrimLds P;
+    __shared__ float red[SAMP_BLOCK / 64];
+    static_assert(SAMP_BLOCK == CFEAT_THREADS, "feature slices are written by sampler-sized workgroups");
+    if (seed_dev) seed += *seed_dev;
+    int b, sy;
+    feat_decode(blockIdx.x, B, b, sy);
+    if (sy < K) sample_wg(P, red, b, sy, params, kinds, u, seed, sample_base, K, n, points, rp, &pred);
+    else feat_slice(gt, b, sy - K, red);
 }
 
 __global__ __launch_bounds__(SAMP_BLOCK) void sample_bwd_kernel(
@@ -637,16 +673,40 @@ extern "C" int vpn_sample_fwd(const float* params, const int32_t* kinds, const f
 }
 
 // sampler forward of the training step: also writes the raster records of the same primitives (what the first launch
-// of vpn_raster_total_fwd would compute) and zeroes the arrival counter at the head of loss_ws
+// of vpn_raster_total_fwd would compute) and zeroes the arrival counter at the head of loss_ws; with a Chamfer
+// workspace it also writes the matrix-pipe filter's features of the sampled cloud and of gt_points into it
 extern "C" int vpn_hotpath_sample_fwd(const float* params, const int32_t* kinds, const float* u, uint64_t seed,
                                       const uint64_t* seed_dev, uint64_t sample_base, int B, int K, int n, float* points,
                                       const float* cam, int H, int W, float sigma, void* records, void* loss_ws,
+                                      const float* gt_points, int M, void* chamfer_ws, size_t chamfer_ws_bytes,
                                       void* stream) {
     if (!cam || !records || H <= 0 || W <= 0 || !(sigma > 0.f) || K > VPN_MAX_PRIMS) return VPN_E_BADARG;
     if (((uintptr_t)records & 15) != 0) return VPN_E_BADARG;
     RasterPrep rp;
     rp.cam = cam; rp.H = H; rp.W = W; rp.sigma = sigma; rp.rec = (float4*)records; rp.zero_me = (int*)loss_ws;
-    return launch_sample_fwd(params, kinds, u, seed, seed_dev, sample_base, B, K, n, points, rp, stream);
+    if (!chamfer_ws) return launch_sample_fwd(params, kinds, u, seed, seed_dev, sample_base, B, K, n, points, rp, stream);
+    if (!params || !kinds || !points || !gt_points) return VPN_E_BADARG;
+    if (B <= 0 || K <= 0 || n <= 0 || M <= 0 || K > CFEAT_SLOTS) return VPN_E_BADARG;
+    if ((long long)B * K * n > 0x7fffffffLL) return VPN_E_TOOBIG;
+    FeatJob pred, gt;
+    int rc = chamfer_feat_jobs(chamfer_ws, chamfer_ws_bytes, B, K * n, M, points, gt_points, &pred, &gt);
+    if (rc) return rc;
+    pred.ysplit = K;                      // one slice (and one max-norm slot) per primitive
+    VPN_LAUNCH(sample_feat_fwd_kernel, dim3((unsigned)B * (unsigned)(K + gt.ysplit)), dim3(SAMP_BLOCK), 0, (hipStream_t)stream,
+               params, kinds, u, seed, seed_dev, sample_base, B, K, n, points, rp, pred, gt);
+    VPN_LAUNCH_CHECK();
+    return 0;
+}
+
+// 1 if vpn_hotpath_sample_fwd can write the Chamfer features for these sizes (the automatic mode of
+// vpn_chamfer_fwd_ws takes the fp16 filter and every primitive gets its own max-norm slot): the caller then runs
+// vpn_chamfer_fwd_ws with mode 7 on the same workspace and stream
+extern "C" int vpn_hotpath_fused_features(int B, int K, int n, int M) {
+    if (B <= 0 || K <= 0 || n <= 0 || M <= 0 || K > CFEAT_SLOTS) return 0;
+    FeatJob a, b;
+    static float dummy[4] __attribute__((aligned(16)));
+    // only the mode decision of chamfer_feat_jobs matters here: a workspace "large enough" is pretended
+    return chamfer_feat_jobs(dummy, (size_t)-1, B, K * n, M, nullptr, nullptr, &a, &b) == 0 ? 1 : 0;
 }
 
 extern "C" int vpn_sample_bwd(const float* params, const int32_t* kinds, const float* u, uint64_t seed,

@@ -525,10 +525,15 @@ class HotPathLossFunction(Function):
                     if t is not None:
                         t.record_stream(side)
         points = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
+        cws = torch.empty((L.vpn_chamfer_workspace(B, N, M) // 4,), dtype=torch.float32, device=dev)
+        chamfer_mode = 0
         if side is None:        # one stream: the sampler's launch also writes the raster records of the same primitives
+            # ... and, when the Chamfer scan will be the matrix-pipe filter, that filter's features of both clouds
+            fused = bool(L.vpn_hotpath_fused_features(B, K, n, M))
             _lib.call('vpn_hotpath_sample_fwd', _lib.ptr(params), _lib.ptr(kinds), None, seed_host, seed_dev,
                       int(sample_base), B, K, n, _lib.ptr(points), _lib.ptr(cam), H, W, float(sigma), _lib.ptr(rec),
-                      _lib.ptr(lws), s)
+                      _lib.ptr(lws), _lib.ptr(gt_points), M, _lib.ptr(cws) if fused else None, cws.numel() * 4, s)
+            chamfer_mode = 7 if fused else 0
         else:
             _lib.call('vpn_sample_fwd', _lib.ptr(params), _lib.ptr(kinds), None, seed_host, seed_dev, int(sample_base), B,
                       K, n, _lib.ptr(points), s)
@@ -536,9 +541,8 @@ class HotPathLossFunction(Function):
         d2 = torch.empty((B, M), dtype=torch.float32, device=dev)
         i1 = torch.empty((B, N), dtype=torch.int32, device=dev)
         i2 = torch.empty((B, M), dtype=torch.int32, device=dev)
-        cws = torch.empty((L.vpn_chamfer_workspace(B, N, M) // 4,), dtype=torch.float32, device=dev)
         _lib.call('vpn_chamfer_fwd_ws', _lib.ptr(points), _lib.ptr(gt_points), B, N, M, _lib.ptr(d1), _lib.ptr(i1),
-                  _lib.ptr(d2), _lib.ptr(i2), _lib.ptr(cws), cws.numel() * 4, 0, s)
+                  _lib.ptr(d2), _lib.ptr(i2), _lib.ptr(cws), cws.numel() * 4, chamfer_mode, s)
         if side is not None:
             main.wait_stream(side)
         else:
