@@ -219,6 +219,56 @@ def test_fused_chamfer_sampler_backward(vpn):
         assert torch.equal(outs[0], outs[1])
 
 
+def test_sampler_written_chamfer_features(vpn):
+    """vpn_hotpath_sample_fwd with a Chamfer workspace + vpn_chamfer_fwd_ws(mode 7) must give the bits of the sampler
+    followed by the stand-alone scan (mode 6, its own feature kernel) and of brute force: odd batch sizes (no XCD
+    remap), point counts that are not multiples of 64 (padding rows written by the last primitive's workgroup), the
+    largest primitive count with a slot of its own (64), mixed kinds, a ground-truth cloud with a ragged last slice.
+    vpn_hotpath_fused_features says when the fusion applies."""
+    from vpn_amd import _lib
+    L = _lib.lib()
+    dev = torch.device(DEV)
+    gen = torch.Generator().manual_seed(4711)
+    assert L.vpn_hotpath_fused_features(64, 32, 256, 2048) == 1            # C3
+    assert L.vpn_hotpath_fused_features(2, 65, 256, 2048) == 0             # more primitives than max-norm slots
+    assert L.vpn_hotpath_fused_features(2, 4, 16, 300) == 0                # small clouds: brute force, no features
+    for (B, K, n, M, H, W) in ((3, 7, 100, 777, 24, 40), (8, 64, 33, 2050, 16, 16), (16, 5, 257, 1000, 32, 32)):
+        assert L.vpn_hotpath_fused_features(B, K, n, M) == 1
+        N = K * n
+        params = g(rand_params(gen, B, K))
+        kinds = vpn.kinds_tensor(sorted((int(x) for x in torch.randint(0, 2, (K,), generator=gen)), reverse=True), dev)
+        gt = g(torch.rand(B, M, 3, generator=gen) - 0.5)
+        cam = g(torch.tensor([[1.0, 0.0, 0.0]]).expand(B, 3).contiguous())
+        rec = torch.empty((L.vpn_raster_records_size(B, K, H, W) // 4,), dtype=torch.float32, device=dev)
+        lws = torch.zeros((L.vpn_raster_loss_workspace(B, H, W) // 4,), dtype=torch.float32, device=dev)
+        nbytes = L.vpn_chamfer_workspace(B, N, M)
+        outs = []
+        for fused in (True, False):
+            ws = torch.full((nbytes // 4,), float('nan'), dtype=torch.float32, device=dev)   # nothing may rely on old contents
+            pts = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
+            _lib.call('vpn_hotpath_sample_fwd', _lib.ptr(params), _lib.ptr(kinds), None, 99, None, 5, B, K, n, _lib.ptr(pts),
+                      _lib.ptr(cam), H, W, 0.05, _lib.ptr(rec), _lib.ptr(lws), _lib.ptr(gt), M,
+                      _lib.ptr(ws) if fused else None, nbytes, _lib.stream())
+            d1 = torch.empty((B, N), device=dev); d2 = torch.empty((B, M), device=dev)
+            i1 = torch.empty((B, N), dtype=torch.int32, device=dev); i2 = torch.empty((B, M), dtype=torch.int32, device=dev)
+            _lib.call('vpn_chamfer_fwd_ws', _lib.ptr(pts), _lib.ptr(gt), B, N, M, _lib.ptr(d1), _lib.ptr(i1), _lib.ptr(d2),
+                      _lib.ptr(i2), _lib.ptr(ws), nbytes, 7 if fused else 6, _lib.stream())
+            outs.append((pts, d1, i1, d2, i2))
+        for x, y in zip(*outs):
+            assert torch.equal(x, y), (B, K, n, M)
+        ref = vpn.chamfer_nn(outs[0][0], gt, mode='brute')
+        assert all(torch.equal(x, y) for x, y in zip(outs[0][1:], ref)), (B, K, n, M)
+    # a workspace that is too small, or sizes the fusion does not cover, are refused, not mis-executed
+    ws = torch.empty((16,), dtype=torch.float32, device=dev)
+    B, K, n, M = 2, 4, 200, 700
+    pts = torch.empty((B, K * n, 3), dtype=torch.float32, device=dev)
+    with pytest.raises(RuntimeError):
+        _lib.call('vpn_hotpath_sample_fwd', _lib.ptr(g(rand_params(gen, B, K))), _lib.ptr(vpn.kinds_tensor([0] * K, dev)),
+                  None, 1, None, 0, B, K, n, _lib.ptr(pts), _lib.ptr(g(torch.ones(B, 3))), 16, 16, 0.05,
+                  _lib.ptr(torch.empty((L.vpn_raster_records_size(B, K, 16, 16) // 4,), device=dev)), None,
+                  _lib.ptr(g(torch.rand(B, M, 3))), M, _lib.ptr(ws), 64, _lib.stream())
+
+
 # ----------------------------------------------------------------------------- Chamfer
 def ulp_diff(a, b):
     return int((a.contiguous().view(torch.int32) - b.contiguous().view(torch.int32)).abs().max())

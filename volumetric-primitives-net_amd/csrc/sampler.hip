@@ -117,11 +117,18 @@ __device__ inline void sample_wg(PrimLds& P, float* red, int b, int k,
         else philox_uniform3(seed, sample_base + (uint64_t)b, (uint32_t)k, (uint32_t)p, uu);
         float c[3];
         canonical_coeff(P, p, uu, c);
-        float x = c[0] * P.v[0], y = c[1] * P.v[1], z = c[2] * P.v[2];
-        const Mat3& R = P.pose.R;
-        const float px = (R.m[0][0] * x + R.m[0][1] * y + R.m[0][2] * z) + tx;   // rotate.py:22-23, translate.py:8
-        const float py = (R.m[1][0] * x + R.m[1][1] * y + R.m[1][2] * z) + ty;
-        const float pz = (R.m[2][0] * x + R.m[2][1] * y + R.m[2][2] * z) + tz;
+        float px, py, pz;
+        {
+            // every product and sum rounded separately, like the reference's element-wise ops (rotate.py:22-23,
+            // translate.py:8) -- and so that this kernel and sample_feat_fwd_kernel give the same bits whatever the
+            // compiler would contract in either
+#pragma clang fp contract(off)
+            const float x = c[0] * P.v[0], y = c[1] * P.v[1], z = c[2] * P.v[2];
+            const Mat3& R = P.pose.R;
+            px = (R.m[0][0] * x + R.m[0][1] * y + R.m[0][2] * z) + tx;
+            py = (R.m[1][0] * x + R.m[1][1] * y + R.m[1][2] * z) + ty;
+            pz = (R.m[2][0] * x + R.m[2][1] * y + R.m[2][2] * z) + tz;
+        }
         st3(out + p * 3, px, py, pz);
         if (feat) nv = fmaxf(nv, feat_point(*feat, b, k * n + p, px, py, pz));
     }
