@@ -640,6 +640,14 @@ __global__ __launch_bounds__(64) void chamfer_nn_pruned_kernel(
 // =====================================================================================
 typedef float f16v __attribute__((ext_vector_type(16)));
 constexpr int CM_BLOCK = 256;            // 4 waves x 32 queries
+#ifndef CM_WAVES16_N
+#define CM_WAVES16_N 8
+#endif
+// waves per workgroup of the fp16 filter: they share the LDS tiles, so 8 waves halve the tile fetches, LDS writes and
+// barriers per query (98.7-99.1 us against 100.1-102.5 with 4 waves, same box, eager launches)
+constexpr int CM_WAVES16 = CM_WAVES16_N;
+constexpr int CM_BLOCK16 = 64 * CM_WAVES16;
+template <int PREC> constexpr int cm_block() { return PREC == 2 ? CM_BLOCK16 : CM_BLOCK; }
 constexpr int CM_TILE = 512;             // targets per LDS feature tile of the fp32 filter (16 B per target per buffer)
 constexpr float CM_EPS = 8.0f * 5.9604644775390625e-08f;   // 8 * 2^-24: bound on the relative rounding of t_ij (fp32 MFMA chain)
 // bf16 variant: 21 exact products accumulated in fp32 (<= 24 * 2^-24), dropped cross terms b2a3+b3a2+b3a3
@@ -942,7 +950,7 @@ struct ScanJob {          // one direction of a Chamfer call
 // 1024 = 0.8 rounds: 5 rounds of time); together they pack into 4.  The long job (more targets per query) goes
 // first so that its workgroups start early and the short ones fill in behind.
 template <int PREC>   // 0: fp32-input MFMA (shares the fp32 vector datapath), 1: bf16 3-piece split on the matrix pipe
-__global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_kernel(const ScanJob j0, const ScanJob j1, int nsamples) {
+__global__ __launch_bounds__(cm_block<PREC>()) void chamfer_nn_mfma_kernel(const ScanJob j0, const ScanJob j1, int nsamples) {
     const bool other = (int)blockIdx.x >= j0.G;
     const float* __restrict__ qpts = other ? j1.qpts : j0.qpts;
     const float* __restrict__ F = other ? j1.F : j0.F;
@@ -964,7 +972,7 @@ __global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_kernel(const ScanJob
     const int b = vid / gx, bx = vid - b * gx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, jq = lane & 31, half = lane >> 5;
     const float* qb = qpts + (size_t)b * Nq * 3;
-    const int qi = (bx * 4 + wave) * 32 + jq;
+    const int qi = (bx * (cm_block<PREC>() / 64) + wave) * 32 + jq;
     const int qc = min(qi, Nq - 1);
     const F3 a3 = ld3(qb + qc * 3);
     const float ax = a3.x, ay = a3.y, az = a3.z;
@@ -1022,21 +1030,22 @@ __global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_kernel(const ScanJob
 #pragma unroll
             for (int e = 0; e < 8; ++e) bq[e] = half ? slot(8 + e) : slot(e);
         }
-        constexpr int F4 = CM_TILE16 * CM_ROWB16 / 16 / CM_BLOCK;      // float4 per lane per tile
-        static_assert(F4 == 2, "tile fetch is written for 2 float4 per lane");
+        constexpr int F4 = CM_TILE16 * CM_ROWB16 / 16 / CM_BLOCK16;    // float4 per lane per tile
+        static_assert(F4 == 2 || F4 == 1, "tile fetch is written for 1 or 2 float4 per lane");
         // tile t0 = rows [t0, t0 + CM_TILE16): one contiguous 8-KB run in HBM; float4 f of it is half (f & 1) of row f >> 1
         // and goes to LDS byte (f >> 1) * 48 + (f & 1) * 16.  No bounds checks: the row buffer is sized for 48-byte rows.
         const float4* Hq = reinterpret_cast<const float4*>(Hb) + threadIdx.x;
         struct Pre { float4 a, b; };
         auto fetch = [&](int t0) -> Pre {
             const float4* p = Hq + t0 * (CM_ROWB16 / 16);
-            return Pre{p[0], p[CM_BLOCK]};
+            if constexpr (F4 == 2) return Pre{p[0], p[CM_BLOCK16]};
+            else return Pre{p[0], p[0]};
         };
-        const int f0 = threadIdx.x, f1 = threadIdx.x + CM_BLOCK;
+        const int f0 = threadIdx.x, f1 = threadIdx.x + CM_BLOCK16;
         const int o0 = (f0 >> 1) * CM_ROWB + (f0 & 1) * 16, o1 = (f1 >> 1) * CM_ROWB + (f1 & 1) * 16;
         auto stash = [&](int buf, const Pre& v) {
             *reinterpret_cast<float4*>(&tileH[buf][o0]) = v.a;
-            *reinterpret_cast<float4*>(&tileH[buf][o1]) = v.b;
+            if constexpr (F4 == 2) *reinterpret_cast<float4*>(&tileH[buf][o1]) = v.b;
         };
         auto rd = [&](const unsigned char* T, int blkk) -> float4 {
             return *reinterpret_cast<const float4*>(T + blkk * 32 * CM_ROWB);
@@ -1703,7 +1712,8 @@ static int mfma_both(const float* p1, const float* p2, int B, int N, int M, floa
         if (e != hipSuccess) return (int)e;
     }
     {
-        const int gx1 = (N + 127) / 128, gx2 = (M + 127) / 128;
+        const int qpw = prec == 2 ? 32 * CM_WAVES16 : 128;          // queries per workgroup
+        const int gx1 = (N + qpw - 1) / qpw, gx2 = (M + qpw - 1) / qpw;
         const ScanJob s1{p1, w2.F, w2.H, w2.nmax, N, M, w2.Ntp, gx1, gx1 * B, d1, i1, w2.undecided};     // p1 against p2
         const ScanJob s2{p2, w1.F, w1.H, w1.nmax, M, N, w1.Ntp, gx2, gx2 * B, d2, i2, w1.undecided};     // p2 against p1
         const bool long_first = (long long)N > (long long)M;       // direction 2 scans the N targets: more work per workgroup
@@ -1714,7 +1724,7 @@ static int mfma_both(const float* p1, const float* p2, int B, int N, int M, floa
         else if (prec == 1)
             VPN_LAUNCH(chamfer_nn_mfma_kernel<1>, dim3(ja.G + jb.G), dim3(CM_BLOCK), 0, s, ja, jb, B);
         else
-            VPN_LAUNCH(chamfer_nn_mfma_kernel<2>, dim3(ja.G + jb.G), dim3(CM_BLOCK), 0, s, ja, jb, B);
+            VPN_LAUNCH(chamfer_nn_mfma_kernel<2>, dim3(ja.G + jb.G), dim3(CM_BLOCK16), 0, s, ja, jb, B);
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
     }
