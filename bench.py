@@ -29,7 +29,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3     # fp32 vector peak = fp32-input MFMA peak (MI355X_MICROARCH.md chip table)
-BF16_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA
+F16_PEAK_TFLOPS = 2500.0     # dense fp16 / bf16 MFMA (MI355X_MICROARCH.md; not the 2:1-sparsity figure)
 N_SIMD = 1024                # 256 CUs x 4 SIMD-32
 PMC_FILE = os.path.join(ROOT, 'profiles', 'r02_pmc.json')     # written by tools/pmc_collect.py from rocprofv3 passes
 
@@ -180,6 +180,25 @@ def raster_only(vpn_amd, _lib, dev, B, K, H, steps, warmup, windows, pmc_key, us
             'pmc_source': os.path.relpath(PMC_FILE, ROOT) if pmc else None}
 
 
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """Start the n ranks of `bench.py --gpus n` as children (one process per GPU, torch.distributed.run on
+    127.0.0.1) and wait for them.  Called before anything in this process has initialised the GPU; nothing is exec'd."""
+    import subprocess
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault('OMP_NUM_THREADS', '4')
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -210,15 +229,17 @@ def main():
     if args.no_extras:
         args.no_cpu_baseline = args.no_c2 = True
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` by itself: this process becomes the launcher.  It has not touched the GPU (no
+        # torch.cuda call, vpn_amd not imported) and never does; the N ranks are CHILD processes started through
+        # torch.distributed.run, their output is relayed and the worst return code is returned.
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d'
-                     % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
     if args.rehearse:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -404,26 +425,27 @@ def main():
     if dom.startswith('chamfer_nn_mfma_kernel'):      # the exact scan with the matrix-pipe filter, both directions per launch
         pair_flops *= 2.0
         tf = pair_flops / dom_s / 1e12
-        roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': round(tf, 2), 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(tf / FP32_PEAK_TFLOPS, 4), 'traffic': traffic_of(dom, pmc),
-                    'basis': 'ALGORITHMIC fp32 flops (8 per point pair: 3 sub, 3 mul, 2 add) / launch time, priced at the '
-                             'fp32 peak of MI355X (157.3 TFLOP/s: vector = fp32-input MFMA, MI355X_MICROARCH.md).  The '
-                             'kernel EXECUTES on the 16-bit matrix pipe (fp16 / bf16 pieces of the fp32 coordinates as a '
-                             'conservative filter with a rigorous error band, exact fp32 finish): see `executed`',
-                    'algorithmic_flops_per_launch': pair_flops, 'avg_launch_us': round(dom_s * 1e6, 2),
-                    'hbm_view': {'algorithmic_bytes_per_launch': alg_bytes[dom], 'achieved_GBps': round(hbm_gbs, 2),
-                                 'frac_of_8TBps': round(hbm_gbs / HBM_PEAK_GBS, 5)}}
-        if dom.endswith('<2>'):    # ONE v_mfma_f32_32x32x16_f16 per 32x32 pairs = 32 flop per pair (12 of 16 K slots used)
-            ex = 2.0 * 32.0 * B * N * M / dom_s / 1e12
-            roofline['executed'] = {'unit': 'fp16 MFMA', 'instruction': 'v_mfma_f32_32x32x16_f16 (fp32 coordinates scaled by 2^11 and '
-                                    'split into 2 fp16 pieces, 12 of 16 K slots used)', 'achieved_TFLOPs': round(ex, 1),
-                                    'peak_TFLOPs': BF16_PEAK_TFLOPS, 'frac': round(ex / BF16_PEAK_TFLOPS, 4)}
-        elif dom.endswith('<1>'):  # v_mfma_f32_32x32x16_bf16 + v_mfma_f32_32x32x8_bf16 per 32x32 pairs = 48 flop per pair
-            ex = 2.0 * 48.0 * B * N * M / dom_s / 1e12
-            roofline['executed'] = {'unit': 'bf16 MFMA', 'instruction': 'v_mfma_f32_32x32x16_bf16 + v_mfma_f32_32x32x8_bf16 '
-                                    '(fp32 coordinates split exactly into 3 bf16 pieces, 21 of 24 K slots used)',
-                                    'achieved_TFLOPs': round(ex, 1), 'peak_TFLOPs': BF16_PEAK_TFLOPS,
-                                    'frac': round(ex / BF16_PEAK_TFLOPS, 4)}
+        # EXECUTED work on the pipe the kernel runs on: matrix-pipe flops issued per 32x32 block of (target, query) pairs
+        #   <2>: ONE v_mfma_f32_32x32x16_f16 = 32 flop per pair (fp32 coordinates scaled by 2^11, split into 2 fp16
+        #        pieces, 12 of 16 K slots used);  <1>: 32x32x16_bf16 + 32x32x8_bf16 = 48 flop per pair;
+        #   <0>: two 32x32x2_f32 = 8 flop per pair on the fp32 pipe
+        per_pair, peak, pipe = {'<2>': (32.0, F16_PEAK_TFLOPS, 'fp16 matrix pipe: v_mfma_f32_32x32x16_f16, one per 32x32 pairs'),
+                                '<1>': (48.0, F16_PEAK_TFLOPS, 'bf16 matrix pipe: v_mfma_f32_32x32x16_bf16 + 32x32x8_bf16 per 32x32 pairs'),
+                                '<0>': (8.0, FP32_PEAK_TFLOPS, 'fp32 matrix pipe: 2 x v_mfma_f32_32x32x2_f32 per 32x32 pairs')}[dom[-3:]]
+        ex_flops = 2.0 * per_pair * B * N * M
+        ex = ex_flops / dom_s / 1e12
+        roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': round(ex, 1), 'peak': peak, 'unit': 'TFLOP/s',
+                    'frac': round(ex / peak, 4), 'traffic': traffic_of(dom, pmc),
+                    'basis': 'EXECUTED matrix-pipe flops per launch (MFMA instructions issued x flops each; equals PMC '
+                             'SQ_INSTS_MFMA x 32768 in profiles/) / measured launch time, against the dense MFMA peak of '
+                             'the input type (MI355X_MICROARCH.md).  ' + pipe,
+                    'executed_flops_per_launch': ex_flops, 'avg_launch_us': round(dom_s * 1e6, 2),
+                    'hbm_frac': round(hbm_gbs / HBM_PEAK_GBS, 5), 'hbm_achieved_GBps': round(hbm_gbs, 2),
+                    'algorithmic_bytes_per_launch': alg_bytes[dom],
+                    # the fp32 FORMULATION's flops (8 per point pair: 3 sub, 3 mul, 2 add) over the same time, against the
+                    # fp32 vector peak: may exceed 1 -- it says the filter beats any fp32 implementation, not headroom
+                    'algorithmic_fp32_tflops': round(tf, 2),
+                    'algorithmic_fp32_vs_vector_peak': round(tf / FP32_PEAK_TFLOPS, 4)}
     else:
         roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': round(hbm_gbs, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': round(hbm_gbs / HBM_PEAK_GBS, 5), 'traffic': traffic_of(dom, pmc),
@@ -496,8 +518,10 @@ def main():
             'hip_event_ms_per_step': {k: (round(v, 5) if isinstance(v, float) else v) for k, v in ev.items()},
             'roofline': roofline, 'raster_roofline': raster_roof, 'kernel_us': kernel_us, 'entry_us': entry_us,
         }
+        assert 0.0 < roofline['frac'] <= 1.0, 'roofline.frac must be a fraction: %r' % (roofline,)
         if step_hbm is not None:
             out['step_hbm'] = step_hbm
+            roofline['step_hbm_frac'] = step_hbm['frac']
         if cpu is not None:
             out['cpu_baseline'] = cpu
         if c2 is not None:
@@ -550,7 +574,13 @@ def cpu_baseline(params, gt_points, params2, K, n, H, W, sigma, gamma, z_far, ki
     (second primitive set, thresholded at 0.5) so the comparison does not depend on the kernel being checked."""
     from oracle import vpn_oracle as O
     host_cores = os.cpu_count() or 1
-    threads = min(host_cores, 16)            # the 1-GPU box's CPU share is 16 cores; more threads than that only thrash
+    # threads = the cores this process may actually run on, capped at the 1-GPU box's CPU share (16 of the host's
+    # cores: the box enforces that share, more threads than that only thrash); both numbers are reported
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = host_cores
+    threads = min(usable, 16)
     torch.set_num_threads(threads)
     S = params.shape[0]
     seed = 1234
@@ -603,9 +633,11 @@ def cpu_baseline(params, gt_points, params2, K, n, H, W, sigma, gamma, z_far, ki
     gerr = float((pg.grad.cpu() - grad_c).abs().max() / grad_c.abs().max())
     lerr = abs(float(loss_g.detach()) - loss_c) / abs(loss_c)
     return {'value': round(S / dt, 3), 'unit': 'images/s', 'cores': threads, 'host_cores': host_cores, 'kind': 'port',
+            'cores_note': 'min(cores in the affinity mask = %d, the 16-core CPU share of a 1-GPU box)' % usable,
             'sample': '%d images of the same workload; 1-image warm-up, then the median of 3 timed passes (%s s), torch CPU '
                       'fp32 with %d threads on a host with %d cores, dense B*N*M Chamfer as chamfer_distance.py:14-23'
                       % (S, '/'.join('%.1f' % t for t in times), threads, host_cores),
+            'parity_loss_rel': float('%.3g' % lerr), 'parity_grad_rel': float('%.3g' % gerr),
             'parity_vs_gpu': {'loss_rel': float('%.3g' % lerr), 'grad_rel': float('%.3g' % gerr),
                               'gt_images': 'rendered by the CPU oracle; %d pixels whose predicted depth lies within '
                                            '1e-5 of the GT depth (sign of the L1 term undecidable in fp32) had '
