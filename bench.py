@@ -196,7 +196,11 @@ def launch_ranks(n, argv):
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC: RCCL needs it on this driver
     env.setdefault('OMP_NUM_THREADS', '4')
-    return subprocess.run(cmd, env=env).returncode
+    # rank 0's JSON line is the only thing relayed to stdout (gloo / c10d chatter of the children goes to stderr)
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in (proc.stdout or '').splitlines():
+        print(line, file=sys.stdout if line.startswith('{"metric"') else sys.stderr, flush=True)
+    return proc.returncode
 
 
 def main():

@@ -18,7 +18,7 @@ def fake_run(cmd, env=None, **kw):
     seen['vpn_loaded'] = any(m == 'vpn_amd' or m.startswith('vpn_amd.') for m in sys.modules)
     seen['cuda_initialised'] = torch.cuda.is_initialized()
     seen['ipc'] = (env or {}).get('HSA_ENABLE_IPC_MODE_LEGACY')
-    class R: returncode = 7
+    class R: returncode = 7; stdout = 'noise\n{"metric": "x"}\n'
     return R()
 subprocess.run = fake_run
 import bench
@@ -46,6 +46,8 @@ def test_gpus_n_spawns_children_before_touching_the_gpu():
     assert seen['vpn_loaded'] is False and seen['cuda_initialised'] is False
     assert seen['ipc'] == '0'
     assert seen['rc'] == 7            # the children's return code is the parent's
+    # only rank 0's JSON line reaches stdout
+    assert [l for l in out.stdout.splitlines() if not l.startswith('PROBE ')] == ['{"metric": "x"}']
 
 
 def test_under_a_launcher_no_respawn():
