@@ -4,6 +4,6 @@
 cd $GRAFT_REPO_ROOT
 for v in "$@"; do
   VPN_EXTRA_FLAGS="$v" python volumetric-primitives-net_amd/build.py --force > /dev/null 2>&1
-  echo "== $v"; python tools/time_chamfer.py mfma16 2>&1 | grep "^mfma16\|== brute"
+  echo "== $v"; python tools/time_chamfer.py mfma16 2>&1 | grep "^mfma16\|== brute\|debug"
 done
 VPN_EXTRA_FLAGS="" python volumetric-primitives-net_amd/build.py --force > /dev/null 2>&1

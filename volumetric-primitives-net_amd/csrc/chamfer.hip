@@ -939,10 +939,108 @@ __device__ inline float near_error(float eps, float abs_eps, float na, float sna
 // products it enters, the constant a flushed denormal input (sqrt of a denormal < 1.1e-19)
 __device__ inline float sqrt_up(float x) { return __builtin_amdgcn_sqrtf(x) * (1.0f + 4.0e-7f) + 1.0e-18f; }
 
+
+// Exact resolution of a scan workgroup's own undecided queries (0.4 % of the queries at C3: 3.6 per workgroup of
+// direction 2, 0.2 of direction 1) by the workgroup itself, THREADS lanes, before it exits -- this used to be a launch
+// of its own (17-20 us at C3) that re-scanned the clouds from lists in memory.  FQ listed queries at a time against the
+// whole target cloud (fp32 planes x, y, z: coalesced float4 loads, UN groups of 4 targets per lane in flight):
+//   prefilter: t = |b|^2 - 2 a.b as three FMAs per pair.  t = d2 - |a|^2 within E = CM_EPS (|a| + |b|)^2 (3 roundings in
+//     |b|^2, 3 in the chain), and a target that can win or tie has exact d2 <= m2 (1 + 1e-6) (m2 = the exact
+//     minimum over the filter's best cell >= the true minimum), hence t <= thr = (m2 (1 + 1e-5) - |a|^2) + E + 4e-7 (m2 + |a|^2);
+//   a candidate (a handful per query) is evaluated exactly -- separately rounded d2, IEEE sqrt -- and posts the key
+//     (sqrt bits, index) to an LDS 64-bit atomic min: the smallest key IS the reference's answer, the lowest index among
+//     the targets whose SQUARE ROOT is smallest (chamfer_distance.py:19-23).  No per-lane bookkeeping, no second pass.
+// The list lives in the workgroup's LDS: lqd = (query x, y, z, the filter's sqrt(m2)), lqi = (query number, the
+// filter's index); snb = an upper bound of the largest target norm.
+#ifndef CM_FQ
+#define CM_FQ 4
+#endif
+#ifndef CM_FUN
+#define CM_FUN 2
+#endif
+template <int THREADS>
+__device__ inline void fixup_own(const float* __restrict__ Fb, float snb, int Nq, int Nt, int Ntp,
+                                 float* __restrict__ out_dist, int32_t* __restrict__ out_idx,
+                                 const float4* lqd, const int2* lqi, int count) {
+    constexpr int FQ = CM_FQ;            // listed queries per pass over the targets
+    constexpr int UN = CM_FUN;           // groups of 4 targets in flight per lane: a pass is latency, not arithmetic
+    __shared__ unsigned long long key[FQ];
+    const int n4 = Ntp >> 2;
+    const float4* f4 = reinterpret_cast<const float4*>(Fb);          // planes x, y, z at f4 + {0, 1, 2} * n4
+    if (threadIdx.x < FQ) key[threadIdx.x] = ~0ull;
+    for (int k0 = 0; k0 < count; k0 += FQ) {
+        // the queries of a pass are the same for every lane: m = -2 a (the query is -0.5 m, exactly) and the threshold
+        // live in SGPRs, which leaves the vector registers to the target loads in flight
+        float mx[FQ], my[FQ], mz[FQ], thr[FQ];
+#pragma unroll
+        for (int c = 0; c < FQ; ++c) {
+            const int k = min(k0 + c, count - 1);
+            const float4 a = lqd[k];                                  // the query and sqrt(m2)
+            const float na = a.x * a.x + a.y * a.y + a.z * a.z;
+            const float sab = sqrt_up(na) + snb;
+            const float E = CM_EPS * (sab * sab) * (1.0f + 1.0e-6f);
+            const float m2 = a.w * a.w;                               // within 1.2e-7 relative of the exact m2
+            float th = (m2 * (1.0f + 1.0e-5f) - na) + (E + 4.0e-7f * (m2 + na));
+            th = th == th ? th : __builtin_inff();                    // NaN anywhere: every target is examined exactly
+            th = k0 + c < count ? th : -__builtin_inff();             // slots past the end of the list: no candidates
+            auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+            mx[c] = uni(-2.0f * a.x); my[c] = uni(-2.0f * a.y); mz[c] = uni(-2.0f * a.z); thr[c] = uni(th);
+        }
+        __syncthreads();                                              // keys initialised
+        for (int base = threadIdx.x; base < n4; base += UN * THREADS) {
+            float4 x[UN], y[UN], z[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {                            // rows past the cloud: clamped loads, skipped below
+                const int g4 = min(base + u * THREADS, n4 - 1);
+                x[u] = f4[g4]; y[u] = f4[n4 + g4]; z[u] = f4[2 * n4 + g4];
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                if (base + u * THREADS >= n4) break;
+                const float xs[4] = {x[u].x, x[u].y, x[u].z, x[u].w}, ys[4] = {y[u].x, y[u].y, y[u].z, y[u].w};
+                const float zs[4] = {z[u].x, z[u].y, z[u].z, z[u].w};
+                float ws[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)                           // |b|^2: 3 roundings
+                    ws[e] = __builtin_fmaf(zs[e], zs[e], __builtin_fmaf(ys[e], ys[e], xs[e] * xs[e]));
+#pragma unroll
+                for (int c = 0; c < FQ; ++c) {
+                    float t[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        t[e] = __builtin_fmaf(mx[c], xs[e], __builtin_fmaf(my[c], ys[e], __builtin_fmaf(mz[c], zs[e], ws[e])));
+                    if (fminf(fminf(fminf(t[0], t[1]), t[2]), t[3]) <= thr[c]) {      // rare: a handful of lanes per query
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int j = (base + u * THREADS) * 4 + e;
+                            if (t[e] <= thr[c] && j < Nt) {                            // rows past Nt are padding
+                                const float d = dist2_exact(-0.5f * mx[c], -0.5f * my[c], -0.5f * mz[c], xs[e], ys[e], zs[e]);
+                                atomicMin(&key[c], ((unsigned long long)__float_as_uint(sqrtf(d)) << 32) | (unsigned)j);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < FQ) {
+            const int k = k0 + threadIdx.x;
+            const unsigned long long best = key[threadIdx.x];
+            key[threadIdx.x] = ~0ull;                                // for the next group (ordered by its barrier)
+            if (k < count) {
+                const int qc = min(max(lqi[k].x, 0), Nq - 1);
+                // no candidate at all only for NaN / infinite inputs: the filter's answer stands
+                out_dist[qc] = best != ~0ull ? __uint_as_float((unsigned)(best >> 32)) : lqd[k].w;
+                out_idx[qc] = best != ~0ull ? (int)(unsigned)best : lqi[k].y;
+            }
+        }
+    }
+}
+
 struct ScanJob {          // one direction of a Chamfer call
     const float* qpts; const float* F; const unsigned short* H; const unsigned int* nmax;
     int Nq, Nt, Ntp, gx, G;                       // G = gx * B workgroups
-    float* out_dist; int32_t* out_idx; int* undecided;
+    float* out_dist; int32_t* out_idx;
 };
 
 // Both directions of a Chamfer call in ONE launch: workgroups [0, j0.G) run job 0, the rest job 1.  Launched
@@ -950,7 +1048,14 @@ struct ScanJob {          // one direction of a Chamfer call
 // 1024 = 0.8 rounds: 5 rounds of time); together they pack into 4.  The long job (more targets per query) goes
 // first so that its workgroups start early and the short ones fill in behind.
 template <int PREC>   // 0: fp32-input MFMA (shares the fp32 vector datapath), 1: bf16 3-piece split on the matrix pipe
-__global__ __launch_bounds__(cm_block<PREC>()) void chamfer_nn_mfma_kernel(const ScanJob j0, const ScanJob j1, int nsamples) {
+// 6 waves per SIMD: the tile loop needs ~70 VGPRs and LDS admits 3 workgroups of 8 waves per CU; the bound keeps the
+// fix-up tail (which few workgroups run) from raising the whole kernel's register allocation
+#ifdef CM_EXP_NOBOUND
+__global__ __launch_bounds__(cm_block<PREC>()) void chamfer_nn_mfma_kernel(
+#else
+__global__ __launch_bounds__(cm_block<PREC>(), 6) void chamfer_nn_mfma_kernel(
+#endif
+    const ScanJob j0, const ScanJob j1, int nsamples) {
     const bool other = (int)blockIdx.x >= j0.G;
     const float* __restrict__ qpts = other ? j1.qpts : j0.qpts;
     const float* __restrict__ F = other ? j1.F : j0.F;
@@ -960,7 +1065,6 @@ __global__ __launch_bounds__(cm_block<PREC>()) void chamfer_nn_mfma_kernel(const
     const int gx = other ? j1.gx : j0.gx, G = other ? j1.G : j0.G;
     float* __restrict__ out_dist = other ? j1.out_dist : j0.out_dist;
     int32_t* __restrict__ out_idx = other ? j1.out_idx : j0.out_idx;
-    int* __restrict__ undecided = other ? j1.undecided : j0.undecided;
     // Workgroups are dealt round-robin over the 8 XCDs (L2 is per XCD), so the id inside the job is remapped such
     // that all workgroups of a sample land on ONE XCD and stream its target rows out of that XCD's L2 (speed only:
     // any placement is correct; j0.G is a multiple of 8 whenever B is, so id & 7 is still the XCD).
@@ -1307,8 +1411,12 @@ __global__ __launch_bounds__(cm_block<PREC>()) void chamfer_nn_mfma_kernel(const
     // 4e-6 m2 covers the rounding of m2 and of |a|^2 and the width of a sqrt bucket.
     const float s = sqrtf(m2);                                      // IEEE: this one is the result
     const float band = E + 4.0e-6f * (m2 + na);                     // any target of the cloud (consistency of the best block)
+    // possible winners: a runner-up that can win or tie has exact d2 <= m2 (1 + 1e-6), i.e. a real d2 <= m2 (1 + 1.4e-6),
+    // and filters to at most that - |a|^2 + E_near; against the computed m2 - na (|a|^2 good to 3 ulp, the difference to
+    // 1): 4e-6 m2 + 4e-7 na covers it (|a|^2 used to be charged 4e-6 too: 2e-6 of a 4e-6 band for a query half a unit from
+    // the origin -- and 40 % of the undecided queries of direction 2)
     const float band_near = near_error(PREC == 2 ? CM_EPS_F16 : (PREC == 1 ? CM_EPS_BF16 : CM_EPS), PREC == 2 ? 5.9604644775390625e-08f : 0.0f,
-                                       na, sna, s * (1.0f + 1.0e-7f), E) + 4.0e-6f * (m2 + na);   // possible winners
+                                       na, sna, s * (1.0f + 1.0e-7f), E) + (4.0e-6f * m2 + 4.0e-7f * na);
     bool ambiguous = !(V2 > (m2 - na) + band_near) || !(m2 - na <= Bv + band);
     if (PREC == 2) ambiguous |= !(nb <= CM_DOMAIN16 && na <= CM_DOMAIN16);     // outside the fp16 filter's range: exact fix-up
     // lowest index attaining the minimum; a different d2 can only share the sqrt if it lies within a few ulp
@@ -1338,16 +1446,43 @@ __global__ __launch_bounds__(cm_block<PREC>()) void chamfer_nn_mfma_kernel(const
             if (d2[e] <= lim && sqrtf(d2[e]) == s) idx = min(idx, base + 8 * (e >> 2) + (e & 3));
     }
     idx = min(idx, __shfl_xor(idx, 32, 64));
+    // Decided queries store their result.  An undecided one goes on the WORKGROUP's list in LDS as (query, sqrt(m2),
+    // index inside the best cell) and is resolved exactly by this workgroup before it exits (fixup_own): no list in
+    // memory, no second launch, nothing shared between workgroups.
+    constexpr int QPW = cm_block<PREC>() / 2;                       // queries per workgroup = capacity of the list
+    __shared__ int s_cnt;
+    __shared__ float4 s_qd[QPW];
+    __shared__ int2 s_qi[QPW];
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
     if (half == 0 && qi < Nq) {
-        out_dist[(size_t)b * Nq + qi] = s;
-        out_idx[(size_t)b * Nq + qi] = idx;
-        if (ambiguous)                                             // resolved by chamfer_fixup_kernel
-            reinterpret_cast<int4*>(undecided + pad4(nsamples))[(size_t)b * Nq + atomicAdd(undecided + b, 1)] =
-                make_int4(qi, __float_as_int(ax), __float_as_int(ay), __float_as_int(az));
+        if (!ambiguous) {
+            out_dist[(size_t)b * Nq + qi] = s;
+            out_idx[(size_t)b * Nq + qi] = idx;
+        } else {
+            const int pos = atomicAdd(&s_cnt, 1);
+            s_qd[pos] = make_float4(ax, ay, az, s); s_qi[pos] = make_int2(qi, idx);
 #ifdef VPN_CHAMFER_DEBUG
-        if (ambiguous) atomicAdd(&g_dbg[6], 1ull);
+            atomicAdd(&g_dbg[6], 1ull);
 #endif
+        }
     }
+    __syncthreads();
+    const int cnt = s_cnt;
+    if (cnt == 0) return;
+#ifdef CM_EXP_NOFIX
+    return;
+#endif
+#ifdef VPN_CHAMFER_DEBUG
+    const unsigned long long t_fix = wall_clock64();
+#endif
+    fixup_own<cm_block<PREC>()>(Fb, snb, Nq, Nt, Ntp, out_dist + (size_t)b * Nq, out_idx + (size_t)b * Nq, s_qd, s_qi, cnt);
+#ifdef VPN_CHAMFER_DEBUG
+    if (threadIdx.x == 0) {       // [1]/[2]: 100 MHz ticks spent in the fix-up by workgroups of job 0 / job 1, [4]/[5]: how many
+        atomicAdd(&g_dbg[other ? 2 : 1], wall_clock64() - t_fix);
+        atomicAdd(&g_dbg[other ? 5 : 4], 1ull);
+    }
+#endif
 }
 
 // =====================================================================================
@@ -1695,16 +1830,16 @@ static MfmaWs mfma_carve(float* F, int B, int Nt, int Nq) {
     return w;
 }
 
-// both directions: features of both clouds (one launch) -> filtered scan of p1 against p2 and of p2 against p1 ->
-// exact fix-up of the undecided queries of both (one launch)
+// both directions: features of both clouds (one launch) -> filtered scan of p1 against p2 and of p2 against p1 with
+// the exact fix-up of the undecided queries inside (one launch)
 static int mfma_both(const float* p1, const float* p2, int B, int N, int M, float* ws, float* d1, int32_t* i1, float* d2,
                      int32_t* i2, int prec, hipStream_t s, bool features_ready = false) {   // prec 0: fp32 MFMA, 1: bf16 x 3, 2: fp16 x 2
     const bool fp32_filter = prec == 0;
     const MfmaWs w2 = mfma_carve(ws, B, M, N);                            // p2 = targets of direction 1
     const MfmaWs w1 = mfma_carve(ws + mfma_ws_floats(B, M, N), B, N, M);  // p1 = targets of direction 2
     auto split = [](int Ntp) { return feat_split(Ntp); };
-    const FeatJob f2{p2, M, w2.Ntp, split(w2.Ntp), w2.F, w2.nmax, fp32_filter ? nullptr : w2.H, w2.undecided, prec == 2};
-    const FeatJob f1{p1, N, w1.Ntp, split(w1.Ntp), w1.F, w1.nmax, fp32_filter ? nullptr : w1.H, w1.undecided, prec == 2};
+    const FeatJob f2{p2, M, w2.Ntp, split(w2.Ntp), w2.F, w2.nmax, fp32_filter ? nullptr : w2.H, prec == 2};
+    const FeatJob f1{p1, N, w1.Ntp, split(w1.Ntp), w1.F, w1.nmax, fp32_filter ? nullptr : w1.H, prec == 2};
     hipError_t e = hipSuccess;
     if (!features_ready) {      // mode 7: written by vpn_hotpath_sample_fwd into the same workspace, earlier on this stream
         VPN_LAUNCH(chamfer_feat_kernel, dim3(B * (f2.ysplit + f1.ysplit)), dim3(CFEAT_THREADS), 0, s, f2, f1, B);
@@ -1714,8 +1849,8 @@ static int mfma_both(const float* p1, const float* p2, int B, int N, int M, floa
     {
         const int qpw = prec == 2 ? 32 * CM_WAVES16 : 128;          // queries per workgroup
         const int gx1 = (N + qpw - 1) / qpw, gx2 = (M + qpw - 1) / qpw;
-        const ScanJob s1{p1, w2.F, w2.H, w2.nmax, N, M, w2.Ntp, gx1, gx1 * B, d1, i1, w2.undecided};     // p1 against p2
-        const ScanJob s2{p2, w1.F, w1.H, w1.nmax, M, N, w1.Ntp, gx2, gx2 * B, d2, i2, w1.undecided};     // p2 against p1
+        const ScanJob s1{p1, w2.F, w2.H, w2.nmax, N, M, w2.Ntp, gx1, gx1 * B, d1, i1};     // p1 against p2
+        const ScanJob s2{p2, w1.F, w1.H, w1.nmax, M, N, w1.Ntp, gx2, gx2 * B, d2, i2};     // p2 against p1
         const bool long_first = (long long)N > (long long)M;       // direction 2 scans the N targets: more work per workgroup
         const ScanJob& ja = long_first ? s2 : s1;
         const ScanJob& jb = long_first ? s1 : s2;
@@ -1728,11 +1863,8 @@ static int mfma_both(const float* p1, const float* p2, int B, int N, int M, floa
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
     }
-    const FixJob x1{w2.F, N, M, w2.Ntp, d1, i1, w2.undecided, nullptr};
-    const FixJob x2{w1.F, M, N, w1.Ntp, d2, i2, w1.undecided, nullptr};
-    VPN_LAUNCH(chamfer_fixup_kernel, dim3(2 * B * CF_GROUPS), dim3(CF_THREADS), 0, s, x1, x2, B);
-    e = hipGetLastError();
-    return e == hipSuccess ? 0 : (int)e;
+    // no fix-up launch: every scan workgroup resolves its own undecided queries exactly before it exits (fixup_own)
+    return 0;
 }
 
 // the two feature jobs of the fp16 filter as mfma_both lays them out (vpn_chamfer_feat.h)
@@ -1746,8 +1878,8 @@ int chamfer_feat_jobs(void* workspace, size_t workspace_bytes, int B, int N, int
     float* ws = (float*)workspace;
     const MfmaWs w2 = mfma_carve(ws, B, M, N);
     const MfmaWs w1 = mfma_carve(ws + mfma_ws_floats(B, M, N), B, N, M);
-    *job2 = FeatJob{p2, M, w2.Ntp, feat_split(w2.Ntp), w2.F, w2.nmax, w2.H, w2.undecided, 1};
-    *job1 = FeatJob{p1, N, w1.Ntp, feat_split(w1.Ntp), w1.F, w1.nmax, w1.H, w1.undecided, 1};
+    *job2 = FeatJob{p2, M, w2.Ntp, feat_split(w2.Ntp), w2.F, w2.nmax, w2.H, 1};
+    *job1 = FeatJob{p1, N, w1.Ntp, feat_split(w1.Ntp), w1.F, w1.nmax, w1.H, 1};
     return 0;
 }
 

@@ -79,7 +79,7 @@ constexpr int CFEAT_PTS = 4;                       // points per lane in flight
 
 struct FeatJob {          // one cloud: slices [0, ysplit) of a sample's workgroups belong to it
     const float* pts; int N, Np, ysplit;
-    float* F; unsigned int* nmax; unsigned short* H; int* undecided;
+    float* F; unsigned int* nmax; unsigned short* H;
     int rows16;           // rows as 32-byte fp16 pieces (PREC 2) instead of 48-byte bf16 pieces (PREC 1)
 };
 
@@ -114,10 +114,9 @@ __device__ inline float feat_point(const FeatJob& J, int b, int j, float x, floa
     return nv;
 }
 
-// per-workgroup bookkeeping of a slice: the max norm of the slice into its slot; slice 0 also resets the sample's
-// undecided list and zeroes the slots no slice owns.  `red`: CFEAT_THREADS / 64 floats of LDS.  Contains a barrier.
+// per-workgroup bookkeeping of a slice: the max norm of the slice into its slot; slice 0 also zeroes the slots no
+// slice owns.  `red`: CFEAT_THREADS / 64 floats of LDS.  Contains a barrier.
 __device__ inline void feat_finish_slice(const FeatJob& J, int b, int by, float nv, float* red) {
-    if (by == 0 && threadIdx.x == 0) J.undecided[b] = 0;     // this sample's list: the scan that follows appends to it
     if (by == 0 && (int)threadIdx.x >= J.ysplit && threadIdx.x < CFEAT_SLOTS) J.nmax[b * CFEAT_SLOTS + threadIdx.x] = 0u;
     nv = feat_wave_max(nv);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = nv;
