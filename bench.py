@@ -311,7 +311,7 @@ def main():
     if multi:
         reducer = (GradAllReduce if args.collective == 'allreduce' else GradAllGather)(Bg, K, dev, rank, world)
     one = torch.ones((), device=dev)
-    # Philox key of the step: a device counter bumped on the stream at the start of every step, read by the sampler
+    # Philox key of the step: a device counter bumped on the stream at the end of every step, read by the sampler
     # kernels, so every replay of the captured graph draws fresh surface points (the reference resamples each step)
     seed_buf = torch.full((1,), 1234, dtype=torch.int64, device=dev)
 
@@ -319,9 +319,10 @@ def main():
         # total = ChamferDistanceLoss(sample(params), gt) + SilhouetteLoss(L1) + L1 depth loss  (train.py:243-262),
         # one autograd node: sampler -> Chamfer scans -> raster with fused image losses, and the matching backward
         params.grad = None
-        seed_buf.add_(1)
+        # advance_seed: the launch that completes the step's losses also bumps the device step counter (no kernel of
+        # its own for the RNG advance)
         out = vpn_amd.HotPathLossFunction.apply(params, kinds, cam, gt_points, gt_sil, gt_depth, n, seed_buf, rank * B,
-                                                H, W, sigma, gamma, z_far, 1.0, 1.0, 1.0)
+                                                H, W, sigma, gamma, z_far, 1.0, 1.0, 1.0, 1.0, 1.0, False, True)
         out[2].backward(one)
         return out[2]
 

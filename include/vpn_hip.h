@@ -215,6 +215,21 @@ int vpn_raster_total_fwd(const float* params, const int32_t* kinds, const float*
                          int B, int K, int H, int W, float sigma, float gamma, float z_far,
                          const float* gt_sil, const float* gt_depth, int sil_mse, float w_sil, float w_dep,
                          void* records, void* loss_ws, void* workspace, int records_ready, void* stream);
+/* vpn_raster_total_fwd and vpn_loss_finalize in ONE launch (what SilhouetteLoss and the training step use): the tile
+ * wave that completes a sample sums that sample's tile losses, the one that completes the batch writes losses[4] as
+ * vpn_loss_finalize defines them (fixed summation order: bitwise reproducible).  chamfer_ws != NULL: the workspace a
+ * preceding vpn_chamfer_fwd_ws call on this stream ran its fp16 filter in (vpn_hotpath_fused_features(B, K, n, M) == 1,
+ * modes 0 / 6 / 7): the per-sample Chamfer term cd_b = cd_w1 mean_i dist1 + cd_w2 mean_j dist2 (chamfer_distance.py:25-28)
+ * is taken from the per-workgroup sums that scan left there, N and M are its cloud sizes; NULL: image losses only
+ * (cd = 0).  loss_b [B] (optional) receives cd_b.  seed_advance (optional): a device uint64 that is incremented once
+ * when the batch is complete -- the step counter vpn_hotpath_sample_fwd was given as seed_dev, so the next step draws
+ * fresh surface points without a kernel of its own; the seed this step used stays readable at (char*)loss_ws + 8. */
+int vpn_raster_total_fwd_fin(const float* params, const int32_t* kinds, const float* cam,
+                             int B, int K, int H, int W, float sigma, float gamma, float z_far,
+                             const float* gt_sil, const float* gt_depth, int sil_mse, float w_sil, float w_dep,
+                             void* records, void* loss_ws, void* workspace, int records_ready,
+                             const void* chamfer_ws, size_t chamfer_ws_bytes, int N, int M, float cd_w1, float cd_w2,
+                             float w_cd, float* losses, float* loss_b, uint64_t* seed_advance, void* stream);
 /* vpn_sample_fwd of the training step: the same launch also writes the raster records of the primitives it samples
  * (one workgroup per (sample, primitive) in both) and zeroes the arrival counter of loss_ws.
  * chamfer_ws != NULL (allowed when vpn_hotpath_fused_features(B, K, n, M) is 1): the launch also writes, into that

@@ -961,8 +961,8 @@ __device__ inline float sqrt_up(float x) { return __builtin_amdgcn_sqrtf(x) * (1
 template <int THREADS>
 __device__ inline void fixup_own(const float* __restrict__ Fb, float snb, int Nq, int Nt, int Ntp,
                                  float* __restrict__ out_dist, int32_t* __restrict__ out_idx,
-                                 const float4* lqd, const int2* lqi, int count) {
-    constexpr int FQ = CM_FQ;            // listed queries per pass over the targets
+                                 float4* lqd, const int2* lqi, int count) {
+    constexpr int FQ = THREADS >= 512 ? CM_FQ : 2;   // listed queries per pass over the targets (register budget of the host kernel)
     constexpr int UN = CM_FUN;           // groups of 4 targets in flight per lane: a pass is latency, not arithmetic
     __shared__ unsigned long long key[FQ];
     const int n4 = Ntp >> 2;
@@ -1030,8 +1030,10 @@ __device__ inline void fixup_own(const float* __restrict__ Fb, float snb, int Nq
             if (k < count) {
                 const int qc = min(max(lqi[k].x, 0), Nq - 1);
                 // no candidate at all only for NaN / infinite inputs: the filter's answer stands
-                out_dist[qc] = best != ~0ull ? __uint_as_float((unsigned)(best >> 32)) : lqd[k].w;
+                const float df = best != ~0ull ? __uint_as_float((unsigned)(best >> 32)) : lqd[k].w;
+                out_dist[qc] = df;
                 out_idx[qc] = best != ~0ull ? (int)(unsigned)best : lqi[k].y;
+                lqd[k].w = df;                                       // the caller sums the final distances
             }
         }
     }
@@ -1041,6 +1043,7 @@ struct ScanJob {          // one direction of a Chamfer call
     const float* qpts; const float* F; const unsigned short* H; const unsigned int* nmax;
     int Nq, Nt, Ntp, gx, G;                       // G = gx * B workgroups
     float* out_dist; int32_t* out_idx;
+    float* wgsum;                                 // [B][gx]: sum of the minima of each workgroup's queries (fixed order)
 };
 
 // Both directions of a Chamfer call in ONE launch: workgroups [0, j0.G) run job 0, the rest job 1.  Launched
@@ -1053,7 +1056,7 @@ template <int PREC>   // 0: fp32-input MFMA (shares the fp32 vector datapath), 1
 #ifdef CM_EXP_NOBOUND
 __global__ __launch_bounds__(cm_block<PREC>()) void chamfer_nn_mfma_kernel(
 #else
-__global__ __launch_bounds__(cm_block<PREC>(), 6) void chamfer_nn_mfma_kernel(
+__global__ __launch_bounds__(cm_block<PREC>(), PREC == 1 ? 5 : 6) void chamfer_nn_mfma_kernel(
 #endif
     const ScanJob j0, const ScanJob j1, int nsamples) {
     const bool other = (int)blockIdx.x >= j0.G;
@@ -1065,6 +1068,7 @@ __global__ __launch_bounds__(cm_block<PREC>(), 6) void chamfer_nn_mfma_kernel(
     const int gx = other ? j1.gx : j0.gx, G = other ? j1.G : j0.G;
     float* __restrict__ out_dist = other ? j1.out_dist : j0.out_dist;
     int32_t* __restrict__ out_idx = other ? j1.out_idx : j0.out_idx;
+    float* __restrict__ wgsum = other ? j1.wgsum : j0.wgsum;
     // Workgroups are dealt round-robin over the 8 XCDs (L2 is per XCD), so the id inside the job is remapped such
     // that all workgroups of a sample land on ONE XCD and stream its target rows out of that XCD's L2 (speed only:
     // any placement is correct; j0.G is a multiple of 8 whenever B is, so id & 7 is still the XCD).
@@ -1453,14 +1457,16 @@ __global__ __launch_bounds__(cm_block<PREC>(), 6) void chamfer_nn_mfma_kernel(
     __shared__ int s_cnt;
     __shared__ float4 s_qd[QPW];
     __shared__ int2 s_qi[QPW];
+    __shared__ float s_ws[cm_block<PREC>() / 64];
     if (threadIdx.x == 0) s_cnt = 0;
     __syncthreads();
+    int pos = -1;
     if (half == 0 && qi < Nq) {
         if (!ambiguous) {
             out_dist[(size_t)b * Nq + qi] = s;
             out_idx[(size_t)b * Nq + qi] = idx;
         } else {
-            const int pos = atomicAdd(&s_cnt, 1);
+            pos = atomicAdd(&s_cnt, 1);
             s_qd[pos] = make_float4(ax, ay, az, s); s_qi[pos] = make_int2(qi, idx);
 #ifdef VPN_CHAMFER_DEBUG
             atomicAdd(&g_dbg[6], 1ull);
@@ -1469,20 +1475,34 @@ __global__ __launch_bounds__(cm_block<PREC>(), 6) void chamfer_nn_mfma_kernel(
     }
     __syncthreads();
     const int cnt = s_cnt;
-    if (cnt == 0) return;
-#ifdef CM_EXP_NOFIX
-    return;
-#endif
+    float sfin = (half == 0 && qi < Nq) ? s : 0.0f;                 // this query's final minimum (once per query)
+#ifndef CM_EXP_NOFIX
+    if (cnt != 0) {
 #ifdef VPN_CHAMFER_DEBUG
-    const unsigned long long t_fix = wall_clock64();
+        const unsigned long long t_fix = wall_clock64();
 #endif
-    fixup_own<cm_block<PREC>()>(Fb, snb, Nq, Nt, Ntp, out_dist + (size_t)b * Nq, out_idx + (size_t)b * Nq, s_qd, s_qi, cnt);
+        fixup_own<cm_block<PREC>()>(Fb, snb, Nq, Nt, Ntp, out_dist + (size_t)b * Nq, out_idx + (size_t)b * Nq, s_qd, s_qi, cnt);
+        __syncthreads();
+        if (pos >= 0) sfin = s_qd[pos].w;                           // the resolved distance of an undecided query
 #ifdef VPN_CHAMFER_DEBUG
-    if (threadIdx.x == 0) {       // [1]/[2]: 100 MHz ticks spent in the fix-up by workgroups of job 0 / job 1, [4]/[5]: how many
-        atomicAdd(&g_dbg[other ? 2 : 1], wall_clock64() - t_fix);
-        atomicAdd(&g_dbg[other ? 5 : 4], 1ull);
+        if (threadIdx.x == 0) {   // [1]/[2]: 100 MHz ticks spent in the fix-up by workgroups of job 0 / job 1, [4]/[5]: how many
+            atomicAdd(&g_dbg[other ? 2 : 1], wall_clock64() - t_fix);
+            atomicAdd(&g_dbg[other ? 5 : 4], 1ull);
+        }
+#endif
     }
 #endif
+    // sum of the workgroup's minima in a fixed order (lanes by butterfly, waves in order): the loss finalisation adds
+    // gx numbers per sample and direction instead of re-reading dist [B,Nq]
+    sfin = wave_sum(sfin);
+    if (lane == 0) s_ws[wave] = sfin;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = s_ws[0];
+#pragma unroll
+        for (int v = 1; v < cm_block<PREC>() / 64; ++v) t += s_ws[v];
+        wgsum[(size_t)b * gx + bx] = t;
+    }
 }
 
 // =====================================================================================
@@ -1810,13 +1830,15 @@ __global__ __launch_bounds__(CM_BLOCK) void chamfer_nn_mfma_pruned_kernel(
 static inline int pad32(int n) { return (n + 63) & ~63; }   // feature planes padded to 64 targets (blocks are processed in pairs)
 // one direction: fp32 planes + bf16 rows of the targets + one tile of slack (the row tiles are fetched without
 // bounds checks) + nmax[B][CFEAT_SLOTS] + the lists of undecided queries (count[pad4(B)], 16-byte entries[B][Nq])
+static inline int wgsum_per_sample(int Nq) { return (Nq + 127) / 128; }       // capacity: the 4-wave filters have 128 queries per workgroup
 static inline size_t mfma_ws_floats(int B, int Nt, int Nq) {
     return (size_t)B * (4 + CM_ROWW) * pad32(Nt) + (size_t)CM_TILE16 * CM_ROWW + (size_t)B * CFEAT_SLOTS + (size_t)pad4(B) + 4 * (size_t)B * Nq
-           + (size_t)B * pad32(Nt) + (size_t)B * (pad32(Nt) / 32) * CS_BOXF;   // + permutation + block boxes (sorted mode); multiple of 4 floats
+           + (size_t)B * pad32(Nt) + (size_t)B * (pad32(Nt) / 32) * CS_BOXF    // + permutation + block boxes (sorted mode); multiple of 4 floats
+           + (size_t)pad4(B * wgsum_per_sample(Nq));                           // + per-workgroup sums of the minima
 }
 
 static inline int feat_split(int Ntp) { const int y = (Ntp + CFEAT_WGPTS - 1) / CFEAT_WGPTS; return y > CFEAT_SLOTS ? CFEAT_SLOTS : y; }
-struct MfmaWs { float* F; unsigned short* H; unsigned int* nmax; int* undecided; int32_t* perm; float* boxes; int Ntp; };
+struct MfmaWs { float* F; unsigned short* H; unsigned int* nmax; int* undecided; int32_t* perm; float* boxes; float* wgsum; int Ntp; };
 
 static MfmaWs mfma_carve(float* F, int B, int Nt, int Nq) {
     MfmaWs w;
@@ -1827,6 +1849,7 @@ static MfmaWs mfma_carve(float* F, int B, int Nt, int Nq) {
     w.undecided = reinterpret_cast<int*>(w.nmax + (size_t)B * CFEAT_SLOTS);
     w.perm = reinterpret_cast<int32_t*>(w.undecided + pad4(B) + 4 * (size_t)B * Nq);
     w.boxes = reinterpret_cast<float*>(w.perm + (size_t)B * w.Ntp);
+    w.wgsum = w.boxes + (size_t)B * (w.Ntp / 32) * CS_BOXF;      // [B][gx] sums of the minima of the scan against this cloud
     return w;
 }
 
@@ -1849,8 +1872,8 @@ static int mfma_both(const float* p1, const float* p2, int B, int N, int M, floa
     {
         const int qpw = prec == 2 ? 32 * CM_WAVES16 : 128;          // queries per workgroup
         const int gx1 = (N + qpw - 1) / qpw, gx2 = (M + qpw - 1) / qpw;
-        const ScanJob s1{p1, w2.F, w2.H, w2.nmax, N, M, w2.Ntp, gx1, gx1 * B, d1, i1};     // p1 against p2
-        const ScanJob s2{p2, w1.F, w1.H, w1.nmax, M, N, w1.Ntp, gx2, gx2 * B, d2, i2};     // p2 against p1
+        const ScanJob s1{p1, w2.F, w2.H, w2.nmax, N, M, w2.Ntp, gx1, gx1 * B, d1, i1, w2.wgsum};     // p1 against p2
+        const ScanJob s2{p2, w1.F, w1.H, w1.nmax, M, N, w1.Ntp, gx2, gx2 * B, d2, i2, w1.wgsum};     // p2 against p1
         const bool long_first = (long long)N > (long long)M;       // direction 2 scans the N targets: more work per workgroup
         const ScanJob& ja = long_first ? s2 : s1;
         const ScanJob& jb = long_first ? s1 : s2;
@@ -1880,6 +1903,23 @@ int chamfer_feat_jobs(void* workspace, size_t workspace_bytes, int B, int N, int
     const MfmaWs w1 = mfma_carve(ws + mfma_ws_floats(B, M, N), B, N, M);
     *job2 = FeatJob{p2, M, w2.Ntp, feat_split(w2.Ntp), w2.F, w2.nmax, w2.H, 1};
     *job1 = FeatJob{p1, N, w1.Ntp, feat_split(w1.Ntp), w1.F, w1.nmax, w1.H, 1};
+    return 0;
+}
+
+// the per-workgroup sums the fp16 scan (modes 6 / 7) leaves in the workspace: sums1 [B][*g1] over dist1 (queries p1),
+// sums2 [B][*g2] over dist2.  Same validity rule as chamfer_feat_jobs.
+int chamfer_wgsums(const void* workspace, size_t workspace_bytes, int B, int N, int M, const float** sums1, int* g1,
+                   const float** sums2, int* g2) {
+    if (!workspace || B <= 0 || N <= 0 || M <= 0 || ((uintptr_t)workspace & 15) != 0) return VPN_E_BADARG;
+    if (workspace_bytes < vpn_chamfer_workspace(B, N, M)) return VPN_E_BADARG;
+    const int forced = chamfer_mode();
+    if (!(forced == 6 || (forced == 0 && (long)N * M >= 512L * 512L))) return VPN_E_BADARG;
+    float* ws = (float*)const_cast<void*>(workspace);
+    const MfmaWs w2 = mfma_carve(ws, B, M, N);
+    const MfmaWs w1 = mfma_carve(ws + mfma_ws_floats(B, M, N), B, N, M);
+    const int qpw = 32 * CM_WAVES16;
+    *sums1 = w2.wgsum; *g1 = (N + qpw - 1) / qpw;
+    *sums2 = w1.wgsum; *g2 = (M + qpw - 1) / qpw;
     return 0;
 }
 

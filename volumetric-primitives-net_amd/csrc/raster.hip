@@ -346,6 +346,75 @@ struct LossArgs {
 
 __device__ inline float sign0(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }   // torch.sign
 
+// Loss finalisation INSIDE the tile kernel of the training step (it used to be a launch of its own: 7-10 us of latency
+// chain): every tile wave publishes its two loss sums and counts itself in on its sample; the wave that arrives last
+// on a sample sums that sample's tiles (fixed order) and its Chamfer term (from the per-workgroup sums the scan left),
+// publishes the per-sample values and counts the sample in; the wave that completes the last sample writes
+//   losses[4] = (silhouette loss, depth loss, w_cd mean_b cd_b + w_sil [0] + w_dep [1], mean_b cd_b).
+// Hand-off form (MI355X guide, inter-workgroup visibility): payload stored write-through (sc1), the storing wave
+// drains (vmcnt(0)), ONE agent-scope add per workgroup, the last adder reads the payload with sc1 loads.
+struct FinArgs {
+    int enabled = 0;
+    int B = 0;
+    int* gcounter = nullptr;            // head of the loss workspace
+    float4* persample = nullptr;        // [B]: (sil sum, depth sum, cd_b, tile counter as int)
+    const float* sums1 = nullptr;       // [B][g1] per-workgroup sums of dist1 (vpn_chamfer_fwd_ws, fp16 filter) or null
+    const float* sums2 = nullptr;       // [B][g2]
+    int g1 = 0, g2 = 0, N = 0, M = 0;
+    float w1 = 0.f, w2 = 0.f, w_cd = 0.f;
+    float* losses = nullptr;            // [4]
+    float* loss_b = nullptr;            // [B] or null
+    unsigned long long* seed_advance = nullptr;   // device step counter of the caller's sampler seed: += 1 when the step is complete
+};
+
+__device__ inline void finalize_sample(const FinArgs& fin, const LossArgs& la, int b, int ntile) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long* tl = reinterpret_cast<const unsigned long long*>(la.tile_loss) + (size_t)b * ntile;
+    float a0 = 0.f, a1 = 0.f;
+    for (int t = lane; t < ntile; t += 64) {
+        const unsigned long long v = __hip_atomic_load(tl + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a0 += __uint_as_float((unsigned)v); a1 += __uint_as_float((unsigned)(v >> 32));
+    }
+    a0 = wave_sum(a0); a1 = wave_sum(a1);
+    float cd = 0.f;
+    if (fin.sums1) {                     // written by an earlier launch on this stream: plain loads
+        float c1 = 0.f, c2 = 0.f;
+        for (int i = lane; i < fin.g1; i += 64) c1 += fin.sums1[(size_t)b * fin.g1 + i];
+        for (int i = lane; i < fin.g2; i += 64) c2 += fin.sums2[(size_t)b * fin.g2 + i];
+        c1 = wave_sum(c1); c2 = wave_sum(c2);
+        cd = fin.w1 * (c1 / (float)fin.N) + fin.w2 * (c2 / (float)fin.M);      // chamfer_distance.py:25-28
+    }
+    int old = 0;
+    if (lane == 0) {
+        if (fin.loss_b) fin.loss_b[b] = cd;
+        float* ps = reinterpret_cast<float*>(fin.persample + b);
+        __hip_atomic_store(ps + 0, a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ps + 1, a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ps + 2, cd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        old = __hip_atomic_fetch_add(fin.gcounter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (__builtin_amdgcn_readfirstlane(old) != fin.B - 1) return;
+    // every sample is complete
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+    for (int i = lane; i < fin.B; i += 64) {
+        float* ps = reinterpret_cast<float*>(fin.persample + i);
+        t0 += __hip_atomic_load(ps + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t1 += __hip_atomic_load(ps + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t2 += __hip_atomic_load(ps + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(reinterpret_cast<int*>(ps + 3), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next call
+    }
+    t0 = wave_sum(t0); t1 = wave_sum(t1); t2 = wave_sum(t2);
+    if (lane == 0) {
+        const float l0 = t0 * la.inv_count, l1 = t1 * la.inv_count, cdm = t2 / (float)fin.B;
+        fin.losses[0] = l0; fin.losses[1] = l1;
+        fin.losses[2] = fin.w_cd * cdm + la.w_sil * l0 + la.w_dep * l1;
+        fin.losses[3] = cdm;
+        __hip_atomic_store(fin.gcounter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (fin.seed_advance) *fin.seed_advance += 1ull;         // the next step draws fresh surface points
+    }
+}
+
 // forward composite of the tile's visible primitives: P = prod(1 - a), S0 = sum w, S1 = sum w z
 __device__ inline unsigned long long tile_forward(const Tile& T, const float4* __restrict__ rec_b, unsigned long long* __restrict__ mrow,
                                     int words, int K, int H, int W, float4* srec, float inv_sigma, float inv_gamma,
@@ -551,7 +620,7 @@ __global__ __launch_bounds__(64, R_TOTAL_WAVES) void raster_total_kernel(const f
                                                            unsigned long long* __restrict__ masks,
                                                            const float* __restrict__ cam, int B, int K, int H, int W,
                                                            int tiles_x, int tiles_y, int words, float sigma, float gamma,
-                                                           float z_far, float* __restrict__ partial, LossArgs la) {
+                                                           float z_far, float* __restrict__ partial, LossArgs la, FinArgs fin) {
     const Tile T = make_tile(H, W, tiles_x, tiles_y, B);
     if (!T.valid) return;
     const int ntile = tiles_x * tiles_y, lane = threadIdx.x & 63;
@@ -604,12 +673,24 @@ __global__ __launch_bounds__(64, R_TOTAL_WAVES) void raster_total_kernel(const f
     }
     lsil = wave_sum(lsil);
     ldep = wave_sum(ldep);
-    if (lane == 0) {
-        la.tile_loss[((size_t)T.b * ntile + T.tile) * 2 + 0] = lsil;
-        la.tile_loss[((size_t)T.b * ntile + T.tile) * 2 + 1] = ldep;
+    int arrived = 0;
+    if (!fin.enabled) {
+        if (lane == 0) {
+            la.tile_loss[((size_t)T.b * ntile + T.tile) * 2 + 0] = lsil;
+            la.tile_loss[((size_t)T.b * ntile + T.tile) * 2 + 1] = ldep;
+        }
+    } else if (lane == 0) {
+        // publish (write-through), drain, count in: the answer is needed only after the backward half below, which
+        // hides the round trip of the add
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(la.tile_loss) + (size_t)T.b * ntile + T.tile,
+                           (unsigned long long)__float_as_uint(lsil) | ((unsigned long long)__float_as_uint(ldep) << 32),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        arrived = __hip_atomic_fetch_add(reinterpret_cast<int*>(fin.persample + T.b) + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     tile_backward(T, rec_b, nullptr, words, K, ntile, H, W, srec, words == 1, m0, inv_sigma, inv_gamma, zref, P, zbar, invS,
                   gAtot, gZbar, partial);
+    if (fin.enabled && __builtin_amdgcn_readfirstlane(arrived) == ntile - 1) finalize_sample(fin, la, T.b, ntile);
 }
 
 // one wave per (b,k): raster_finish_wave (vpn_raster_common.h), then write / accumulate the gradient
@@ -886,7 +967,41 @@ extern "C" int vpn_raster_total_fwd(const float* params, const int32_t* kinds, c
     const Grid G = raster_grid(B, K, H, W);
     LossArgs la{gt_sil, gt_depth, sil_mse, 1.0f / ((float)B * (float)H * (float)W), tile_loss_of(loss_ws, B), nullptr, w_sil, w_dep};
     VPN_LAUNCH(raster_total_kernel, G.g, dim3(64), 0, s, (const float4*)records, masks_of(records, B, K), cam, B, K,
-               H, W, G.tiles_x, G.tiles_y, G.words, sigma, gamma, z_far, (float*)workspace, la);
+               H, W, G.tiles_x, G.tiles_y, G.words, sigma, gamma, z_far, (float*)workspace, la, FinArgs{});
+    VPN_LAUNCH_CHECK();
+    return 0;
+}
+
+namespace vpn { int chamfer_wgsums(const void* workspace, size_t workspace_bytes, int B, int N, int M, const float** sums1, int* g1,
+                                   const float** sums2, int* g2); }
+
+extern "C" int vpn_raster_total_fwd_fin(const float* params, const int32_t* kinds, const float* cam, int B, int K, int H,
+                                        int W, float sigma, float gamma, float z_far, const float* gt_sil,
+                                        const float* gt_depth, int sil_mse, float w_sil, float w_dep, void* records,
+                                        void* loss_ws, void* workspace, int records_ready,
+                                        const void* chamfer_ws, size_t chamfer_ws_bytes, int N, int M, float cd_w1,
+                                        float cd_w2, float w_cd, float* losses, float* loss_b, uint64_t* seed_advance,
+                                        void* stream) {
+    int rc = raster_check(params, kinds, cam, B, K, H, W, sigma, gamma);
+    if (rc) return rc;
+    if (!records || !loss_ws || !workspace || !losses) return VPN_E_BADARG;
+    if (((uintptr_t)records & 15) != 0 || ((uintptr_t)workspace & 15) != 0 || ((uintptr_t)loss_ws & 15) != 0) return VPN_E_BADARG;
+    FinArgs fin;
+    fin.enabled = 1; fin.B = B;
+    fin.gcounter = (int*)loss_ws;
+    fin.persample = reinterpret_cast<float4*>(reinterpret_cast<char*>(loss_ws) + 16);
+    if (chamfer_ws) {
+        if (N <= 0 || M <= 0) return VPN_E_BADARG;
+        if ((rc = vpn::chamfer_wgsums(chamfer_ws, chamfer_ws_bytes, B, N, M, &fin.sums1, &fin.g1, &fin.sums2, &fin.g2))) return rc;
+        fin.N = N; fin.M = M; fin.w1 = cd_w1; fin.w2 = cd_w2; fin.w_cd = w_cd;
+    }
+    fin.losses = losses; fin.loss_b = loss_b; fin.seed_advance = (unsigned long long*)seed_advance;
+    hipStream_t s = (hipStream_t)stream;
+    if (!records_ready && (rc = launch_prep(params, kinds, cam, B, K, H, W, sigma, records, (int*)loss_ws, s))) return rc;
+    const Grid G = raster_grid(B, K, H, W);
+    LossArgs la{gt_sil, gt_depth, sil_mse, 1.0f / ((float)B * (float)H * (float)W), tile_loss_of(loss_ws, B), nullptr, w_sil, w_dep};
+    VPN_LAUNCH(raster_total_kernel, G.g, dim3(64), 0, s, (const float4*)records, masks_of(records, B, K), cam, B, K,
+               H, W, G.tiles_x, G.tiles_y, G.words, sigma, gamma, z_far, (float*)workspace, la, fin);
     VPN_LAUNCH_CHECK();
     return 0;
 }

@@ -105,7 +105,13 @@ __device__ inline void sample_wg(PrimLds& P, float* red, int b, int k,
 #pragma unroll
         for (int i = 0; i < R_REC; ++i) out[i] = r[i];
     }
-    if (rp.zero_me && threadIdx.x >= 128 && threadIdx.x < 132 && k == 0 && b == 0) rp.zero_me[threadIdx.x - 128] = 0;
+    // head of the loss workspace: the arrival counter is zeroed, the Philox seed this step really uses is kept (the
+    // backward reads it from there: the caller's device counter may have advanced by then); per sample: tile counter
+    if (rp.zero_me && k == 0) {
+        if (b == 0 && threadIdx.x >= 128 && threadIdx.x < 130) rp.zero_me[threadIdx.x - 128] = 0;
+        if (b == 0 && threadIdx.x == 130) *reinterpret_cast<uint64_t*>(rp.zero_me + 2) = seed;
+        if (threadIdx.x == 131) rp.zero_me[4 + 4 * b + 3] = 0;
+    }
     __syncthreads();
     const float tx = prm[7], ty = prm[8], tz = prm[9];
     const float* ub = u ? u + ((size_t)b * K + k) * n * 3 : nullptr;
@@ -640,6 +646,7 @@ __global__ __launch_bounds__(256) void raster_prep_kernel(const float* __restric
     if (zero_me && bk < 4) zero_me[bk] = 0;
     if (bk >= BK) return;
     const int b = bk / K, k = bk - b * K;
+    if (zero_me && k == 0) zero_me[4 + 4 * b + 3] = 0;           // the sample's tile counter (fused finalisation)
     float4 r[R_REC];
     make_record(params + (size_t)bk * VPN_PARAM_STRIDE, kinds[k] == VPN_SPHERE ? VPN_SPHERE : VPN_CUBOID, cam, b, H, W, sigma, r);
     float4* out = rec + (size_t)bk * R_REC;

@@ -158,5 +158,8 @@ __device__ inline void feat_slice(const FeatJob& J, int b, int by, float* red) {
 // automatic mode would not take the fp16 filter for these sizes.
 int chamfer_feat_jobs(void* workspace, size_t workspace_bytes, int B, int N, int M, const float* p1, const float* p2,
                       FeatJob* job1, FeatJob* job2);
+// the per-workgroup sums of the minima the fp16 scan leaves in that workspace: sums1 [B][*g1] (dist1), sums2 [B][*g2] (dist2)
+int chamfer_wgsums(const void* workspace, size_t workspace_bytes, int B, int N, int M, const float** sums1, int* g1,
+                   const float** sums2, int* g2);
 
 }  // namespace vpn

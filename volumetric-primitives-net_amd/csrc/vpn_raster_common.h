@@ -174,7 +174,8 @@ __device__ inline float wave_reduce16(float v[16]) {
 struct RasterPrep {       // what a kernel outside raster.hip needs to write the raster records (rec == nullptr: nothing to do)
     const float* cam = nullptr;
     float4* rec = nullptr;
-    int* zero_me = nullptr;            // 4 ints: arrival counter of the loss finalisation
+    int* zero_me = nullptr;            // head of the loss workspace: {arrival counter, spare, effective Philox seed (u64)},
+                                       // then per sample a float4 (sil sum, depth sum, cd, arrival counter of its tiles)
     int H = 0, W = 0;
     float sigma = 0.f;
 };

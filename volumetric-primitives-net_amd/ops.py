@@ -426,11 +426,11 @@ class RasterTotalFunction(Function):
         lws = torch.empty((L.vpn_raster_loss_workspace(B, H, W) // 4,), dtype=torch.float32, device=dev)
         ws = torch.empty((L.vpn_raster_bwd_workspace(B, K, H, W) // 4,), dtype=torch.float32, device=dev)
         losses = torch.empty((4,), dtype=torch.float32, device=dev)
-        _lib.call('vpn_raster_total_fwd', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(cam), B, K, H, W, float(sigma),
+        # render, image losses, gradient partials and the loss finalisation: one launch after the record launch
+        _lib.call('vpn_raster_total_fwd_fin', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(cam), B, K, H, W, float(sigma),
                   float(gamma), float(z_far), _lib.ptr(gt_sil), _lib.ptr(gt_depth), int(bool(sil_mse)), float(w_sil),
-                  float(w_dep), _lib.ptr(rec), _lib.ptr(lws), _lib.ptr(ws), 0, s)
-        _lib.call('vpn_loss_finalize', _lib.ptr(lws), B, H, W, None, None, 0, 0, 0.0, 0.0, 0.0, float(w_sil), float(w_dep),
-                  _lib.ptr(losses), None, s)
+                  float(w_dep), _lib.ptr(rec), _lib.ptr(lws), _lib.ptr(ws), 0, None, 0, 0, 0, 0.0, 0.0, 0.0,
+                  _lib.ptr(losses), None, None, s)
         ctx.save_for_backward(params, cam, rec, ws)
         ctx.meta = (B, K, H, W)
         sil, dep, tot, _ = losses.unbind(0)
@@ -489,7 +489,7 @@ class HotPathLossFunction(Function):
 
     @staticmethod
     def forward(ctx, params, kinds, cam, gt_points, gt_sil, gt_depth, n, seed, sample_base, H, W, sigma, gamma,
-                z_far, w_cd, w_sil, w_depth, cd_w1=1.0, cd_w2=1.0, sil_mse=False):
+                z_far, w_cd, w_sil, w_depth, cd_w1=1.0, cd_w2=1.0, sil_mse=False, advance_seed=False):
         params, cam, gt_points = _f32c(params), _f32c(cam), _f32c(gt_points)
         B, K, _ = params.shape
         M = gt_points.shape[1]
@@ -512,6 +512,9 @@ class HotPathLossFunction(Function):
             _lib.call('vpn_raster_total_fwd', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(cam), B, K, H, W, float(sigma),
                       float(gamma), float(z_far), _lib.ptr(gt_sil), _lib.ptr(gt_depth), sil_mse, float(w_sil),
                       float(w_depth), _lib.ptr(rec), _lib.ptr(lws), _lib.ptr(rws), records_ready, stream)
+
+        if advance_seed and seed_dev is None:
+            raise ValueError('advance_seed needs a device seed (a CUDA int64 tensor of one element)')
 
         main = torch.cuda.current_stream()
         # optionally the raster branch (independent of the sampler + Chamfer branch until the finalisation) runs on a
@@ -543,17 +546,33 @@ class HotPathLossFunction(Function):
         i2 = torch.empty((B, M), dtype=torch.int32, device=dev)
         _lib.call('vpn_chamfer_fwd_ws', _lib.ptr(points), _lib.ptr(gt_points), B, N, M, _lib.ptr(d1), _lib.ptr(i1),
                   _lib.ptr(d2), _lib.ptr(i2), _lib.ptr(cws), cws.numel() * 4, chamfer_mode, s)
-        if side is not None:
-            main.wait_stream(side)
+        fused_fin = side is None and chamfer_mode == 7
+        if fused_fin:
+            # raster forward+backward pass and the loss finalisation (image losses, per-sample Chamfer terms from the
+            # scan's per-workgroup sums, total, optional advance of the step counter) in ONE launch
+            _lib.call('vpn_raster_total_fwd_fin', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(cam), B, K, H, W, float(sigma),
+                      float(gamma), float(z_far), _lib.ptr(gt_sil), _lib.ptr(gt_depth), sil_mse, float(w_sil),
+                      float(w_depth), _lib.ptr(rec), _lib.ptr(lws), _lib.ptr(rws), 1, _lib.ptr(cws), cws.numel() * 4, N, M,
+                      cd_w1, cd_w2, float(w_cd), _lib.ptr(losses), None, seed_dev if advance_seed else None, s)
         else:
-            raster_branch(s, 1)
-        _lib.call('vpn_loss_finalize', _lib.ptr(lws), B, H, W, _lib.ptr(d1), _lib.ptr(d2), N, M, cd_w1, cd_w2, float(w_cd),
-                  float(w_sil), float(w_depth), _lib.ptr(losses), None, s)
+            if side is not None:
+                main.wait_stream(side)
+            else:
+                raster_branch(s, 1)
+            _lib.call('vpn_loss_finalize', _lib.ptr(lws), B, H, W, _lib.ptr(d1), _lib.ptr(d2), N, M, cd_w1, cd_w2, float(w_cd),
+                      float(w_sil), float(w_depth), _lib.ptr(losses), None, s)
+            if advance_seed:
+                seed.add_(1)
         pattern = _grad_pattern(B, w_cd, dev)
         empty = torch.empty(0, device=dev)
         seed_t = seed if isinstance(seed, torch.Tensor) else empty
-        ctx.save_for_backward(params, kinds, cam, gt_points, points, d1, i1, d2, i2, rec, rws, pattern, seed_t)
-        ctx.meta = (B, K, n, M, H, W, seed_host, seed_dev is not None, int(sample_base), cd_w1, cd_w2, float(w_cd) / B)
+        # the sampler's launch of the one-stream path keeps the seed it used at loss_ws + 8: backward reads it from there,
+        # whatever has happened to the caller's counter since
+        seed_saved = side is None and seed_dev is not None
+        ctx.save_for_backward(params, kinds, cam, gt_points, points, d1, i1, d2, i2, rec, rws, pattern,
+                              lws if seed_saved else seed_t)
+        ctx.meta = (B, K, n, M, H, W, 0 if seed_saved else seed_host, seed_dev is not None, int(sample_base), cd_w1, cd_w2,
+                    float(w_cd) / B, seed_saved)
         sil, dep, tot, _ = losses.unbind(0)
         ctx.mark_non_differentiable(sil, dep)
         ctx.set_materialize_grads(False)       # no zero-filled gradients for the two reported (non-differentiable) values
@@ -562,12 +581,16 @@ class HotPathLossFunction(Function):
     @staticmethod
     def backward(ctx, _g_sil, _g_dep, grad_total):
         (params, kinds, cam, gt_points, points, d1, i1, d2, i2, rec, rws, pattern, seed_t) = ctx.saved_tensors
-        B, K, n, M, H, W, seed, has_seed_dev, base, cd_w1, cd_w2, w_cd_over_b = ctx.meta
+        B, K, n, M, H, W, seed, has_seed_dev, base, cd_w1, cd_w2, w_cd_over_b, seed_saved = ctx.meta
         N = K * n
         s = _lib.stream()
-        seed_dev = _lib.ptr(seed_t) if has_seed_dev else None
+        seed_dev = None
+        if seed_saved:                                          # seed_t is the loss workspace: effective seed at byte 8
+            seed_dev = ctypes.c_void_p(seed_t.data_ptr() + 8)
+        elif has_seed_dev:
+            seed_dev = _lib.ptr(seed_t)
         if grad_total is None:                                  # the total was not used (set_materialize_grads(False))
-            return (None,) * 20
+            return (None,) * 21
         grad_total = _f32c(grad_total).reshape(1)
         # Chamfer backward and sampler backward in one launch: the [B,N,3] point gradient never exists
         grad_params = torch.empty_like(params)
@@ -578,7 +601,7 @@ class HotPathLossFunction(Function):
                       _lib.ptr(points), _lib.ptr(gt_points), M, _lib.ptr(d1), _lib.ptr(i1), _lib.ptr(d2), _lib.ptr(i2),
                       None, cd_w1 * w_cd_over_b, cd_w2 * w_cd_over_b, _lib.ptr(cam), H, W, _lib.ptr(rec), _lib.ptr(rws),
                       _lib.ptr(grad_total), _lib.ptr(grad_params), s)
-            return (grad_params,) + (None,) * 19
+            return (grad_params,) + (None,) * 20
         else:                                                   # GT clouds beyond the fused kernel's LDS match lists
             gvec = pattern * grad_total                         # d total / d loss_b [B]
             grad_points = torch.empty_like(points)
@@ -589,4 +612,4 @@ class HotPathLossFunction(Function):
         # the raster's gradient partials were produced by the forward launch: chain rule x upstream gradient, added
         _lib.call('vpn_raster_total_bwd', _lib.ptr(params), _lib.ptr(cam), B, K, H, W, _lib.ptr(rec), _lib.ptr(rws),
                   _lib.ptr(grad_total), _lib.ptr(grad_params), 1, s)
-        return (grad_params,) + (None,) * 19
+        return (grad_params,) + (None,) * 20
