@@ -1050,6 +1050,74 @@ def test_hot_path_device_seed_and_side_stream(vpn):
         vpn.kinds_tensor(torch.tensor([0, 3], dtype=torch.int32, device=DEV), torch.device(DEV))
 
 
+def test_hot_path_config3_full(vpn):
+    """The single-node step exactly as bench.py runs it: BASELINE config C3 (B=64, K=32 spheres x 256 points = 8192
+    points vs 2048 GT points, 256x256, Chamfer + L1 silhouette + L1 depth) through HotPathLossFunction -- sampler launch
+    with the Chamfer features (mode 7), filtered scan with its in-launch fix-up and per-workgroup sums, raster with the
+    finalisation inside, fused backward.  Gradient rows of samples 0, 31, 63 against the fp32 / fp64 oracle run on those
+    images alone (the step is per-sample: row b of the gradient depends on sample b only, times 1/B); the loss against
+    the independently tested module pieces; the C4 per-rank shards B=32 and B=128 against the B=64 rows bit for bit."""
+    from vpn_amd import _lib
+    gen = torch.Generator().manual_seed(1234)
+    B, K, n, M, H, W = 64, 32, 256, 2048, 256, 256
+    assert _lib.lib().vpn_hotpath_fused_features(B, K, n, M) == 1       # the path under test is the fused one
+    params = rand_params(gen, 128, K)                                   # 128 samples: B=64 uses the first 64
+    kinds = [0] * K
+    gt_pts = torch.rand(128, M, 3, generator=gen) - 0.5
+    gt_sil = (torch.rand(128, 1, H, W, generator=gen) > 0.5).float()
+    gt_dep = 2.0 - torch.rand(128, H, W, generator=gen)
+    cam = torch.tensor([[1.0, 0.0, 0.0]]).expand(128, 3).contiguous()
+    rows = [0, 31, 63]
+    for b in rows:
+        gt_dep[b:b + 1] = decidable_depth_gt(O, params[b:b + 1], kinds, cam[b:b + 1], gt_dep[b:b + 1], H, W, chunk=1)
+    seed = 4242
+    kt = vpn.kinds_tensor(kinds, torch.device(DEV))
+    dev = {k: g(v) for k, v in dict(params=params, gt_pts=gt_pts, gt_sil=gt_sil, gt_dep=gt_dep, cam=cam).items()}
+
+    def step(nb, w_sil, w_dep):
+        p = dev['params'][:nb].clone().requires_grad_(True)
+        out = vpn.HotPathLossFunction.apply(p, kt, dev['cam'][:nb].contiguous(), dev['gt_pts'][:nb].contiguous(),
+                                            dev['gt_sil'][:nb].contiguous(), dev['gt_dep'][:nb].contiguous(), n, seed, 0, H, W,
+                                            0.05, 0.1, 2.0, 1.0, w_sil, w_dep)
+        out[2].backward()
+        return [o.detach() for o in out], p.grad
+    (sil, dep, tot), grad = step(B, 1.0, 1.0)
+    # --- gradient rows against the oracle
+    for b in rows:
+        ref = {}
+        for dt in (torch.float32, torch.float64):
+            u = O.philox_uniforms(seed, b, 1, K, n).to(dt)
+            pc = params[b:b + 1].to(dt).clone().requires_grad_(True)
+            pts = O.sample_primitives(pc, kinds, u)
+            a, d = O.raster(pc, kinds, cam[b:b + 1].to(dt), H, W, 0.05, 0.1, 2.0)
+            lb = (O.chamfer_loss(pts, gt_pts[b:b + 1].to(dt)) / B + (a[:, None] - gt_sil[b:b + 1].to(dt)).abs().sum() / (B * H * W)
+                  + (d - gt_dep[b:b + 1].to(dt)).abs().sum() / (B * H * W))
+            lb.backward()
+            ref[dt] = pc.grad[0]
+        e_cpu = rel_err(ref[torch.float32], ref[torch.float64])
+        got = grad[b].cpu()
+        assert rel_err(got, ref[torch.float64]) <= RTOL, (b, rel_err(got, ref[torch.float64]), e_cpu)
+        assert rel_err(got, ref[torch.float32]) <= RTOL + e_cpu, (b, rel_err(got, ref[torch.float32]), e_cpu)
+    # --- the three losses against the module pieces (brute-force Chamfer scan, two-call raster losses)
+    pts = vpn.Sampling.sample_primitives(dev['params'][:B], kt, n, seed=seed)
+    d1, i1, d2, i2 = vpn.chamfer_nn(pts, dev['gt_pts'][:B], mode='brute')
+    cd = (d1.double().mean(1) + d2.double().mean(1)).mean()
+    img = vpn.RasterLossFunction.apply(dev['params'][:B], kt, dev['cam'][:B].contiguous(), dev['gt_sil'][:B].contiguous(),
+                                       dev['gt_dep'][:B].contiguous(), H, W, 0.05, 0.1, 2.0, False)
+    assert rel_err(torch.stack([sil, dep]).cpu(), img.cpu()) <= 1e-5
+    assert abs(float(tot) - float(cd + img.double().sum())) / float(tot) <= 1e-5
+    # bitwise reproducible
+    (_, _, tot_b), grad_b = step(B, 1.0, 1.0)
+    assert torch.equal(tot_b, tot) and torch.equal(grad_b, grad)
+    # --- C4 shards: Chamfer term of B=32 and B=128 against the B=64 rows, bit for bit (the 1/B of the batch mean is a
+    # power of two: exact scaling).  The image weights are zero, the raster still runs.
+    (_, _, t64), g64 = step(64, 0.0, 0.0)
+    (_, _, t32), g32 = step(32, 0.0, 0.0)
+    (_, _, t128), g128 = step(128, 0.0, 0.0)
+    assert torch.equal(g32 * 0.5, g64[:32]) and torch.equal(g128[:64] * 2.0, g64)
+    assert bool(torch.isfinite(g128).all()) and float(t32) > 0 and float(t128) > 0
+
+
 def test_raster_escape_report():
     """Runs last in this file: how often the fp64 clause of _raster_case was needed (it must stay rare, and only
     where the fp32 oracle itself is noisy)."""
