@@ -284,6 +284,31 @@ int vpn_mesh_bwd(const float* params, const int32_t* kinds, const int32_t* offse
                  const float* tpl_sphere, const float* tpl_cuboid, int B, int K, int Ptot,
                  const float* grad_verts, float* grad_params, void* stream);
 
+/* ---- the triangle-mesh path: meshes that carry NO primitives (train_sphere.py:53-76,128: the 386-vertex sphere of
+ * 386.obj deformed in place, sampled by kaolin's TriangleMesh.sample and rendered by VertexRenderer.render /
+ * SilhouetteLoss.forward through kaolin's DIBRenderer, vertex_renderer.py:20-24).  kaolin is absent: the arithmetic is
+ * this repository's specification (oracle.vpn_oracle.mesh_raster / mesh_sample), parity unpinned.
+ * verts [B,P,3] fp32 (B meshes of one topology), faces [F,3] int32 (vertex indices, clamped to [0,P) on the device),
+ * cam [B,3] = (dist, elev deg, azim deg) as vpn_raster_fwd.
+ * vpn_mesh_raster_fwd: alpha [B,H,W] = 1 - prod_f (1 - sigmoid(+-d2_f / sigma)), d2_f = squared NDC distance of the
+ *   pixel centre to the nearest edge of face f, + inside / - outside; workspace = vpn_mesh_raster_workspace(B, P) bytes
+ *   (projected vertices, kept for the backward call).
+ * vpn_mesh_raster_bwd: grad_verts [B,P,3] = d (sum grad_alpha . alpha) / d verts (same workspace as the forward call).
+ * vpn_mesh_sample_fwd: n area-weighted uniform surface points per mesh: points [B,n,3], face_idx [B,n], bary [B,n,3]
+ *   (the barycentric weights, for the backward); u [B,n,3] explicit uniforms or NULL = Philox(seed; mesh_base + b,
+ *   slot 0xFFFFFFFF, point); cdf [B,F] scratch (cumulative face areas).
+ * vpn_mesh_sample_bwd: grad_verts [B,P,3] = sum_i bary_i * grad_points_i (the face choice is not differentiated). */
+size_t vpn_mesh_raster_workspace(int B, int P);
+int vpn_mesh_raster_fwd(const float* verts, const int32_t* faces, const float* cam, int B, int P, int F, int H, int W,
+                        float sigma, void* workspace, float* alpha, void* stream);
+int vpn_mesh_raster_bwd(const float* verts, const int32_t* faces, const float* cam, int B, int P, int F, int H, int W,
+                        float sigma, void* workspace, const float* alpha, const float* grad_alpha, float* grad_verts,
+                        void* stream);
+int vpn_mesh_sample_fwd(const float* verts, const int32_t* faces, const float* u, uint64_t seed, uint64_t mesh_base,
+                        int B, int P, int F, int n, float* cdf, float* points, int32_t* face_idx, float* bary, void* stream);
+int vpn_mesh_sample_bwd(const int32_t* faces, const int32_t* face_idx, const float* bary, const float* grad_points,
+                        int B, int P, int F, int n, float* grad_verts, void* stream);
+
 /* ---- head post-processing into packed primitive parameters (row f4)
  * restrict_range + split + restrict_volumes of the reference's model (modules/network/vpnet_one_resnet.py:34-41,
  * :67-85): volumes [B,3K], rotates [B,4K], translates [B,3K] (raw head outputs) -> params [B,K,10].

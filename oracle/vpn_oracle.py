@@ -419,6 +419,108 @@ def raster(params, types, cam, H, W, sigma=0.05, gamma=0.1, z_far=2.0):
     return alpha, depth
 
 
+# ----------------------------------------------------------------------------------------------------------------
+# Triangle-mesh path: a mesh that carries no primitives (train_sphere.py:53-76,128: 386.obj deformed in place,
+# sampled with kaolin's TriangleMesh.sample and rasterised by kaolin's DIBRenderer through vertex_renderer.py:20-24).
+# kaolin is absent, so neither function below has reference outputs: PARITY UNPINNED, the call-site contract
+# (shapes, camera convention, "alpha is a soft silhouette of the union of the triangles", "samples are uniform on the
+# surface") is what they restate; the HIP kernels are held to these functions.
+MESH_NEAR = 1e-3          # faces with a vertex closer than this to the camera plane are not drawn
+
+
+def mesh_project(verts, cam):
+    """verts (B,P,3), cam (B,3) -> (B,P,3): x, y in NDC (y in [-1,1] over the image height, x in [-W/H, W/H]; +x to
+    the right, +y up: the pixel grid of `pixel_grid` divided by tan(fov/2)) and z = depth along the optical axis."""
+    dt = verts.dtype
+    eye, right, up, fwd = camera_basis(cam, dt)
+    rel = verts - eye[:, None, :]
+    xc = (rel * right[:, None, :]).sum(-1)
+    yc = (rel * up[:, None, :]).sum(-1)
+    zc = (rel * fwd[:, None, :]).sum(-1)
+    th = math.tan(0.5 * FOVY_DEG * math.pi / 180)
+    zs = torch.where(zc > MESH_NEAR, zc, torch.ones_like(zc))          # not drawn anyway: keeps the division finite
+    return torch.stack([xc / (zs * th), yc / (zs * th), zc], -1)
+
+
+def mesh_raster(verts, faces, cam, H, W, sigma=1e-4):
+    """Soft silhouette of a triangle mesh: alpha (B,H,W).
+    Per pixel centre p (NDC) and face f with projected corners (a, b, c):
+        d2_f = min over the three edges of the squared distance from p to the SEGMENT;
+        s_f = +1 if p lies inside the triangle (either winding: no back-face culling, as a silhouette has none) else -1;
+        a_f = sigmoid(s_f * d2_f / sigma);      alpha = 1 - prod_f (1 - a_f)
+    (the probabilistic union of SoftRas / DIB-R's soft alpha: the 0.5 contour of a_f is the triangle's outline;
+    sigma in NDC^2: 1e-4 is about one pixel of softness at 128 x 128).  Faces with a vertex at depth <= MESH_NEAR are
+    skipped.  Differentiable w.r.t. verts; vectorised over pixels x faces, so small cases only."""
+    dt = verts.dtype
+    B = verts.shape[0]
+    pr = mesh_project(verts, cam)                                        # (B,P,3)
+    th = math.tan(0.5 * FOVY_DEG * math.pi / 180)
+    px, py = pixel_grid(H, W, dt)
+    gx = (px / th)[None, :].expand(H, W).reshape(-1)                      # (HW,)
+    gy = (py / th)[:, None].expand(H, W).reshape(-1)
+    tri = pr[:, faces.long(), :]                                         # (B,F,3,3)
+    ok = (tri[..., 2] > MESH_NEAR).all(-1)                               # (B,F)
+    ax, ay = tri[:, :, 0, 0], tri[:, :, 0, 1]
+    bx, by = tri[:, :, 1, 0], tri[:, :, 1, 1]
+    cx, cy = tri[:, :, 2, 0], tri[:, :, 2, 1]
+
+    def seg_d2(x0, y0, x1, y1):                                          # -> (B,F,HW)
+        ex, ey = (x1 - x0)[..., None], (y1 - y0)[..., None]
+        wx, wy = gx[None, None, :] - x0[..., None], gy[None, None, :] - y0[..., None]
+        t = ((wx * ex + wy * ey) / (ex * ex + ey * ey).clamp_min(1e-20)).clamp(0.0, 1.0)
+        qx, qy = wx - t * ex, wy - t * ey
+        return qx * qx + qy * qy
+
+    def edge(x0, y0, x1, y1):                                            # 2D cross (b - a) x (p - a)
+        return (x1 - x0)[..., None] * (gy[None, None, :] - y0[..., None]) - (y1 - y0)[..., None] * (gx[None, None, :] - x0[..., None])
+    d2 = torch.minimum(torch.minimum(seg_d2(ax, ay, bx, by), seg_d2(bx, by, cx, cy)), seg_d2(cx, cy, ax, ay))
+    e0, e1, e2 = edge(ax, ay, bx, by), edge(bx, by, cx, cy), edge(cx, cy, ax, ay)
+    inside = ((e0 >= 0) & (e1 >= 0) & (e2 >= 0)) | ((e0 <= 0) & (e1 <= 0) & (e2 <= 0))
+    logit = torch.where(inside, d2, -d2) / sigma
+    a = torch.sigmoid(logit.clamp(-80.0, 80.0))
+    a = torch.where(ok[..., None], a, torch.zeros_like(a))
+    alpha = 1.0 - torch.prod(1.0 - a, dim=1)
+    return alpha.reshape(B, H, W)
+
+
+def mesh_face_normals(verts, faces):
+    """Unit face normals (B,F,3): the third output of vertex_renderer.py:24 (DIBRenderer returns face normals)."""
+    tri = verts[:, faces.long(), :]
+    n = torch.cross(tri[:, :, 1] - tri[:, :, 0], tri[:, :, 2] - tri[:, :, 0], dim=-1)
+    return n / n.norm(dim=-1, keepdim=True).clamp_min(1e-20)
+
+
+def mesh_sample(verts, faces, u):
+    """Area-weighted uniform samples on a triangle mesh (what train_sphere.py:76 asks of kaolin's TriangleMesh.sample):
+    verts (P,3), faces (F,3), u (n,3) uniforms in [0,1) -> points (n,3), face index (n,).
+    Face from u[:,0] through the cumulative face areas (fp32 inclusive prefix sums in face order, the face is the first
+    one whose cumulative area exceeds u0 * total); barycentric point from (u1, u2) with the square-root map
+    p = (1 - r) a + r (1 - u2) b + r u2 c, r = sqrt(u1), which is uniform over the triangle.  The face choice is not
+    differentiated (the areas enter through a discrete choice); the points are linear in the vertices."""
+    f = faces.long()
+    a, b, c = verts[f[:, 0]], verts[f[:, 1]], verts[f[:, 2]]
+    area = 0.5 * torch.cross(b - a, c - a, dim=1).norm(dim=1).detach().float()
+    cdf = torch.cumsum(area, 0)
+    target = u[:, 0].float() * cdf[-1]
+    idx = torch.searchsorted(cdf, target, right=True).clamp_max(f.shape[0] - 1)
+    r = torch.sqrt(u[:, 1]).to(verts.dtype)
+    w0, w1, w2 = 1.0 - r, r * (1.0 - u[:, 2].to(verts.dtype)), r * u[:, 2].to(verts.dtype)
+    pts = w0[:, None] * a[idx] + w1[:, None] * b[idx] + w2[:, None] * c[idx]
+    return pts, idx
+
+
+def philox_uniforms_mesh(seed, mesh_index, n):
+    """The draws of vpn_mesh_sample for one mesh: point i uses counter (i, 0xFFFFFFFF, mesh_index) of the same
+    Philox4x32-10 stream as the primitive sampler (primitive slot 0xFFFFFFFF is never a primitive)."""
+    import numpy as np
+    i = np.arange(n, dtype=np.uint32)
+    ctr = np.stack([i, np.full(n, 0xFFFFFFFF, np.uint32), np.full(n, mesh_index & 0xFFFFFFFF, np.uint32),
+                    np.full(n, (mesh_index >> 32) & 0xFFFFFFFF, np.uint32)], 1)
+    key = np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], np.uint32)
+    out = philox4x32_10(ctr, key)
+    return torch.from_numpy(((out[:, :3] >> 8).astype(np.float32) * np.float32(2.0 ** -24)))
+
+
 def silhouette_loss(alpha, gt_silhouettes, func='L1'):
     """SilhouetteLoss.forward (modules/loss/silhouette.py:13-23): L1Loss / MSELoss
     (mean) between the predicted alpha (B,1,H,W) and the GT silhouette."""

@@ -154,6 +154,32 @@ def test_emd_gradient(emd):
 
 
 @pytest.mark.gpu
+def test_emd_backward_with_unassigned_points():
+    """vpn_emd_bwd through the C ABI with assignment = -1 (what a forward whose group barrier gave up leaves, next
+    to a NaN distance): the gradient of such a point is NaN and nothing is read through the index -- not the 12 bytes
+    in front of xyz2 (sample 0) nor the previous sample's last point."""
+    import vpn_amd
+    from vpn_amd import _lib
+    B, n = 2, 64
+    x1, x2 = _clouds(B, n, 3)
+    a, b = x1.to(DEV), x2.to(DEV)
+    assign = torch.arange(n, dtype=torch.int32, device=DEV).repeat(B, 1).contiguous()
+    assign[0, 0] = -1
+    assign[1, 5] = -1
+    assign[1, 6] = n + 3                       # out of range the other way
+    gd = torch.ones(B, n, device=DEV)
+    g1 = torch.zeros(B, n, 3, device=DEV)
+    _lib.call('vpn_emd_bwd', _lib.ptr(a), _lib.ptr(b), _lib.ptr(gd), _lib.ptr(assign), B, n, _lib.ptr(g1), _lib.stream())
+    torch.cuda.synchronize()
+    g1 = g1.cpu()
+    bad = torch.zeros(B, n, dtype=torch.bool)
+    bad[0, 0] = bad[1, 5] = bad[1, 6] = True
+    assert bool(torch.isnan(g1[bad]).all()) and bool(torch.isfinite(g1[~bad]).all())
+    ref = 2.0 * (x1 - x2)                       # identity assignment elsewhere
+    assert torch.equal(g1[~bad], ref[~bad])
+
+
+@pytest.mark.gpu
 def test_emd_reference_selfcheck_at_full_size(emd):
     """test_emd (emd_module.py:81-95) at its own point count: the distance is the one the assignment implies,
     nearly every target is used, and a long auction completes to within n*eps of ... itself rerun (determinism)."""

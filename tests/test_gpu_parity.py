@@ -193,7 +193,13 @@ def test_fused_chamfer_sampler_backward(vpn):
     from vpn_amd import _lib
     gen = torch.Generator().manual_seed(77)
     B, K, n, M = 3, 5, 96, 333
-    params = g(rand_params(gen, B, K))
+    params = rand_params(gen, B, K)
+    # thin primitives (extents 1e-6 .. 1e-4 against translations ~0.3, as in fixture g2's extreme aspect ratio): the
+    # canonical coefficient cannot be recovered from the stored point there, the kernel must redraw it
+    params[0, 0, 0] = 1e-6
+    params[1, 3, 1] = 3e-5
+    params[2, 2, 2] = 1e-4
+    params = g(params)
     kinds = vpn.kinds_tensor([1, 1, 0, 0, 0], torch.device(DEV))
     gt = g(torch.rand(B, M, 3, generator=gen) - 0.5)
     gl = g(torch.rand(B, generator=gen) + 0.5)

@@ -1,0 +1,285 @@
+"""The triangle-mesh path: meshes that carry no primitives (train_sphere.py:53-76,119-128 -- 386.obj deformed in place,
+`mesh.sample(n)`, SilhouetteLoss on the deformed meshes).  The reference's arithmetic for both operations lives in
+kaolin (TriangleMesh.sample, DIBRenderer), which is absent: PARITY UNPINNED.  The HIP kernels are held to the
+repository's own specification (oracle.vpn_oracle.mesh_raster / mesh_sample), which is checked for what the call sites
+rely on: a soft silhouette of the union of the triangles under the camera of the primitive raster, and uniform,
+area-weighted surface samples."""
+import math
+
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import vpn_oracle as O
+
+DEV = 'cuda'
+
+
+def icosphere(sub=1, radius=0.3):
+    t = (1.0 + 5 ** 0.5) / 2
+    v = torch.tensor([[-1, t, 0], [1, t, 0], [-1, -t, 0], [1, -t, 0], [0, -1, t], [0, 1, t], [0, -1, -t], [0, 1, -t],
+                      [t, 0, -1], [t, 0, 1], [-t, 0, -1], [-t, 0, 1]], dtype=torch.float32)
+    f = [[0, 11, 5], [0, 5, 1], [0, 1, 7], [0, 7, 10], [0, 10, 11], [1, 5, 9], [5, 11, 4], [11, 10, 2], [10, 7, 6], [7, 1, 8],
+         [3, 9, 4], [3, 4, 2], [3, 2, 6], [3, 6, 8], [3, 8, 9], [4, 9, 5], [2, 4, 11], [6, 2, 10], [8, 6, 7], [9, 8, 1]]
+    v = v / v.norm(dim=1, keepdim=True)
+    for _ in range(sub):
+        vs, cache, nf = v.tolist(), {}, []
+
+        def mid(a, b):
+            k = (min(a, b), max(a, b))
+            if k not in cache:
+                m = torch.tensor(vs[a]) + torch.tensor(vs[b])
+                vs.append((m / m.norm()).tolist())
+                cache[k] = len(vs) - 1
+            return cache[k]
+        for a, b, c in f:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            nf += [[a, ab, ca], [b, bc, ab], [c, ca, bc], [ab, bc, ca]]
+        v, f = torch.tensor(vs), nf
+    return v * radius, torch.tensor(f, dtype=torch.int64)
+
+
+# ------------------------------------------------------------------------------------------------ oracle (CPU)
+def test_oracle_mesh_raster_is_a_silhouette_and_differentiable():
+    v, f = icosphere(1, 0.3)
+    cam = torch.tensor([[1.0, 0.0, 0.0]])
+    H = W = 48
+    a = O.mesh_raster(v[None], f, cam, H, W, 1e-4)
+    # a sphere of radius r at distance d: silhouette radius in NDC = tan(asin(r/d)) / tan(fov/2)
+    th = math.tan(0.5 * O.FOVY_DEG * math.pi / 180)
+    rn = math.tan(math.asin(0.3 / 1.0)) / th
+    px, py = O.pixel_grid(H, W)
+    rr = ((px / th)[None, :] ** 2 + (py / th)[:, None] ** 2).sqrt()
+    inside, outside = rr < 0.9 * rn * 0.93, rr > 1.1 * rn            # 0.93: an icosphere is inscribed in its sphere
+    assert bool((a[0][inside] > 0.5).all()) and bool((a[0][outside] < 0.5).all())
+    assert float(a.min()) >= 0.0 and float(a.max()) <= 1.0
+    # moving the mesh to the right moves the silhouette to the right (camera convention of the primitive raster:
+    # for dist=1, elev=azim=0 image-x is -z, gcn.py:152-153)
+    a2 = O.mesh_raster((v + torch.tensor([0.0, 0.0, -0.1]))[None], f, cam, H, W, 1e-4)
+    cx = lambda im: float((im * torch.arange(W)[None, :]).sum() / im.sum())
+    assert cx(a2[0]) > cx(a[0]) + 1.0
+    vd = (v[None] * 1.0).double().requires_grad_(True)
+    assert torch.autograd.gradcheck(lambda x: O.mesh_raster(x, f, cam.double(), 12, 16, 1e-2).sum(), (vd,), eps=1e-7, atol=1e-5,
+                                    rtol=1e-3)
+
+
+def test_oracle_mesh_sample_is_uniform_on_the_surface():
+    v, f = icosphere(0, 1.0)
+    v = v * torch.tensor([1.0, 0.3, 2.0])                              # unequal face areas
+    n = 20000
+    u = O.philox_uniforms_mesh(7, 3, n)
+    pts, idx = O.mesh_sample(v, f, u)
+    a, b, c = v[f[:, 0]], v[f[:, 1]], v[f[:, 2]]
+    area = 0.5 * torch.cross(b - a, c - a, dim=1).norm(dim=1)
+    share = torch.bincount(idx, minlength=f.shape[0]).float() / n
+    assert float((share - area / area.sum()).abs().max()) < 0.012      # ~4 sigma of a binomial share at n = 20000
+    # every point lies in the plane and inside its triangle
+    nrm = torch.cross(b - a, c - a, dim=1)[idx]
+    assert float(((pts - a[idx]) * nrm).sum(1).abs().max()) < 1e-5
+    # barycentric mean of a uniform distribution is the centroid
+    cen = ((a + b + c) / 3)[idx]
+    assert float((pts - cen).mean(0).abs().max()) < 0.02
+    assert float(u.min()) >= 0.0 and float(u.max()) < 1.0
+
+
+def test_stale_primitives_are_not_trusted():
+    """A Meshing-made mesh renders from its primitives only while its vertices are the ones Meshing wrote: the in-place
+    edit of train_sphere.py:66 (and a rebound tensor) makes it a plain triangle mesh (host logic, no GPU needed)."""
+    from vpn_amd.modules.meshing import TriangleMesh
+    from vpn_amd.primitives import PrimitivePack, mesh_batches
+    v, f = icosphere(0)
+
+    class FakePack(PrimitivePack):
+        def __init__(self):
+            pass
+    m = TriangleMesh(v.clone(), f, FakePack())
+    assert m.primitives is not None and PrimitivePack.of(m) is m.primitives
+    m.vertices += 0.01                                                # train_sphere.py:66
+    assert m.primitives is None
+    with pytest.raises(TypeError):
+        PrimitivePack.of(m)
+    m2 = TriangleMesh(v.clone(), f, FakePack())
+    m2.vertices = m2.vertices + 0.01                                  # rebound
+    assert m2.primitives is None
+    groups = mesh_batches([m, m2, TriangleMesh(v[:6].clone(), f[:2])])
+    assert [g for g, _, _ in groups] == [[0, 1], [2]] and groups[0][1].shape == (2, 12, 3)
+    with pytest.raises(TypeError):
+        mesh_batches([object()])
+
+
+# ------------------------------------------------------------------------------------------------ HIP kernels
+@pytest.fixture(scope='module')
+def vpn():
+    if not torch.cuda.is_available():
+        pytest.fail('-m gpu tests need a GPU (no CPU fallback exists)')
+    import vpn_amd
+    vpn_amd._lib.lib()
+    return vpn_amd
+
+
+def _random_mesh(gen, P, F, scale=0.25):
+    return (torch.rand(P, 3, generator=gen) - 0.5) * 2 * scale, torch.randint(0, P, (F, 3), generator=gen)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,P,F,H,W,sigma,camrow', [
+    (2, 12, 20, 32, 32, 1e-3, (1.0, 0.0, 0.0)),
+    (3, 50, 130, 40, 56, 3e-4, (1.2, 20.0, 140.0)),          # more than 64 faces: two passes; ragged image
+    (1, 386, 768, 64, 64, 1e-4, (1.0, 0.0, 0.0)),            # train_sphere.py's sizes (BASELINE config C1: 64 x 64)
+])
+def test_mesh_raster_vs_oracle(vpn, B, P, F, H, W, sigma, camrow):
+    from vpn_amd.ops import MeshRasterFunction, faces_i32
+    gen = torch.Generator().manual_seed(P + F)
+    if P == 386:
+        v, f = icosphere(2, 0.3)                                       # 162 vertices, 320 faces: a closed surface
+        v, f = v[None].repeat(B, 1, 1) + 0.02 * torch.randn(B, v.shape[0], 3, generator=gen), f
+    else:
+        vf = [_random_mesh(gen, P, F) for _ in range(B)]
+        v, f = torch.stack([x[0] for x in vf]), vf[0][1]
+    cam = torch.tensor([camrow]).expand(B, 3).contiguous()
+    Wt = torch.randn(B, H, W, generator=gen)
+    ref = {}
+    for dt in (torch.float32, torch.float64):
+        vc = v.to(dt).clone().requires_grad_(True)
+        a = O.mesh_raster(vc, f, cam.to(dt), H, W, sigma)
+        (a * Wt.to(dt)).sum().backward()
+        ref[dt] = (a.detach(), vc.grad)
+    vg = v.to(DEV).requires_grad_(True)
+    a = MeshRasterFunction.apply(vg, faces_i32(f, torch.device(DEV)), cam.to(DEV), H, W, sigma)
+    (a * Wt.to(DEV)).sum().backward()
+    assert float((a.detach().cpu() - ref[torch.float64][0]).abs().max()) <= 2e-5          # alpha is in [0,1]
+    e_cpu = rel_err(ref[torch.float32][1], ref[torch.float64][1])
+    e_gpu = rel_err(vg.grad.cpu(), ref[torch.float64][1])
+    assert e_gpu <= max(1e-4, 2 * e_cpu), (e_gpu, e_cpu)
+    # linear in the upstream gradient, finite
+    vg2 = v.to(DEV).requires_grad_(True)
+    a2 = MeshRasterFunction.apply(vg2, faces_i32(f, torch.device(DEV)), cam.to(DEV), H, W, sigma)
+    (a2 * (2 * Wt).to(DEV)).sum().backward()
+    assert rel_err(vg2.grad.cpu(), 2 * vg.grad.cpu()) <= 1e-5 and bool(torch.isfinite(vg.grad).all())
+
+
+@pytest.mark.gpu
+def test_mesh_raster_edge_cases(vpn):
+    """Faces behind the camera are skipped; degenerate (zero-area) faces and out-of-range vertex indices neither fault
+    nor produce NaN; an empty tile set (mesh outside the frustum) gives alpha = 0 and a zero gradient."""
+    from vpn_amd.ops import MeshRasterFunction
+    dev = torch.device(DEV)
+    v = torch.tensor([[[0.0, 0.0, 0.0], [0.0, 0.1, 0.0], [0.0, 0.0, 0.1], [2.0, 0.0, 0.0], [2.0, 0.1, 0.0], [2.0, 0.0, 0.1],
+                       [0.0, 0.0, 0.0]]])
+    f = torch.tensor([[0, 1, 2], [3, 4, 5], [0, 0, 6], [0, 1, 99]], dtype=torch.int32)     # front, behind the eye, degenerate, bad index
+    cam = torch.tensor([[1.0, 0.0, 0.0]])
+    vg = v.to(dev).requires_grad_(True)
+    a = MeshRasterFunction.apply(vg, f.to(dev), cam.to(dev), 32, 32, 1e-3)
+    a.sum().backward()
+    ref = O.mesh_raster(v, torch.tensor([[0, 1, 2], [0, 0, 6], [0, 1, 6]]), cam, 32, 32, 1e-3)   # index 99 clamps to the last vertex
+    assert bool(torch.isfinite(a).all()) and bool(torch.isfinite(vg.grad).all())
+    assert float((a.detach().cpu() - ref).abs().max()) <= 2e-5
+    assert float(vg.grad[0, 3:6].abs().max()) == 0.0                  # the face behind the camera got no gradient
+    far = (v + torch.tensor([0.0, 5.0, 0.0])).to(dev).requires_grad_(True)
+    a2 = MeshRasterFunction.apply(far, f[:1].to(dev), cam.to(dev), 32, 32, 1e-3)
+    a2.sum().backward()
+    assert float(a2.detach().max()) == 0.0 and float(far.grad.abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+def test_mesh_sample_vs_oracle(vpn):
+    """vpn_mesh_sample_fwd/bwd against the oracle on the same Philox draws and on explicit uniforms: face choice equal
+    (one cumulative-area rounding may differ per ~1e6 draws), points to 1e-6, gradient = barycentric scatter."""
+    from vpn_amd.ops import MeshSampleFunction, faces_i32
+    dev = torch.device(DEV)
+    v, f = icosphere(2, 0.3)
+    v = v * torch.tensor([1.0, 0.4, 1.7])
+    gen = torch.Generator().manual_seed(11)
+    B, n = 3, 4000
+    vb = v[None] + 0.01 * torch.randn(B, v.shape[0], 3, generator=gen)
+    for mode in ('philox', 'explicit'):
+        u = torch.rand(B, n, 3, generator=gen) if mode == 'explicit' else None
+        vg = vb.to(dev).requires_grad_(True)
+        pts, idx = MeshSampleFunction.apply(vg, faces_i32(f, dev), n, u.to(dev) if u is not None else None, 77, 5)
+        Wt = torch.randn(B, n, 3, generator=gen)
+        (pts * Wt.to(dev)).sum().backward()
+        for b in range(B):
+            ub = u[b] if u is not None else O.philox_uniforms_mesh(77, 5 + b, n)
+            vc = vb[b].clone().requires_grad_(True)
+            rp, ri = O.mesh_sample(vc, f, ub)
+            same = idx[b].cpu().long() == ri
+            assert float(same.float().mean()) > 0.999
+            assert float((pts[b].detach().cpu() - rp.detach())[same].abs().max()) <= 1e-6
+            (rp * Wt[b] * same[:, None]).sum().backward()
+            got = vg.grad[b].cpu()
+            if bool(same.all()):
+                assert rel_err(got, vc.grad) <= 1e-5
+    assert not idx.requires_grad and idx.dtype == torch.int32
+
+
+@pytest.mark.gpu
+def test_train_sphere_call_pattern(vpn, tmp_path):
+    """train_sphere.py:50-128 as written, on this surface: TriangleMesh.from_obj -> .cuda() -> in-place deformation by
+    the network's offsets -> mesh.sample(n)[0] -> ChamferDistanceLoss, SilhouetteLoss(list of meshes, ...) -> backward
+    to the offsets.  BASELINE config C1 sizes: batch 4, 64 x 64 silhouettes."""
+    v, f = icosphere(2, 0.3)
+    obj = tmp_path / 'sphere.obj'
+    obj.write_text(''.join('v %.9g %.9g %.9g\n' % tuple(p) for p in v.tolist()) + ''.join('f %d %d %d\n' % tuple(i + 1 for i in t) for t in f.tolist()))
+    v = vpn.load_obj(str(obj))[0]                                      # exactly what the meshes below hold
+    B, H, W, n = 4, 64, 64, 128
+    gen = torch.Generator().manual_seed(3)
+    offsets = (0.02 * torch.randn(B, v.shape[0], 3, generator=gen)).to(DEV).requires_grad_(True)
+    meshes = []
+    for b in range(B):
+        m = vpn.TriangleMesh.from_obj(str(obj))                       # train_sphere.py:51-55
+        m.cuda()
+        meshes.append(m)
+    for b in range(B):
+        meshes[b].vertices += offsets[b]                              # train_sphere.py:66
+    points = torch.cat([meshes[b].sample(n)[0][None] for b in range(B)], 0)       # train_sphere.py:75-78
+    assert points.shape == (B, n, 3)
+    gt_points = (torch.rand(B, 2048, 3, generator=gen) - 0.5).to(DEV)
+    gt_sil = (torch.rand(B, 1, H, W, generator=gen) > 0.5).float().to(DEV)
+    dists = torch.ones(B, device=DEV)
+    elevs, azims = torch.zeros(B, device=DEV), torch.zeros(B, device=DEV)
+    cd = vpn.ChamferDistanceLoss()(points, gt_points)
+    sil = vpn.SilhouetteLoss()(meshes, gt_sil, dists, elevs, azims)   # train_sphere.py:128
+    (cd + sil).backward()
+    assert bool(torch.isfinite(offsets.grad).all()) and float(offsets.grad.abs().max()) > 0
+    # the same numbers from the oracle
+    oc = offsets.detach().cpu().clone().requires_grad_(True)
+    vs = v[None] + oc
+    a = O.mesh_raster(vs, f, torch.tensor([[1.0, 0.0, 0.0]]).expand(B, 3), H, W, vpn.config.MESH_RASTER_SIGMA)
+    ref_sil = (a[:, None] - gt_sil.cpu()).abs().mean()
+    assert abs(float(sil.detach()) - float(ref_sil.detach())) / float(ref_sil.detach()) <= 1e-4
+    # VertexRenderer.render on such a mesh: vertex_renderer.py:24's three outputs
+    rgb, alpha, normals = vpn.VertexRenderer.render(meshes[0], 1.0, 0.0, 0.0, image_size=(H, W))
+    assert rgb.shape == (1, H, W, 3) and alpha.shape == (1, H, W, 1) and normals.shape == (1, f.shape[0], 3)
+    assert float((alpha[0, :, :, 0].detach().cpu() - a[0].detach()).abs().max()) <= 2e-5
+    assert rel_err(normals[0].detach().cpu(), O.mesh_face_normals(vs[:1].detach(), f)[0]) <= 1e-5
+
+
+@pytest.mark.gpu
+def test_meshing_made_mesh_renders_the_same_silhouette_through_both_paths(vpn):
+    """A mesh made by Meshing carries its primitives and renders through the primitive raster; the SAME mesh with its
+    vertices touched renders its triangles.  Both are soft silhouettes of the same solid: the 0.5 contours agree up to
+    the discretisation of the 128-vertex template (the polygon is inscribed in the ellipsoid's outline)."""
+    gen = torch.Generator().manual_seed(9)
+    B, H, W = 2, 128, 128
+    v = torch.tensor([[0.25, 0.15, 0.2], [0.12, 0.3, 0.18]])
+    q = torch.rand(B, 4, generator=gen)
+    t = 0.1 * (torch.rand(B, 3, generator=gen) - 0.5)
+    meshes = vpn.Meshing.sphere_meshing(v.to(DEV), q.to(DEV), t.to(DEV))
+    _, a_prim, _ = vpn.VertexRenderer.render(meshes, 1.0, 0.0, 0.0, image_size=(H, W))
+    for m in meshes:
+        m.vertices += 0.0                                              # an in-place edit (even a no-op) drops the primitives
+        assert m.primitives is None
+    _, a_tri, _ = vpn.VertexRenderer.render(meshes, 1.0, 0.0, 0.0, image_size=(H, W))
+    sp, st = a_prim[..., 0] > 0.5, a_tri[..., 0] > 0.5
+    inter, union = (sp & st).sum((1, 2)).float(), (sp | st).sum((1, 2)).float()
+    assert bool((inter / union > 0.9).all()), (inter / union)
+    # (the soft UNION of the faces pushes its 0.5 contour slightly outward where several faces meet the outline, the
+    # inscribed polygon pulls it inward: the areas agree to a few per cent)
+    ratio = st.sum((1, 2)).float() / sp.sum((1, 2)).float()
+    assert bool(((ratio > 0.95) & (ratio < 1.05)).all()), ratio
+    # a moved mesh moves its rendered silhouette -- the edit is not ignored
+    for m in meshes:
+        m.vertices += torch.tensor([0.0, 0.0, -0.15], device=DEV)
+    _, a_mv, _ = vpn.VertexRenderer.render(meshes, 1.0, 0.0, 0.0, image_size=(H, W))
+    cx = lambda im: (im * torch.arange(W, device=im.device)[None, None, :]).sum((1, 2)) / im.sum((1, 2))
+    assert bool((cx(a_mv[..., 0]) > cx(a_tri[..., 0]) + 10).all())

@@ -129,9 +129,12 @@ def test_reference_mesh_list_call_pattern():
     # silhouette.py:17: VertexRenderer.render(predict_meshes[i], dists[i], elevs[i], azims[i]) on one composed mesh
     _, alpha, _ = VertexRenderer.render(predict_meshes[1], dists[1], elevs[1], azims[1], image_size=(H, W))
     assert alpha.shape == (1, H, W, 1) and rel_err(alpha[0, :, :, 0].detach().cpu(), a_ref[1].detach()) <= 1e-4
-    # a mesh that carries no primitives (loaded from a file, say) cannot be rendered by the primitive raster
+    # a mesh that carries no primitives (loaded from a file, say) is not rendered by the primitive raster
+    # (PrimitivePack.of refuses it) but through its triangles (tests/test_mesh_path.py): a finite loss of the same solid
     bare = vpn_amd.TriangleMesh(predict_meshes[0].vertices.detach(), predict_meshes[0].faces)
     with pytest.raises(TypeError):
-        silhouette_loss_func([bare] * BATCH_SIZE, silhouettes, dists, elevs, azims)
+        vpn_amd.PrimitivePack.of([bare] * BATCH_SIZE)
+    l_tri = silhouette_loss_func([bare] * BATCH_SIZE, silhouettes, dists, elevs, azims)
+    assert bool(torch.isfinite(l_tri)) and 0.0 < float(l_tri) < 1.0
     mixed = Meshing.compose_meshes([predict_meshes[0], bare])
     assert mixed.primitives is None

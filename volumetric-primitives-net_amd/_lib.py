@@ -53,6 +53,11 @@ SIGNATURES = {
     'vpn_camera_transform_bwd': (_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _i, _i, _i, _c_f, _c_f]),
     'vpn_mesh_fwd': (_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _i, _i, _i, _c_f, _c_f]),
     'vpn_mesh_bwd': (_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _i, _i, _i, _c_f, _c_f, _c_f]),
+    'vpn_mesh_raster_workspace': (_sz, [_i, _i]),
+    'vpn_mesh_raster_fwd': (_i, [_c_f, _c_f, _c_f, _i, _i, _i, _i, _i, _f, _c_f, _c_f, _c_f]),
+    'vpn_mesh_raster_bwd': (_i, [_c_f, _c_f, _c_f, _i, _i, _i, _i, _i, _f, _c_f, _c_f, _c_f, _c_f, _c_f]),
+    'vpn_mesh_sample_fwd': (_i, [_c_f, _c_f, _c_f, _u64, _u64, _i, _i, _i, _i, _c_f, _c_f, _c_f, _c_f, _c_f]),
+    'vpn_mesh_sample_bwd': (_i, [_c_f, _c_f, _c_f, _c_f, _i, _i, _i, _i, _c_f, _c_f]),
     'vpn_head_pack_fwd': (_i, [_c_f, _c_f, _c_f, _i, _i, _i, _f, _f, _f, _f, _f, _c_f, _c_f]),
     'vpn_head_pack_bwd': (_i, [_c_f, _c_f, _c_f, _c_f, _i, _i, _i, _f, _f, _f, _f, _f, _c_f, _c_f, _c_f, _c_f]),
     'vpn_emd_workspace': (_sz, [_i, _i]),

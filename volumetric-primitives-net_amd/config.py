@@ -19,3 +19,4 @@ IMG_SIZE = 128              # config.py:49
 RASTER_SIGMA = 0.05
 RASTER_GAMMA = 0.1
 RASTER_Z_FAR = 2.0
+MESH_RASTER_SIGMA = 1e-4    # triangle-mesh silhouettes (oracle/vpn_oracle.py::mesh_raster): NDC^2, ~1 pixel of softness at 128^2

@@ -248,6 +248,7 @@ __global__ __launch_bounds__(EMD_THREADS) void emd_auction_kernel(const float* _
     }
     for (int j = gtid; j < n; j += gthreads) {                  // CalcDist :217-226
         const int t = emd_ld(assign + j);
+        if (t < 0 || t >= n) { dist[(size_t)b * n + j] = __builtin_nanf(""); continue; }    // unassigned: no target to measure to
         const float dx = p1[j * 3] - p2[t * 3], dy = p1[j * 3 + 1] - p2[t * 3 + 1], dz = p1[j * 3 + 2] - p2[t * 3 + 2];
         dist[(size_t)b * n + j] = ((dx * dx) + (dy * dy)) + (dz * dz);
     }
@@ -261,6 +262,11 @@ __global__ __launch_bounds__(256) void emd_bwd_kernel(const float* __restrict__ 
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= total) return;
     const int b = e / n, t = assignment[e];
+    if (t < 0 || t >= n) {          // a point the forward left unassigned (its distance is NaN): the gradient says so too,
+        const float nan = __builtin_nanf("");      // and nothing is read through the index
+        grad_xyz1[(size_t)e * 3] = nan; grad_xyz1[(size_t)e * 3 + 1] = nan; grad_xyz1[(size_t)e * 3 + 2] = nan;
+        return;
+    }
     const float* a = xyz1 + (size_t)e * 3;
     const float* c = xyz2 + ((size_t)b * n + t) * 3;
     const float g = grad_dist[e] * 2.0f;

@@ -282,10 +282,14 @@ __global__ __launch_bounds__(SAMP_BLOCK) void sample_chamfer_bwd_kernel(
     // The canonical coefficient c of a point (p = R (c * v) + t) is RECOVERED from the point the forward pass wrote,
     // c = R^T (p - t) / v: 12 instructions instead of redrawing the Philox uniforms and redoing acos / sin / cos
     // (~300: two thirds of this kernel's instructions).  It differs from the forward's c by rounding only (1e-7
-    // relative; the gradient is a 1e-4 contract).  A degenerate extent (|v_a| < 1e-20, never produced by the network:
-    // vpnet_one_resnet.py:71,84) falls back to the exact recomputation, uniformly for the workgroup.
+    // relative; the gradient is a 1e-4 contract).  The error of a recovered c_a is ~2^-24 |p| / |v_a| (p - t cancels):
+    // a THIN primitive (smallest extent below 1e-3 of the size of the numbers it is subtracted from; the network's
+    // range, vpnet_one_resnet.py:71,84, stays 10x above that) falls back to the exact recomputation from the uniforms /
+    // the Philox counter, uniformly for the workgroup.
     const float tx = prm[7], ty = prm[8], tz = prm[9];
-    const bool recover = fabsf(P.v[0]) > 1e-20f && fabsf(P.v[1]) > 1e-20f && fabsf(P.v[2]) > 1e-20f;
+    const float vmin = fminf(fminf(fabsf(P.v[0]), fabsf(P.v[1])), fabsf(P.v[2]));
+    const float big = fmaxf(fmaxf(fmaxf(fabsf(tx), fabsf(ty)), fabsf(tz)), fmaxf(fmaxf(fabsf(P.v[0]), fabsf(P.v[1])), fabsf(P.v[2])));
+    const bool recover = vmin >= 1.0e-3f * big && vmin > 1e-20f;
     const float iv0 = recover ? 1.0f / P.v[0] : 0.0f, iv1 = recover ? 1.0f / P.v[1] : 0.0f, iv2 = recover ? 1.0f / P.v[2] : 0.0f;
     auto add = [&](int pl, float gx, float gy, float gz) {              // point pl of this primitive gets gradient g
         float c[3];

@@ -68,8 +68,14 @@ class SilhouetteLoss(nn.Module):
         made by Meshing: each carries its primitives), a list of per-sample packs, or one PrimitivePack for the
         batch; the B sequential
         renders of silhouette.py:16-18 become one launch at the GT silhouette's resolution."""
-        predict_meshes = PrimitivePack.of(predict_meshes)
         H, W = gt_silhouettes.shape[-2:]
+        try:
+            predict_meshes = PrimitivePack.of(predict_meshes)
+        except TypeError:
+            # meshes without (valid) primitives, e.g. train_sphere.py:119-128 (a sphere mesh deformed in place): their
+            # triangles are rendered, silhouette.py:16-22 as written (B renders -> cat -> L1Loss / MSELoss)
+            alpha, _ = VertexRenderer.triangle_alpha(predict_meshes, dists, elevs, azims, H, W)
+            return self.loss_func(alpha[:, None], gt_silhouettes.to(alpha.device).float().reshape(alpha.shape[0], 1, H, W))
         B = len(predict_meshes)
         dev = predict_meshes.params.device
         cam = torch.stack([dists.to(dev).float().reshape(-1).expand(B), elevs.to(dev).float().reshape(-1).expand(B),

@@ -15,14 +15,31 @@ from ..primitives import PrimitivePack
 
 
 class TriangleMesh:
-    """The two attributes of kaolin.rep.TriangleMesh that the reference touches (meshing.py:35-43), plus
+    """The attributes and methods of kaolin.rep.TriangleMesh that the reference touches: `vertices` / `faces`
+    (meshing.py:35-43, vertex_renderer.py:20-21), `from_obj`, `cuda` and `sample` (train_sphere.py:53-54,76), plus
     `primitives`: the PrimitivePack (one sample, [1,K,10] + kinds) the mesh was generated from, attached by
-    Meshing.*_meshing and carried through compose_meshes.  The raster consumes primitives, not triangles, so a mesh
-    that carries them renders through SilhouetteLoss / VertexRenderer exactly as train.py:122-149,176 builds and
-    passes it; a mesh without them (e.g. loaded from an OBJ) cannot be rendered."""
+    Meshing.*_meshing and carried through compose_meshes.
+
+    How a mesh renders (SilhouetteLoss / VertexRenderer.render):
+      * a mesh that carries primitives AND whose vertices are still the ones Meshing wrote renders through the
+        primitive raster, exactly as train.py:122-149,176 builds and passes it;
+      * any other mesh -- loaded from an OBJ, built from tensors, or a Meshing-made mesh whose vertices were edited
+        afterwards (train_sphere.py:62-68 deforms its meshes in place: `mesh.vertices += offset`) -- renders its
+        TRIANGLES through the mesh raster (vpn_mesh_raster_fwd/bwd).  An edit is never silently ignored: the
+        primitives are only trusted while (vertices tensor, its version counter) are the ones recorded here."""
 
     def __init__(self, vertices: torch.Tensor, faces: torch.Tensor, primitives=None):
-        self.vertices, self.faces, self.primitives = vertices, faces, primitives
+        self.vertices, self.faces = vertices, faces
+        self._primitives = primitives
+        # the tensor itself is kept (not its id, which a later tensor may reuse) with the version it had
+        self._stamp = (vertices, vertices._version) if primitives is not None else None
+
+    @property
+    def primitives(self):
+        """The primitives this mesh was made from, or None once its vertices have been replaced or edited in place."""
+        if self._primitives is None or self._stamp[0] is not self.vertices or self._stamp[1] != self.vertices._version:
+            return None
+        return self._primitives
 
     @classmethod
     def from_tensors(cls, vertices, faces, primitives=None):
@@ -33,8 +50,33 @@ class TriangleMesh:
         return cls(*load_obj(path))
 
     def to(self, device):
-        self.vertices, self.faces = self.vertices.to(device), self.faces.to(device)
+        moved = self.vertices.to(device)
+        keep = self.primitives if moved is self.vertices else None
+        self.vertices, self.faces = moved, self.faces.to(device)
+        self._primitives = keep
+        self._stamp = (self.vertices, self.vertices._version) if keep is not None else None
         return self
+
+    def cuda(self):
+        return self.to('cuda')                                   # train_sphere.py:54
+
+    def sample(self, num_samples: int, seed=None):
+        """kaolin's TriangleMesh.sample as train_sphere.py:76 uses it: `num_samples` points drawn uniformly from the
+        surface (faces chosen in proportion to their area, uniform inside the face) -> (points [n,3], face_choices
+        [n]).  Differentiable w.r.t. the vertices.  Draws come from Philox keyed by (seed, a per-process call counter)
+        unless a seed is given."""
+        from ..ops import MeshSampleFunction, faces_i32
+        if seed is None:
+            TriangleMesh._calls += 1
+            seed, base = TriangleMesh.sample_seed, TriangleMesh._calls
+        else:
+            base = 0
+        pts, idx = MeshSampleFunction.apply(self.vertices[None], faces_i32(self.faces, self.vertices.device), int(num_samples),
+                                            None, int(seed), int(base))
+        return pts[0], idx[0].long()
+
+    sample_seed = 1234          # config.py:20 MANUAL_SEED of the reference
+    _calls = 0
 
 
 def load_obj(path):

@@ -2,8 +2,8 @@
 import torch
 
 from .. import config
-from ..ops import RasterFunction
-from ..primitives import PrimitivePack
+from ..ops import MeshRasterFunction, RasterFunction, faces_i32
+from ..primitives import PrimitivePack, mesh_batches
 
 
 def _as_batch(x, B, device):
@@ -31,7 +31,11 @@ class VertexRenderer:
 
     @classmethod
     def render(cls, mesh, dist, elev, azim, colors=None, image_size=None):
-        mesh = PrimitivePack.of(mesh)        # a pack, a Meshing-made mesh (train.py:122-149), or a list of them
+        try:
+            mesh = PrimitivePack.of(mesh)    # a pack, a Meshing-made mesh (train.py:122-149), or a list of them
+        except TypeError:
+            # a mesh without (valid) primitives: its triangles are rendered (vertex_renderer.py:20-24 as written)
+            return cls.render_triangles(mesh, dist, elev, azim, colors, image_size)
         B = len(mesh)
         dev = mesh.params.device
         cam = torch.stack([_as_batch(dist, B, dev), _as_batch(elev, B, dev), _as_batch(azim, B, dev)], 1)
@@ -43,3 +47,42 @@ class VertexRenderer:
         else:
             render_rgbs = render_alphas * colors.reshape(-1, 1, 1, 3)
         return render_rgbs, render_alphas, depth[..., None]
+
+    mesh_sigma = config.MESH_RASTER_SIGMA
+
+    @classmethod
+    def triangle_alpha(cls, meshes, dist, elev, azim, H, W):
+        """alpha (B,H,W) of triangle meshes (one mesh or a list, one per sample) and their batches."""
+        batches = mesh_batches(meshes)
+        B = sum(len(g) for g, _, _ in batches)
+        dev = batches[0][1].device
+        cam = torch.stack([_as_batch(dist, B, dev), _as_batch(elev, B, dev), _as_batch(azim, B, dev)], 1)
+        out = [None] * B
+        for idx, verts, faces in batches:
+            sel = torch.tensor(idx, device=dev)
+            a = MeshRasterFunction.apply(verts, faces_i32(faces, dev), cam[sel].contiguous(), H, W, cls.mesh_sigma)
+            for j, i in enumerate(idx):
+                out[i] = a[j]
+        return torch.stack(out), batches
+
+    @classmethod
+    def render_triangles(cls, mesh, dist, elev, azim, colors=None, image_size=None):
+        """vertex_renderer.py:14-26 for a mesh given by vertices and faces: (rgb (B,H,W,3), alpha (B,H,W,1), unit face
+        normals (B,F,3) as DIBRenderer returns them -- a list of per-mesh tensors if the topologies differ)."""
+        H, W = image_size or cls.image_size
+        alpha, batches = cls.triangle_alpha(mesh, dist, elev, azim, H, W)
+        B = alpha.shape[0]
+        render_alphas = alpha[..., None]
+        if colors is None:
+            render_rgbs = render_alphas.expand(B, H, W, 3)
+        else:
+            render_rgbs = render_alphas * colors.reshape(-1, 1, 1, 3)
+        normals = [None] * B
+        for idx, verts, faces in batches:
+            tri = verts[:, faces.long(), :]
+            nrm = torch.cross(tri[:, :, 1] - tri[:, :, 0], tri[:, :, 2] - tri[:, :, 0], dim=-1)
+            nrm = nrm / nrm.norm(dim=-1, keepdim=True).clamp_min(1e-20)
+            for j, i in enumerate(idx):
+                normals[i] = nrm[j]
+        face_norms = torch.stack(normals) if len(batches) == 1 else normals
+        return render_rgbs, render_alphas, face_norms

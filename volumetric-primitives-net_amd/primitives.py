@@ -63,9 +63,31 @@ class PrimitivePack:
             if not obj:
                 raise TypeError('empty list of meshes')
             return PrimitivePack.stack([PrimitivePack.of(o) for o in obj])
-        prims = getattr(obj, 'primitives', None)
+        prims = getattr(obj, 'primitives', None)      # None once the mesh's vertices were edited (TriangleMesh.primitives)
         if isinstance(prims, PrimitivePack):
             return prims
         raise TypeError('the primitive raster renders primitive parameters: pass a PrimitivePack or a mesh made by '
-                        'Meshing.sphere_meshing / cuboid_meshing / compose_meshes (which carries its primitives); '
-                        'got %s without primitives' % type(obj).__name__)
+                        'Meshing.sphere_meshing / cuboid_meshing / compose_meshes whose vertices are unchanged (it '
+                        'carries its primitives); got %s without primitives' % type(obj).__name__)
+
+
+def mesh_batches(obj):
+    """Triangle meshes behind `obj` (one mesh or the per-sample list of train_sphere.py:58-59,128) as batches of one
+    topology: [(sample indices, verts [b,P,3], faces [F,3])].  Meshes that share their face tensor (or equal faces and
+    vertex count) render in one launch; the reference renders them one by one (silhouette.py:16-18)."""
+    meshes = list(obj) if isinstance(obj, (list, tuple)) else [obj]
+    if not meshes:
+        raise TypeError('empty list of meshes')
+    for m in meshes:
+        if not (hasattr(m, 'vertices') and hasattr(m, 'faces')):
+            raise TypeError('cannot render %s: neither primitives nor vertices / faces' % type(m).__name__)
+    groups = []
+    for i, m in enumerate(meshes):
+        for g in groups:
+            f0, v0 = meshes[g[0]].faces, meshes[g[0]].vertices
+            if m.vertices.shape == v0.shape and (m.faces is f0 or (m.faces.shape == f0.shape and torch.equal(m.faces, f0))):
+                g.append(i)
+                break
+        else:
+            groups.append([i])
+    return [(g, torch.stack([meshes[i].vertices for i in g]), meshes[g[0]].faces) for g in groups]
