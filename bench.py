@@ -31,7 +31,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3     # fp32 vector peak = fp32-input MFMA peak (MI355X_MICROARCH.md chip table)
 F16_PEAK_TFLOPS = 2500.0     # dense fp16 / bf16 MFMA (MI355X_MICROARCH.md; not the 2:1-sparsity figure)
 N_SIMD = 1024                # 256 CUs x 4 SIMD-32
-PMC_FILE = os.path.join(ROOT, 'profiles', 'r02_pmc.json')     # written by tools/pmc_collect.py from rocprofv3 passes
+PMC_FILE = os.path.join(ROOT, 'profiles', 'r03_pmc.json')     # written by tools/pmc_collect.py from rocprofv3 passes
 
 
 def synth_inputs(B, K, M, seed, device):
@@ -60,7 +60,7 @@ def event_windows(run, steps, windows):
 
 
 def load_pmc(workload_key):
-    """Counter summaries of the same command collected with rocprofv3 (tools/pmc_collect.py -> profiles/r02_pmc.json):
+    """Counter summaries of the same command collected with rocprofv3 (tools/pmc_collect.py -> profiles/r03_pmc.json):
     {kernel: {counter: mean per dispatch}} for this workload, or {}."""
     try:
         return json.load(open(PMC_FILE)).get(workload_key, {})
@@ -69,9 +69,9 @@ def load_pmc(workload_key):
 
 
 def load_isa_mix():
-    """Static issue-class mix of the raster kernels (tools/isa_mix.py -> profiles/r02_isa_mix.json)."""
+    """Static issue-class mix of the raster kernels (tools/isa_mix.py -> profiles/r03_isa_mix.json)."""
     try:
-        return json.load(open(os.path.join(ROOT, 'profiles', 'r02_isa_mix.json')))
+        return json.load(open(os.path.join(ROOT, 'profiles', 'r03_isa_mix.json')))
     except (OSError, ValueError):
         return {}
 
@@ -481,7 +481,7 @@ def main():
             step_hbm = {'traffic_bytes_per_step': int(tot), 'achieved_GBps': round(gbs, 1), 'peak_GBps': HBM_PEAK_GBS,
                         'frac': round(gbs / HBM_PEAK_GBS, 4), 'algorithmic_bytes_per_step': int(alg),
                         'note': 'sum over the kernels of one step of FETCH_SIZE (x2 for the 16-B-per-lane streams) + '
-                                'WRITE_SIZE from profiles/r02_pmc.json, over the hipEvent median step time: the step is '
+                                'WRITE_SIZE from profiles/r03_pmc.json, over the hipEvent median step time: the step is '
                                 'issue-bound (VALU / matrix pipe), not HBM-bound'}
 
     # The legs below are reported NEXT to the headline: a failure in one of them (host out of memory in the CPU leg, ...)

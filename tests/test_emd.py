@@ -128,6 +128,25 @@ def test_emd_equals_oracle(emd, B, n, eps, iters):
 
 
 @pytest.mark.gpu
+def test_emd_both_kernels_agree(emd):
+    """One-tile problems run the replicated-state kernel (one group barrier per round, state in every workgroup's
+    LDS); VPN_EMD_STREAMING=1 forces the streaming kernel (state in memory, two barriers) that larger clouds use.  Both
+    must equal the oracle bit for bit -- and therefore each other -- for every group size."""
+    import os
+    from vpn_amd.ops import EmdFunction
+    x1, x2 = _clouds(5, 700, 21)
+    rd, ra = O.emd_auction(x1, x2, 0.005, 40)
+    try:
+        for streaming in ('0', '1'):
+            os.environ['VPN_EMD_STREAMING'] = streaming
+            for G in (None, 1, 2, 8):
+                dist, assign = EmdFunction.apply(x1.to(DEV), x2.to(DEV), 0.005, 40, G)
+                assert torch.equal(assign.cpu(), ra) and torch.equal(dist.cpu(), rd), (streaming, G)
+    finally:
+        os.environ.pop('VPN_EMD_STREAMING', None)
+
+
+@pytest.mark.gpu
 def test_emd_ties_and_duplicates(emd):
     """Lattice points (equal values everywhere) and duplicated targets: lowest index wins, second best
     counts duplicates, equal increments resolve to the lowest bidder (also across workgroups of a group)."""

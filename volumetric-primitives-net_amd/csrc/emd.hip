@@ -16,6 +16,7 @@
 // oracle (oracle/vpn_oracle.py::emd_auction) bit for bit.  Parity with the CUDA extension itself is unpinned: it
 // cannot be built here (no nvcc) and ships no stored answers (its only check is test_emd, emd_module.py:81-95).
 #include "vpn_common.h"
+#include <stdlib.h>
 
 #pragma clang fp contract(off)
 
@@ -25,7 +26,7 @@ constexpr int EMD_THREADS = 1024;
 constexpr int EMD_WAVES = EMD_THREADS / 64;
 constexpr int EMD_TILE = 4096;           // targets per LDS tile: 4 planes x 16 KB
 constexpr int EMD_UNROLL = 4;            // targets per lane per step of the scan; tiles are padded to 64 * EMD_UNROLL
-constexpr int EMD_WS_PLANES = 8;         // 4-byte words of workspace per point
+constexpr int EMD_WS_PLANES = 10;        // 4-byte words of workspace per point (8 used by the streaming kernel, 10 by the replicated one)
 constexpr int EMD_MAX_GROUP = 16;        // workgroups cooperating on one sample
 
 // one bidder's running result over a set of targets
@@ -254,6 +255,143 @@ __global__ __launch_bounds__(EMD_THREADS) void emd_auction_kernel(const float* _
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// One-tile problems (n <= EMD_TILE, i.e. every training call: train.py:193 has n = 2048): REPLICATED STATE.
+// After the first three rounds an auction round has ~100 bidders per sample (2048 points, eps 0.005): it is a chain of
+// latencies, not work -- in the kernel above: rebuild the list from `assign` in memory, re-stage the prices, scan,
+// group barrier, Assign through memory, group barrier.  Here every workgroup of the sample keeps its OWN copy of the
+// auction state in LDS (assign, assign_inv, and the prices inside the target tile, which is staged once for the whole
+// auction) and all copies evolve identically:
+//   list of unassigned points from the LDS copy -> Bid scan against the LDS tile (each workgroup its share of the
+//   bidders) -> each bidder publishes (target, increment) and posts the 64-bit atomic max on the target -> ONE group
+//   barrier -> EVERY workgroup applies the Assign step of ALL bidders to its own copy (one lane per bidder; winners of
+//   different targets touch disjoint state, so the parallel update is deterministic).
+// One barrier per round instead of two, no price re-staging, no state round trips through memory.  What crosses
+// workgroups: bid / increment per point (double-buffered by round parity: a loser bids again in the next round while a
+// slower workgroup may still be reading this round's entry) and the per-target atomic max (three buffers: the one
+// round r wrote is read in the interval after barrier r and zeroed, by slices, in the interval after barrier r + 1).
+// Same arithmetic and tie rules as emd_auction_kernel: bit-equal to the oracle for every group size.
+__global__ __launch_bounds__(EMD_THREADS) void emd_auction_local_kernel(const float* __restrict__ xyz1,
+                                                                        const float* __restrict__ xyz2, int B, int n,
+                                                                        int npad, int G, float eps, int iters,
+                                                                        float* __restrict__ dist, int32_t* assignment,
+                                                                        float* wsf, unsigned* counters) {
+    extern __shared__ __attribute__((aligned(16))) float emd_lds[];      // 4 planes of npad floats + 3 arrays of npad ints
+    float* tx = emd_lds; float* ty = tx + npad; float* tz = ty + npad; float* tp = tz + npad;
+    int* assign_l = reinterpret_cast<int*>(tp + npad);
+    int* inv_l = assign_l + npad;
+    int* ulist = inv_l + npad;
+    __shared__ int wcount[EMD_WAVES];
+    __shared__ int gave_up;
+    if (threadIdx.x == 0) gave_up = 0;
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int b = (q / G) * 8 + xcd, g = q % G;
+    if (b >= B) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* p1 = xyz1 + (size_t)b * n * 3;
+    const float* p2 = xyz2 + (size_t)b * n * 3;
+    float* base = wsf + (size_t)b * EMD_WS_PLANES * n;
+    unsigned long long* top = reinterpret_cast<unsigned long long*>(base);     // 3 buffers of n keys: (increment, ~bidder) max
+    int* gbid = reinterpret_cast<int*>(base + 6 * n);                          // 2 buffers of n: target a point bids for
+    float* ginc = base + 8 * n;                                                // 2 buffers of n: its bid increment
+    unsigned* counter = counters + 2 * b;
+    unsigned passed = 0;
+    bool ok = true;
+
+    for (int j = tid; j < npad; j += EMD_THREADS) {             // the whole auction's tile and state (emd_module.py:44-50)
+        if (j < n) { const float* c = p2 + (size_t)j * 3; tx[j] = c[0]; ty[j] = c[1]; tz[j] = c[2]; tp[j] = 0.0f; }
+        else { tx[j] = 0.0f; ty[j] = 0.0f; tz[j] = 0.0f; tp[j] = __builtin_inff(); }      // padding never wins
+        assign_l[j] = -1; inv_l[j] = -1;
+    }
+    for (int j = g * EMD_THREADS + tid; j < 3 * n; j += G * EMD_THREADS) emd_st(top + j, 0ull);
+    ok = emd_group_sync(counter, passed, G, &gave_up);
+
+    const int per = (n + EMD_THREADS - 1) / EMD_THREADS, j0 = min(n, tid * per), j1 = min(n, j0 + per);
+    for (int it = 0; ok && it < iters; ++it) {
+        const bool last = it == iters - 1;
+        unsigned long long* top_w = top + (size_t)(it % 3) * n;              // this round's keys
+        unsigned long long* top_z = top + (size_t)((it + 1) % 3) * n;        // read two rounds ago: zeroed now
+        int* bid_w = gbid + (size_t)(it & 1) * n;
+        float* inc_w = ginc + (size_t)(it & 1) * n;
+        // ---- unassigned points in ascending order, from this workgroup's own copy
+        int cnt = 0;
+        for (int j = j0; j < j1; ++j) cnt += assign_l[j] == -1;
+        int scan = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t2 = __shfl_up(scan, o, 64); if (lane >= o) scan += t2; }
+        if (lane == 63) wcount[wave] = scan;
+        __syncthreads();
+        int before = 0, U = 0;
+#pragma unroll
+        for (int w = 0; w < EMD_WAVES; ++w) { const int c = wcount[w]; before += w < wave ? c : 0; U += c; }
+        if (U == 0) break;                                      // every copy agrees
+        int pos = before + scan - cnt;
+        for (int j = j0; j < j1; ++j) if (assign_l[j] == -1) ulist[pos++] = j;
+        if (it >= 1) for (int j = g * EMD_THREADS + tid; j < n; j += G * EMD_THREADS) emd_st(top_z + j, 0ull);
+        __syncthreads();
+
+        // ---- Bid (:95-179): wave w of workgroup g takes bidders g*16+w, +16G, ...
+        for (int u = g * EMD_WAVES + wave; u < U; u += G * EMD_WAVES) {
+            const int i = ulist[u];
+            const float x1 = p1[i * 3], y1 = p1[i * 3 + 1], z1 = p1[i * 3 + 2];
+            Bid3 r{-1e9f, -1e9f, -1};                           // :116
+            for (int k = lane; k < npad; k += 64 * EMD_UNROLL) {
+#pragma unroll
+                for (int e = 0; e < EMD_UNROLL; ++e) {
+                    const int kk = k + 64 * e;
+                    const float dx = tx[kk] - x1, dy = ty[kk] - y1, dz = tz[kk] - z1;              // :139-141
+                    const float d = (3.0f - emd_sqrt(((dx * dx) + (dy * dy)) + (dz * dz))) - tp[kk];   // :143
+                    r.idx = d > r.best ? kk : r.idx;                                               // :144-151
+                    r.better = __builtin_amdgcn_fmed3f(r.best, d, r.better);
+                    r.best = fmaxf(r.best, d);
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ob = __shfl_xor(r.best, o, 64), obt = __shfl_xor(r.better, o, 64);
+                const int oi = __shfl_xor(r.idx, o, 64);
+                emd_merge(r, ob, obt, oi);
+            }
+            if (lane == 0) {
+                const float v = (r.best - r.better) + eps;                                  // :175-176
+                emd_st(bid_w + i, r.idx); emd_st(inc_w + i, v);
+                const unsigned long long key =
+                    ((unsigned long long)(unsigned)__float_as_int(v) << 32) | (unsigned)(0x7fffffff - i);
+                __hip_atomic_fetch_max(top_w + r.idx, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // :177 + GetMax
+            }
+        }
+        if (!(ok = emd_group_sync(counter, passed, G, &gave_up))) break;      // the round's only group barrier
+
+        // ---- Assign (:196-215) of ALL bidders on this workgroup's copy: one lane per bidder
+        for (int u = tid; u < U; u += EMD_THREADS) {
+            const int i = ulist[u];
+            const int t = min(max(emd_ld(bid_w + i), 0), n - 1);
+            if (last) { assign_l[i] = t; continue; }
+            const unsigned long long key = emd_ld(top_w + t);
+            const float v = emd_ld(inc_w + i);
+            if (0x7fffffff - (int)(unsigned)key != i) continue;
+            const int prev = inv_l[t];
+            if (prev != -1) assign_l[prev] = -1;
+            inv_l[t] = i;
+            assign_l[i] = t;
+            tp[t] = tp[t] + v;                                  // :211
+        }
+        __syncthreads();
+    }
+
+    if (!ok) {                                                  // the group barrier timed out: no result for this sample
+        for (int j = g * EMD_THREADS + tid; j < n; j += G * EMD_THREADS) { dist[(size_t)b * n + j] = __builtin_nanf(""); assignment[(size_t)b * n + j] = -1; }
+        return;
+    }
+    for (int j = g * EMD_THREADS + tid; j < n; j += G * EMD_THREADS) {        // CalcDist :217-226 + the assignment itself
+        const int t = assign_l[j];
+        assignment[(size_t)b * n + j] = t;
+        if (t < 0 || t >= n) { dist[(size_t)b * n + j] = __builtin_nanf(""); continue; }
+        const float dx = p1[j * 3] - tx[t], dy = p1[j * 3 + 1] - ty[t], dz = p1[j * 3 + 2] - tz[t];
+        dist[(size_t)b * n + j] = ((dx * dx) + (dy * dy)) + (dz * dz);
+    }
+}
+
 // NmDistanceGradKernel :284-300: grad_xyz1 = (2 g) (x1 - x2[assignment]); xyz2 gets no gradient
 __global__ __launch_bounds__(256) void emd_bwd_kernel(const float* __restrict__ xyz1, const float* __restrict__ xyz2,
                                                       const float* __restrict__ grad_dist,
@@ -282,12 +420,12 @@ using namespace vpn;
 // Largest group size G (power of two) such that the whole grid is resident: workgroups per CU from the occupancy
 // query of THIS kernel on the CURRENT device (asked every call: nothing is cached across devices) times its CU
 // count.  max_group caps it (1 = no inter-workgroup barrier at all).
-static int emd_group_size(int B, int n, int max_group) {
+static int emd_group_size_of(const void* kernel, size_t dyn_lds, int B, int n, int max_group) {
     int dev = 0, cus = 0, per_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
         return 1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, emd_auction_kernel, EMD_THREADS, 0) != hipSuccess || per_cu <= 0)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, EMD_THREADS, dyn_lds) != hipSuccess || per_cu <= 0)
         return 1;
     const long long slots = (long long)cus * per_cu;
     const int padded = (B + 7) / 8 * 8;
@@ -295,6 +433,16 @@ static int emd_group_size(int B, int n, int max_group) {
     int G = 1;
     while (G * 2 <= cap && (long long)padded * G * 2 <= slots && G * 2 * EMD_WAVES * 4 <= n) G *= 2;
     return G;
+}
+
+static int emd_group_size(int B, int n, int max_group) {
+    return emd_group_size_of(reinterpret_cast<const void*>(emd_auction_kernel), 0, B, n, max_group);
+}
+
+// VPN_EMD_STREAMING=1: the streaming kernel also for one-tile problems (cross-check of the two kernels in the tests)
+static bool emd_force_streaming() {
+    const char* e = getenv("VPN_EMD_STREAMING");
+    return e && e[0] == '1';
 }
 
 static size_t emd_state_bytes(int B, int n) { return (size_t)B * n * EMD_WS_PLANES * sizeof(float); }
@@ -312,10 +460,39 @@ extern "C" int vpn_emd_fwd(const float* xyz1, const float* xyz2, int B, int n, f
     if (((uintptr_t)workspace & 7) != 0) return VPN_E_BADARG;
     if (B == 0 || n == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    int G = emd_group_size(B, n, max_group);
     unsigned* counters = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + emd_state_bytes(B, n));
     if (hipMemsetAsync(counters, 0, (size_t)2 * B * sizeof(unsigned), s) != hipSuccess) return (int)hipGetLastError();
     float* wsf = (float*)workspace;
+    if (n <= EMD_TILE && !emd_force_streaming()) {
+        // one-tile problem (every training call): replicated state, one group barrier per round
+        int npad = (n + 64 * EMD_UNROLL - 1) / (64 * EMD_UNROLL) * (64 * EMD_UNROLL);
+        const size_t lds = (size_t)npad * 7 * sizeof(float);
+        static size_t raised = 0;                      // largest dynamic LDS size the kernel has been allowed so far
+        if (lds > raised) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(emd_auction_local_kernel),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+            raised = lds;
+        }
+        int G = emd_group_size_of(reinterpret_cast<const void*>(emd_auction_local_kernel), lds, B, n, max_group);
+        if (G > 1) {
+            void* args[] = {(void*)&xyz1, (void*)&xyz2, (void*)&B, (void*)&n, (void*)&npad, (void*)&G, (void*)&eps, (void*)&iters,
+                            (void*)&dist, (void*)&assignment, (void*)&wsf, (void*)&counters};
+            vpn::prof_begin("emd_auction_local_kernel", s);
+            const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(emd_auction_local_kernel),
+                                                            dim3((B + 7) / 8 * 8 * G), dim3(EMD_THREADS), args, (unsigned)lds, s);
+            vpn::prof_end(s);
+            if (e == hipSuccess) return 0;
+            (void)hipGetLastError();
+            if (e != hipErrorCooperativeLaunchTooLarge && e != hipErrorNotSupported && e != hipErrorInvalidConfiguration) return (int)e;
+            G = 1;
+        }
+        VPN_LAUNCH(emd_auction_local_kernel, dim3((B + 7) / 8 * 8 * G), dim3(EMD_THREADS), lds, s, xyz1, xyz2, B, n, npad, G, eps,
+                   iters, dist, assignment, wsf, counters);
+        VPN_LAUNCH_CHECK();
+        return 0;
+    }
+    int G = emd_group_size(B, n, max_group);
     if (G > 1) {
         // the G workgroups of a sample synchronise with each other: a COOPERATIVE launch makes the runtime check that
         // the whole grid can be resident at once; if it says no, fall back to one workgroup per sample
