@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VPN_ABI_VERSION 2
+#define VPN_ABI_VERSION 3
 
 /* primitive kinds (reference: train.py:106-116 cuboids first, then spheres, cones are stubs) */
 #define VPN_SPHERE 0

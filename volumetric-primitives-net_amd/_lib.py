@@ -9,7 +9,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libvpn_hip.so')
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _c_f = ctypes.c_void_p      # device pointers travel as void*
 _i, _f, _u64, _sz = ctypes.c_int, ctypes.c_float, ctypes.c_uint64, ctypes.c_size_t
