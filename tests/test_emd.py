@@ -79,7 +79,7 @@ def test_cabi_validation_and_surface():
     import vpn_amd
     import vpn_amd._lib as lib
     L = lib.lib()
-    assert L.vpn_emd_workspace(3, 1000) == 3 * 1000 * 8 * 4 + 24      # state + (arrival counter, gave-up flag) per sample
+    assert L.vpn_emd_workspace(3, 1000) == 3 * 1000 * 10 * 4 + 24     # 10 words of state per point + (arrival counter, gave-up flag) per sample
     assert L.vpn_emd_workspace(0, 5) == 0
     assert L.vpn_emd_fwd(None, None, 1, 8, 0.005, 50, None, None, None, 0, None) == -1
     assert L.vpn_emd_bwd(None, None, None, None, 1, 8, None, None) == -1
