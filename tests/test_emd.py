@@ -129,21 +129,28 @@ def test_emd_equals_oracle(emd, B, n, eps, iters):
 
 @pytest.mark.gpu
 def test_emd_both_kernels_agree(emd):
-    """One-tile problems run the replicated-state kernel (one group barrier per round, state in every workgroup's
-    LDS); VPN_EMD_STREAMING=1 forces the streaming kernel (state in memory, two barriers) that larger clouds use.  Both
-    must equal the oracle bit for bit -- and therefore each other -- for every group size."""
+    """n <= 2048 runs the replicated-state kernel with the grid-pruned Bid scan, VPN_EMD_NOGRID=1 the same rounds with the
+    full scan (what 2048 < n <= 4096 uses), VPN_EMD_STREAMING=1 the streaming kernel (state in memory, two barriers) that
+    larger clouds use.  All three must equal the oracle bit for bit -- and therefore each other -- for every group size."""
     import os
     from vpn_amd.ops import EmdFunction
     x1, x2 = _clouds(5, 700, 21)
-    rd, ra = O.emd_auction(x1, x2, 0.005, 40)
+    # clustered, anisotropic and degenerate clouds: the pruned scan's grid must not care
+    gen = torch.Generator().manual_seed(4)
+    y1 = torch.cat([0.05 * torch.randn(2, 300, 3, generator=gen) + 0.5, torch.rand(2, 212, 3, generator=gen)], 1)
+    y2 = torch.rand(2, 512, 3, generator=gen) * torch.tensor([1.0, 0.01, 0.0]) + torch.tensor([0.0, 0.3, 0.25])   # a flat sheet
+    cases = [(x1, x2, 0.005, 40), (y1, y2, 0.005, 40), (y2, y1, 0.01, 25), (x1[:, :64], x2[:, :64], 0.005, 30)]
+    refs = [O.emd_auction(a, b, e, it) for a, b, e, it in cases]
     try:
-        for streaming in ('0', '1'):
-            os.environ['VPN_EMD_STREAMING'] = streaming
-            for G in (None, 1, 2, 8):
-                dist, assign = EmdFunction.apply(x1.to(DEV), x2.to(DEV), 0.005, 40, G)
-                assert torch.equal(assign.cpu(), ra) and torch.equal(dist.cpu(), rd), (streaming, G)
+        for streaming, nogrid in (('0', '0'), ('0', '1'), ('1', '0')):       # pruned / replicated-state / streaming kernel
+            os.environ['VPN_EMD_STREAMING'], os.environ['VPN_EMD_NOGRID'] = streaming, nogrid
+            for (a, b, e, it), (rd, ra) in zip(cases, refs):
+                for G in (None, 1, 2, 8):
+                    dist, assign = EmdFunction.apply(a.to(DEV), b.to(DEV), e, it, G)
+                    assert torch.equal(assign.cpu(), ra) and torch.equal(dist.cpu(), rd), (streaming, nogrid, G, a.shape)
     finally:
         os.environ.pop('VPN_EMD_STREAMING', None)
+        os.environ.pop('VPN_EMD_NOGRID', None)
 
 
 @pytest.mark.gpu

@@ -392,6 +392,295 @@ __global__ __launch_bounds__(EMD_THREADS) void emd_auction_local_kernel(const fl
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// n <= EMD_GRID_MAX (the training call: n = SAMPLE_NUM * VP_NUM = 2048, train.py:193): the replicated-state rounds of
+// emd_auction_local_kernel with a PRUNED Bid scan.  At B = 64 the auction is bound by the arithmetic of the scan
+// (10 011 bidder scans x 2048 targets x 23 instructions per sample), and almost all of it is spent on targets that
+// cannot matter: a bidder's value for target j is v_j = (3 - |x_i - y_j|) - price_j with price_j >= 0, so a target
+// farther than R = 3 - S from the bidder (S = any lower bound of its final second-best value) is STRICTLY below the
+// runner-up: it changes neither best, nor second best, nor a tie.  The targets do not move during an auction, so
+// they are sorted once into a uniform 8 x 8 x 8 grid over their bounding box (counting sort in LDS; x-fastest cell
+// order makes every (y, z) row of cells one contiguous run of sorted targets).  A bidder's wave
+//   A. scans the 3 x 3 x 3 cells around the bidder (flattened into a per-wave list of target positions, so all 64 lanes
+//      work even when a row holds a dozen targets) and merges: (best, second best, index);
+//   B. takes S = that second best, R = 3 - S (+ margin), and if the cells covering [x - R, x + R]^3 go beyond block A,
+//      scans that larger box instead (its result replaces A's).  Fewer than two targets in A: the whole grid.
+// The cell of a coordinate is a monotone function of it and the box bounds go through the same function, so a target
+// outside the box differs from the bidder by more than R along some axis: exact, whatever the rounding.
+// Ties are resolved on ORIGINAL indices (the order inside a cell is whatever the counting sort's atomics gave, and
+// differs between the workgroups of a sample; nothing depends on it).  Bit-equal to the oracle like the other two.
+constexpr int EMD_GRID_MAX = 2048;
+constexpr int EG = 8, ENC = EG * EG * EG;
+constexpr int ELIST = 448;              // target positions of a box one wave flattens at a time
+
+struct EmdGrid { float mn[3], sc[3]; };
+__device__ inline int emd_cell1(float x, float mn, float sc) {
+    const int c = (int)((x - mn) * sc);                          // monotone in x (truncation toward zero included)
+    return min(max(c, 0), EG - 1);
+}
+
+// one target (sorted position kk) into the lane's running result; r.idx is a SORTED position here
+__device__ inline void emd_eval(Bid3& r, int kk, float x1, float y1, float z1, const float* tx, const float* ty, const float* tz,
+                                const float* tp, const int* orig) {
+    const float dx = tx[kk] - x1, dy = ty[kk] - y1, dz = tz[kk] - z1;                                  // :139-141
+    const float d = (3.0f - emd_sqrt(((dx * dx) + (dy * dy)) + (dz * dz))) - tp[kk];                    // :143
+    bool take = d > r.best;                                                                         // :144-151
+    if (__builtin_amdgcn_ballot_w64(d == r.best && r.idx >= 0))        // equal values: the lower ORIGINAL index wins (rare)
+        take = take || (d == r.best && r.idx >= 0 && orig[kk] < orig[r.idx]);
+    r.idx = take ? kk : r.idx;
+    r.better = __builtin_amdgcn_fmed3f(r.best, d, r.better);
+    r.best = fmaxf(r.best, d);
+}
+
+// wave64 reductions on the VALU (DPP row shifts + row broadcasts, result wave-uniform): a butterfly of ds_bpermute
+// shuffles costs ~70 cycles per step and value, and a bidder's scan is a chain of latencies
+#define EMD_DPPI(v, ctrl, rmask) __builtin_amdgcn_update_dpp((int)(v), (int)(v), ctrl, rmask, 0xf, false)
+__device__ inline float emd_wave_max(float v) {
+#define EMD_STEP(ctrl, rmask) v = fmaxf(v, __int_as_float(EMD_DPPI(__float_as_int(v), ctrl, rmask)))
+    EMD_STEP(0x111, 0xf); EMD_STEP(0x112, 0xf); EMD_STEP(0x114, 0xf); EMD_STEP(0x118, 0xf); EMD_STEP(0x142, 0xa); EMD_STEP(0x143, 0xc);
+#undef EMD_STEP
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ inline int emd_wave_min_i(int v) {
+#define EMD_STEP(ctrl, rmask) v = min(v, EMD_DPPI(v, ctrl, rmask))
+    EMD_STEP(0x111, 0xf); EMD_STEP(0x112, 0xf); EMD_STEP(0x114, 0xf); EMD_STEP(0x118, 0xf); EMD_STEP(0x142, 0xa); EMD_STEP(0x143, 0xc);
+#undef EMD_STEP
+    return __builtin_amdgcn_readlane(v, 63);
+}
+// the 64 lanes' results over disjoint target sets (ORIGINAL indices) -> the result over their union, in every lane:
+// largest value, lowest index among the lanes that hold it, second largest counting duplicates (= what folding the
+// lanes with emd_merge gives: the winner's own runner-up competes with every other lane's best)
+__device__ inline Bid3 emd_wave_merge(const Bid3& r) {
+    Bid3 o;
+    o.best = emd_wave_max(r.best);
+    o.idx = emd_wave_min_i((r.best == o.best && r.idx >= 0) ? r.idx : 0x7fffffff);
+    o.better = emd_wave_max((r.idx == o.idx && r.idx >= 0) ? r.better : r.best);
+    if (o.idx == 0x7fffffff) o.idx = -1;
+    return o;
+}
+
+// all targets of the cells [c0, c1] (per axis, inclusive) -> the merged result of the wave, with an ORIGINAL index
+__device__ inline Bid3 emd_scan_box(const int c0[3], const int c1[3], float x1, float y1, float z1, const float* tx, const float* ty,
+                                    const float* tz, const float* tp, const int* orig, const int* cell_start, int* wlist) {
+    const int lane = threadIdx.x & 63;
+    const int ny = c1[1] - c0[1] + 1, nz = c1[2] - c0[2] + 1, nrows = ny * nz;      // <= 64
+    int s0 = 0, len = 0;
+    if (lane < nrows) {
+        const int cy = c0[1] + lane % ny, cz = c0[2] + lane / ny, base = (cz * EG + cy) * EG;
+        s0 = cell_start[base + c0[0]];
+        len = cell_start[base + c1[0] + 1] - s0;
+    }
+    int off = len;                                               // inclusive prefix sum over the rows
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(off, o, 64); if (lane >= o) off += t; }
+    const int T = __shfl(off, 63, 64);
+    Bid3 r{-1e9f, -1e9f, -1};                                    // :116
+    // the rows' targets as ONE flat list, ELIST positions at a time: a lane writes the part of its row that falls into
+    // the window, then all 64 lanes evaluate the window (a row holds a dozen targets: row by row, 50 lanes would idle)
+    const int first = off - len;                                 // this lane's row covers flat positions [first, off)
+    for (int w0 = 0; w0 < T; w0 += ELIST) {
+        const int qlo = max(first, w0), qhi = min(off, w0 + ELIST);
+        for (int q = qlo; q < qhi; ++q) wlist[q - w0] = s0 + (q - first);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        const int cw = min(ELIST, T - w0);
+        for (int k = lane; k < cw; k += 64) emd_eval(r, wlist[k], x1, y1, z1, tx, ty, tz, tp, orig);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();                         // the list is rewritten by the next window / box
+    }
+    r.idx = r.idx >= 0 ? orig[r.idx] : -1;
+    return emd_wave_merge(r);
+}
+
+__global__ __launch_bounds__(EMD_THREADS) void emd_auction_grid_kernel(const float* __restrict__ xyz1,
+                                                                       const float* __restrict__ xyz2, int B, int n,
+                                                                       int npad, int G, float eps, int iters,
+                                                                       float* __restrict__ dist, int32_t* assignment,
+                                                                       float* wsf, unsigned* counters) {
+    extern __shared__ __attribute__((aligned(16))) float emd_lds[];      // 7 planes of npad floats + 5 arrays of npad ints
+    float* tx = emd_lds; float* ty = tx + npad; float* tz = ty + npad; float* tp = tz + npad;       // SORTED by cell
+    int* assign_l = reinterpret_cast<int*>(tp + npad);
+    int* inv_l = assign_l + npad;
+    int* ulist = inv_l + npad;
+    int* orig = ulist + npad;           // sorted position -> target
+    int* pos_of = orig + npad;          // target -> sorted position
+    float* bx = reinterpret_cast<float*>(pos_of + npad);         // the bidders' coordinates: a global load per bidder was
+    float* by = bx + npad; float* bz = by + npad;                // ~1 us at the head of every scan's latency chain
+    __shared__ int cell_start[ENC + 8];
+    __shared__ int cursor[ENC];
+    __shared__ int wlists[EMD_WAVES][ELIST];
+    __shared__ float red[EMD_WAVES][6];
+    __shared__ EmdGrid grid;
+    __shared__ int wcount[EMD_WAVES];
+    __shared__ int gave_up;
+    if (threadIdx.x == 0) gave_up = 0;
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int b = (q / G) * 8 + xcd, g = q % G;
+    if (b >= B) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* p1 = xyz1 + (size_t)b * n * 3;
+    const float* p2 = xyz2 + (size_t)b * n * 3;
+    float* base = wsf + (size_t)b * EMD_WS_PLANES * n;
+    unsigned long long* top = reinterpret_cast<unsigned long long*>(base);
+    int* gbid = reinterpret_cast<int*>(base + 6 * n);
+    float* ginc = base + 8 * n;
+    unsigned* counter = counters + 2 * b;
+    unsigned passed = 0;
+    bool ok = true;
+
+    // ---- the grid: bounding box of the targets, counting sort by cell (once per auction)
+    {
+        float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+        for (int j = tid; j < n; j += EMD_THREADS)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { const float c = p2[(size_t)j * 3 + a]; lo[a] = fminf(lo[a], c); hi[a] = fmaxf(hi[a], c); }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], o, 64)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o, 64)); }
+            if (lane == 0) { red[wave][a] = lo[a]; red[wave][3 + a] = hi[a]; }
+        }
+        for (int c = tid; c < ENC; c += EMD_THREADS) cursor[c] = 0;
+        __syncthreads();
+        if (tid < 3) {
+            float l = red[0][tid], h = red[0][3 + tid];
+            for (int w = 1; w < EMD_WAVES; ++w) { l = fminf(l, red[w][tid]); h = fmaxf(h, red[w][3 + tid]); }
+            grid.mn[tid] = l;
+            grid.sc[tid] = h > l ? (float)EG / (h - l) : 0.0f;      // a flat (or non-finite) extent: one layer of cells
+        }
+        __syncthreads();
+        for (int j = tid; j < n; j += EMD_THREADS) {
+            const int c = (emd_cell1(p2[(size_t)j * 3 + 2], grid.mn[2], grid.sc[2]) * EG + emd_cell1(p2[(size_t)j * 3 + 1], grid.mn[1], grid.sc[1])) * EG
+                          + emd_cell1(p2[(size_t)j * 3], grid.mn[0], grid.sc[0]);
+            atomicAdd(&cursor[c], 1);
+        }
+        __syncthreads();
+        // exclusive scan of the ENC counts: lanes of the first ENC / 64 waves, then across waves
+        int cnt = 0, incl = 0;
+        if (tid < ENC) { cnt = cursor[tid]; incl = cnt; }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        if (lane == 63) wcount[wave] = incl;
+        __syncthreads();
+        if (tid < ENC) {
+            int before = 0;
+            for (int w = 0; w < wave; ++w) before += wcount[w];
+            cell_start[tid] = before + incl - cnt;
+            cursor[tid] = before + incl - cnt;
+        }
+        if (tid == 0) cell_start[ENC] = n;
+        __syncthreads();
+        for (int j = tid; j < n; j += EMD_THREADS) {
+            const float x = p2[(size_t)j * 3], y = p2[(size_t)j * 3 + 1], z = p2[(size_t)j * 3 + 2];
+            const int c = (emd_cell1(z, grid.mn[2], grid.sc[2]) * EG + emd_cell1(y, grid.mn[1], grid.sc[1])) * EG + emd_cell1(x, grid.mn[0], grid.sc[0]);
+            const int pos = atomicAdd(&cursor[c], 1);
+            tx[pos] = x; ty[pos] = y; tz[pos] = z; tp[pos] = 0.0f; orig[pos] = j; pos_of[j] = pos;
+        }
+        for (int j = tid; j < npad; j += EMD_THREADS) {
+            if (j >= n) { tx[j] = 0.0f; ty[j] = 0.0f; tz[j] = 0.0f; tp[j] = __builtin_inff(); orig[j] = 0x7fffffff; }
+            assign_l[j] = -1; inv_l[j] = -1;
+            const int jc = min(j, n - 1);
+            bx[j] = p1[(size_t)jc * 3]; by[j] = p1[(size_t)jc * 3 + 1]; bz[j] = p1[(size_t)jc * 3 + 2];
+        }
+    }
+    for (int j = g * EMD_THREADS + tid; j < 3 * n; j += G * EMD_THREADS) emd_st(top + j, 0ull);
+    ok = emd_group_sync(counter, passed, G, &gave_up);
+
+    const int per = (n + EMD_THREADS - 1) / EMD_THREADS, j0 = min(n, tid * per), j1 = min(n, j0 + per);
+    int* wlist = wlists[wave];
+    for (int it = 0; ok && it < iters; ++it) {
+        const bool last = it == iters - 1;
+        unsigned long long* top_w = top + (size_t)(it % 3) * n;
+        unsigned long long* top_z = top + (size_t)((it + 1) % 3) * n;
+        int* bid_w = gbid + (size_t)(it & 1) * n;
+        float* inc_w = ginc + (size_t)(it & 1) * n;
+        int cnt = 0;
+        for (int j = j0; j < j1; ++j) cnt += assign_l[j] == -1;
+        int scan = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t2 = __shfl_up(scan, o, 64); if (lane >= o) scan += t2; }
+        if (lane == 63) wcount[wave] = scan;
+        __syncthreads();
+        int before = 0, U = 0;
+#pragma unroll
+        for (int w = 0; w < EMD_WAVES; ++w) { const int c = wcount[w]; before += w < wave ? c : 0; U += c; }
+        if (U == 0) break;
+        int pos = before + scan - cnt;
+        for (int j = j0; j < j1; ++j) if (assign_l[j] == -1) ulist[pos++] = j;
+        if (it >= 1) for (int j = g * EMD_THREADS + tid; j < n; j += G * EMD_THREADS) emd_st(top_z + j, 0ull);
+        __syncthreads();
+
+        // ---- Bid (:95-179), pruned
+        for (int u = g * EMD_WAVES + wave; u < U; u += G * EMD_WAVES) {
+            const int i = ulist[u];
+            const float x1 = bx[i], y1 = by[i], z1 = bz[i];
+            const float xyz[3] = {x1, y1, z1};
+            int a0[3], a1[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const int c = emd_cell1(xyz[a], grid.mn[a], grid.sc[a]);
+                a0[a] = max(c - 1, 0); a1[a] = min(c + 1, EG - 1);
+            }
+            Bid3 r = emd_scan_box(a0, a1, x1, y1, z1, tx, ty, tz, tp, orig, cell_start, wlist);
+            // every target outside [x - R, x + R]^3 is strictly below the runner-up found so far
+            const bool two = r.idx >= 0 && r.better > -1e8f;
+            const float R = two ? (3.0f - r.better) + 1.0e-5f : __builtin_inff();
+            int b0[3], b1[3];
+            bool inside = true;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                b0[a] = emd_cell1(xyz[a] - R, grid.mn[a], grid.sc[a]);
+                b1[a] = emd_cell1(xyz[a] + R, grid.mn[a], grid.sc[a]);
+                if (!(R < 1e30f)) { b0[a] = 0; b1[a] = EG - 1; }                // also a NaN radius: everything
+                inside = inside && b0[a] >= a0[a] && b1[a] <= a1[a];
+            }
+            if (!inside) {
+#pragma unroll
+                for (int a = 0; a < 3; ++a) { b0[a] = min(b0[a], a0[a]); b1[a] = max(b1[a], a1[a]); }
+                r = emd_scan_box(b0, b1, x1, y1, z1, tx, ty, tz, tp, orig, cell_start, wlist);
+            }
+            if (lane == 0) {
+                const float v = (r.best - r.better) + eps;                                  // :175-176
+                emd_st(bid_w + i, r.idx); emd_st(inc_w + i, v);
+                const unsigned long long key =
+                    ((unsigned long long)(unsigned)__float_as_int(v) << 32) | (unsigned)(0x7fffffff - i);
+                __hip_atomic_fetch_max(top_w + min(max(r.idx, 0), n - 1), key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (!(ok = emd_group_sync(counter, passed, G, &gave_up))) break;
+
+        // ---- Assign (:196-215) of ALL bidders on this workgroup's copy
+        for (int u = tid; u < U; u += EMD_THREADS) {
+            const int i = ulist[u];
+            const int t = min(max(emd_ld(bid_w + i), 0), n - 1);
+            if (last) { assign_l[i] = t; continue; }
+            const unsigned long long key = emd_ld(top_w + t);
+            const float v = emd_ld(inc_w + i);
+            if (0x7fffffff - (int)(unsigned)key != i) continue;
+            const int prev = inv_l[t];
+            if (prev != -1) assign_l[prev] = -1;
+            inv_l[t] = i;
+            assign_l[i] = t;
+            const int ps = pos_of[t];
+            tp[ps] = tp[ps] + v;                                // :211
+        }
+        __syncthreads();
+    }
+
+    if (!ok) {
+        for (int j = g * EMD_THREADS + tid; j < n; j += G * EMD_THREADS) { dist[(size_t)b * n + j] = __builtin_nanf(""); assignment[(size_t)b * n + j] = -1; }
+        return;
+    }
+    for (int j = g * EMD_THREADS + tid; j < n; j += G * EMD_THREADS) {        // CalcDist :217-226 + the assignment itself
+        const int t = assign_l[j];
+        assignment[(size_t)b * n + j] = t;
+        if (t < 0 || t >= n) { dist[(size_t)b * n + j] = __builtin_nanf(""); continue; }
+        const int ps = pos_of[t];
+        const float dx = bx[j] - tx[ps], dy = by[j] - ty[ps], dz = bz[j] - tz[ps];
+        dist[(size_t)b * n + j] = ((dx * dx) + (dy * dy)) + (dz * dz);
+    }
+}
+
 // NmDistanceGradKernel :284-300: grad_xyz1 = (2 g) (x1 - x2[assignment]); xyz2 gets no gradient
 __global__ __launch_bounds__(256) void emd_bwd_kernel(const float* __restrict__ xyz1, const float* __restrict__ xyz2,
                                                       const float* __restrict__ grad_dist,
@@ -439,11 +728,13 @@ static int emd_group_size(int B, int n, int max_group) {
     return emd_group_size_of(reinterpret_cast<const void*>(emd_auction_kernel), 0, B, n, max_group);
 }
 
-// VPN_EMD_STREAMING=1: the streaming kernel also for one-tile problems (cross-check of the two kernels in the tests)
-static bool emd_force_streaming() {
-    const char* e = getenv("VPN_EMD_STREAMING");
+// VPN_EMD_STREAMING=1: the streaming kernel also for one-tile problems; VPN_EMD_NOGRID=1: the unpruned replicated-state
+// kernel also for n <= 2048 (cross-checks of the three kernels in the tests)
+static bool emd_env_flag(const char* name) {
+    const char* e = getenv(name);
     return e && e[0] == '1';
 }
+static bool emd_force_streaming() { return emd_env_flag("VPN_EMD_STREAMING"); }
 
 static size_t emd_state_bytes(int B, int n) { return (size_t)B * n * EMD_WS_PLANES * sizeof(float); }
 
@@ -466,29 +757,34 @@ extern "C" int vpn_emd_fwd(const float* xyz1, const float* xyz2, int B, int n, f
     if (n <= EMD_TILE && !emd_force_streaming()) {
         // one-tile problem (every training call): replicated state, one group barrier per round
         int npad = (n + 64 * EMD_UNROLL - 1) / (64 * EMD_UNROLL) * (64 * EMD_UNROLL);
-        const size_t lds = (size_t)npad * 7 * sizeof(float);
-        static size_t raised = 0;                      // largest dynamic LDS size the kernel has been allowed so far
-        if (lds > raised) {
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(emd_auction_local_kernel),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const bool grid = n <= EMD_GRID_MAX && n >= 64 && !emd_env_flag("VPN_EMD_NOGRID");     // pruned Bid scan
+        const void* kern = grid ? reinterpret_cast<const void*>(emd_auction_grid_kernel)
+                                : reinterpret_cast<const void*>(emd_auction_local_kernel);
+        const size_t lds = (size_t)npad * (grid ? 12 : 7) * sizeof(float);
+        static size_t raised[2] = {0, 0};              // largest dynamic LDS size each kernel has been allowed so far
+        if (lds > raised[grid]) {
+            const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return (int)e;
-            raised = lds;
+            raised[grid] = lds;
         }
-        int G = emd_group_size_of(reinterpret_cast<const void*>(emd_auction_local_kernel), lds, B, n, max_group);
+        int G = emd_group_size_of(kern, lds, B, n, max_group);
         if (G > 1) {
             void* args[] = {(void*)&xyz1, (void*)&xyz2, (void*)&B, (void*)&n, (void*)&npad, (void*)&G, (void*)&eps, (void*)&iters,
                             (void*)&dist, (void*)&assignment, (void*)&wsf, (void*)&counters};
-            vpn::prof_begin("emd_auction_local_kernel", s);
-            const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(emd_auction_local_kernel),
-                                                            dim3((B + 7) / 8 * 8 * G), dim3(EMD_THREADS), args, (unsigned)lds, s);
+            vpn::prof_begin(grid ? "emd_auction_grid_kernel" : "emd_auction_local_kernel", s);
+            const hipError_t e = hipLaunchCooperativeKernel(kern, dim3((B + 7) / 8 * 8 * G), dim3(EMD_THREADS), args, (unsigned)lds, s);
             vpn::prof_end(s);
             if (e == hipSuccess) return 0;
             (void)hipGetLastError();
             if (e != hipErrorCooperativeLaunchTooLarge && e != hipErrorNotSupported && e != hipErrorInvalidConfiguration) return (int)e;
             G = 1;
         }
-        VPN_LAUNCH(emd_auction_local_kernel, dim3((B + 7) / 8 * 8 * G), dim3(EMD_THREADS), lds, s, xyz1, xyz2, B, n, npad, G, eps,
-                   iters, dist, assignment, wsf, counters);
+        if (grid)
+            VPN_LAUNCH(emd_auction_grid_kernel, dim3((B + 7) / 8 * 8 * G), dim3(EMD_THREADS), lds, s, xyz1, xyz2, B, n, npad, G, eps,
+                       iters, dist, assignment, wsf, counters);
+        else
+            VPN_LAUNCH(emd_auction_local_kernel, dim3((B + 7) / 8 * 8 * G), dim3(EMD_THREADS), lds, s, xyz1, xyz2, B, n, npad, G, eps,
+                       iters, dist, assignment, wsf, counters);
         VPN_LAUNCH_CHECK();
         return 0;
     }
