@@ -4,8 +4,13 @@
  *
  * Conventions:
  *  - every pointer is DEVICE memory owned by the caller (outputs and workspaces
- *    included); the library allocates nothing and keeps no global state
- *    (contrast: the reference's module-global renderer, vertex_renderer.py:7,18);
+ *    included); the library allocates no device memory and keeps no state that a
+ *    RESULT depends on (contrast: the reference's module-global renderer,
+ *    vertex_renderer.py:7,18).  What it does keep per process: the optional launch
+ *    profiler's event list (vpn_profile_enable/read), two "dynamic LDS limit
+ *    already raised" marks and the cached VPN_CHAMFER_MODE / VPN_CHAMFER_R
+ *    environment overrides -- one process per GPU is the intended deployment,
+ *    several host threads driving one library instance are not supported;
  *  - all tensors are contiguous fp32 unless stated, indices are int32;
  *  - `stream` is a hipStream_t passed as void*; kernels are only enqueued, no
  *    entry point synchronises with the host (the reference syncs through

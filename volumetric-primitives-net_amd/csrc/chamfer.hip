@@ -1053,10 +1053,13 @@ struct ScanJob {          // one direction of a Chamfer call
 template <int PREC>   // 0: fp32-input MFMA (shares the fp32 vector datapath), 1: bf16 3-piece split on the matrix pipe
 // 6 waves per SIMD: the tile loop needs ~70 VGPRs and LDS admits 3 workgroups of 8 waves per CU; the bound keeps the
 // fix-up tail (which few workgroups run) from raising the whole kernel's register allocation
+#ifndef CM_WAVES_PER_EU
+#define CM_WAVES_PER_EU 6
+#endif
 #ifdef CM_EXP_NOBOUND
 __global__ __launch_bounds__(cm_block<PREC>()) void chamfer_nn_mfma_kernel(
 #else
-__global__ __launch_bounds__(cm_block<PREC>(), PREC == 1 ? 5 : 6) void chamfer_nn_mfma_kernel(
+__global__ __launch_bounds__(cm_block<PREC>(), PREC == 1 ? 5 : CM_WAVES_PER_EU) void chamfer_nn_mfma_kernel(
 #endif
     const ScanJob j0, const ScanJob j1, int nsamples) {
     const bool other = (int)blockIdx.x >= j0.G;
@@ -1181,6 +1184,19 @@ __global__ __launch_bounds__(cm_block<PREC>(), PREC == 1 ? 5 : 6) void chamfer_n
             const int nblk = min(CM_TILE16, Ntp - t0) >> 5;          // 2, 4, 6 or 8 (Ntp is a multiple of 64)
             const unsigned char* T = &tileH[buf][jq * CM_ROWB + half * 16];
             const float before = best;
+#ifdef CM_EXP_NO_PINGPONG
+            float4 a0 = rd(T, 0), a1 = rd(T, 1);
+            CM_PAIR(a0, a1, 0)
+            if (nblk > 2) {
+                a0 = rd(T, 2); a1 = rd(T, 3);
+                CM_PAIR(a0, a1, 1)
+                if (nblk > 4) {
+                    a0 = rd(T, 4); a1 = rd(T, 5);
+                    CM_PAIR(a0, a1, 2)
+                    if (nblk > 6) { a0 = rd(T, 6); a1 = rd(T, 7); CM_PAIR(a0, a1, 3) }
+                }
+            }
+#else
             float4 a0 = rd(T, 0), a1 = rd(T, 1), b0 = rd(T, 2), b1 = rd(T, 3);
             CM_PAIR(a0, a1, 0)
             if (nblk > 2) {
@@ -1192,6 +1208,7 @@ __global__ __launch_bounds__(cm_block<PREC>(), PREC == 1 ? 5 : 6) void chamfer_n
                     if (nblk > 6) CM_PAIR(b0, b1, 3)
                 }
             }
+#endif
             blk = best < before ? t0 + (blkc << 6) : blk;            // the tile improved this lane's minimum
             if (more) stash(buf ^ 1, pre);
             __syncthreads();

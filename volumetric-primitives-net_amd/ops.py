@@ -23,7 +23,22 @@ def _f32c(t):
     return t.contiguous().float()          # emd_module.py:41-42 does the same to its inputs
 
 
-_KINDS_OK = set()      # (data_ptr, version, numel) of device kind tensors whose contents have been validated
+import weakref
+
+# device kind tensors whose contents have been validated: id(tensor) -> (weak reference to it, the version counter it
+# had then).  The entry dies with its tensor (weakref callback) and a hit also requires the reference to be the same
+# object, so a later tensor that reuses the id or the device address is never mistaken for a validated one.
+_KINDS_OK = {}
+
+
+def _kinds_known(t):
+    hit = _KINDS_OK.get(id(t))
+    return hit is not None and hit[0]() is t and hit[1] == t._version
+
+
+def _kinds_remember(t):
+    key = id(t)
+    _KINDS_OK[key] = (weakref.ref(t, lambda _r, key=key: _KINDS_OK.pop(key, None)), t._version)
 
 
 def _check_kinds(kinds):
@@ -34,24 +49,21 @@ def _check_kinds(kinds):
 
 def kinds_tensor(kinds, device):
     """int32 device tensor of primitive kinds; rejects cones (sampling.py:39-45 is `pass`).  A tensor already on
-    the device is validated once (one host copy the first time that storage / version is seen: kind tensors are
-    made once per run) so that an unknown kind never reaches a kernel."""
+    the device is validated once per (tensor object, version) -- one host copy the first time: kind tensors are made
+    once per run -- so that an unknown kind never reaches a kernel."""
     device = torch.device(device)
     if isinstance(kinds, torch.Tensor):
         if kinds.device.type == device.type and kinds.dtype == torch.int32 and kinds.is_contiguous():
-            key = (kinds.data_ptr(), kinds._version, kinds.numel())
-            if key not in _KINDS_OK:
+            if not _kinds_known(kinds):
                 _check_kinds(kinds.detach().cpu().tolist())
-                if len(_KINDS_OK) > 4096:
-                    _KINDS_OK.clear()
-                _KINDS_OK.add(key)
+                _kinds_remember(kinds)
             return kinds
         kinds = kinds.detach().cpu().tolist()
     kinds = [int(k) for k in kinds]
     _check_kinds(kinds)
     t = torch.tensor(kinds, dtype=torch.int32, device=device)
     if t.is_cuda:
-        _KINDS_OK.add((t.data_ptr(), t._version, t.numel()))
+        _kinds_remember(t)
     return t
 
 
