@@ -789,7 +789,9 @@ def test_hot_path_random_shapes_equal_module_composition(vpn):
         shape = (case, B, K, n, M, H, W)
         assert rel_err(out[2].detach().cpu(), tot.detach().cpu()) <= 1e-5, shape
         assert rel_err(out[0].detach().cpu(), img[0].detach().cpu()) <= 1e-5, shape
-        assert rel_err(pg.grad.cpu(), pm.grad.cpu()) <= 2e-5, shape
+        # two GPU paths with different roundings (the fused backward recovers the canonical coefficient from the stored
+        # point, the module path redraws it): half of the 1e-4 contract each of them owes the oracle
+        assert rel_err(pg.grad.cpu(), pm.grad.cpu()) <= 5e-5, shape
 
 
 def test_hot_path_large_gt_cloud_falls_back(vpn):

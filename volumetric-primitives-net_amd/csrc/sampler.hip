@@ -47,12 +47,28 @@ __device__ inline void cuboid_quota(const float v[3], int n, int cum[7]) {
 // canonical coefficient c with p_c = c * v  (unit sphere point, or unit box point snapped to a face)
 __device__ inline void canonical_coeff(const PrimLds& P, int p, const float u[3], float c[3]) {
     if (P.kind == VPN_SPHERE) {
+#ifdef SAMP_REFERENCE_TRIG
         float elev = -acosf(1.0f - 2.0f * u[0]) + VPN_PI * 0.5f;   // sphere.py:26
         float azim = u[1] * 2.0f * VPN_PI;                          // sphere.py:27
         float ce = cosf(elev);
         c[0] = ce * sinf(azim);                                     // sphere.py:38-40
         c[1] = sinf(elev);
         c[2] = ce * cosf(azim);
+#else
+        // sphere.py:26, :38-40: elev = -acos(w) + pi/2 with w = 1 - 2 u0, then sin(elev) and cos(elev): in closed form
+        // sin(elev) = w and cos(elev) = sqrt(1 - w^2) = 2 sqrt(u0 (1 - u0)) -- no acos, no sin, no cos (three of the five
+        // transcendental calls of a point: the kernel is bound by instruction issue).  The reference's own chain carries
+        // the rounding of pi/2 - acos(w) (6e-8 absolute in the angle); the closed form is within that of it, i.e. 1e-7
+        // of a coefficient that is then scaled by the primitive's extent (the parity bar is 1e-4).
+        const float w = 1.0f - 2.0f * u[0];
+        const float ce = 2.0f * sqrtf(u[0] * (1.0f - u[0]));
+        const float azim = u[1] * 2.0f * VPN_PI;                    // sphere.py:27
+        float sa, ca;
+        sincosf(azim, &sa, &ca);                                    // one range reduction for both
+        c[0] = ce * sa;                                             // sphere.py:38-40
+        c[1] = w;
+        c[2] = ce * ca;
+#endif
     } else {
         c[0] = -1.0f + 2.0f * u[0];                                 // cuboid.py:66
         c[1] = -1.0f + 2.0f * u[1];
@@ -97,14 +113,16 @@ __device__ inline void sample_wg(PrimLds& P, float* red, int b, int k,
     const float* prm = params + ((size_t)b * K + k) * VPN_PARAM_STRIDE;
     if (threadIdx.x == 0) load_prim(P, prm, kinds[k], n);
     // the training step renders the same primitives: their raster records (pose, ray coefficients, culling conic) are
-    // written here by the second wave while the first one computes the sampler's pose -- one launch less per step
-    if (rp.rec && threadIdx.x == 64) {
-        float4 r[R_REC];
-        make_record(prm, kinds[k] == VPN_SPHERE ? VPN_SPHERE : VPN_CUBOID, rp.cam, b, rp.H, rp.W, rp.sigma, r);
-        float4* out = rp.rec + ((size_t)b * K + k) * R_REC;
-#pragma unroll
-        for (int i = 0; i < R_REC; ++i) out[i] = r[i];
-    }
+    // written by this launch -- one launch less per step.  The record lane (first lane of the second wave) makes the
+    // camera while the pose lane makes the pose (two chains of sin / cos side by side in front of the barrier), and
+    // finishes the record from both after it, while the other waves are already sampling.
+    Camera C;
+#ifndef SAMP_EXP_NOREC
+    const bool rec_lane = rp.rec && threadIdx.x == 64;
+#else
+    const bool rec_lane = false;
+#endif
+    if (rec_lane) C = make_camera(rp.cam + b * 3);
     // head of the loss workspace: the arrival counter is zeroed, the Philox seed this step really uses is kept (the
     // backward reads it from there: the caller's device counter may have advanced by then); per sample: tile counter
     if (rp.zero_me && k == 0) {
@@ -113,6 +131,13 @@ __device__ inline void sample_wg(PrimLds& P, float* red, int b, int k,
         if (threadIdx.x == 131) rp.zero_me[4 + 4 * b + 3] = 0;
     }
     __syncthreads();
+    if (rec_lane) {
+        float4 r[R_REC];
+        make_record_from(C, P.pose, prm, kinds[k] == VPN_SPHERE ? VPN_SPHERE : VPN_CUBOID, rp.H, rp.W, rp.sigma, r);
+        float4* out = rp.rec + ((size_t)b * K + k) * R_REC;
+#pragma unroll
+        for (int i = 0; i < R_REC; ++i) out[i] = r[i];
+    }
     const float tx = prm[7], ty = prm[8], tz = prm[9];
     const float* ub = u ? u + ((size_t)b * K + k) * n * 3 : nullptr;
     float* out = points + ((size_t)b * K + k) * n * 3;
@@ -136,7 +161,9 @@ __device__ inline void sample_wg(PrimLds& P, float* red, int b, int k,
             pz = (R.m[2][0] * x + R.m[2][1] * y + R.m[2][2] * z) + tz;
         }
         st3(out + p * 3, px, py, pz);
+#ifndef SAMP_EXP_NOFEAT
         if (feat) nv = fmaxf(nv, feat_point(*feat, b, k * n + p, px, py, pz));
+#endif
     }
     if (feat) {
         // the last primitive's workgroup also writes the padding rows [N, Np) of the sample (fewer than 64)
@@ -154,9 +181,11 @@ __global__ __launch_bounds__(SAMP_BLOCK) void sample_fwd_kernel(
     sample_wg(P, nullptr, blockIdx.y, blockIdx.x, params, kinds, u, seed, sample_base, K, n, points, rp, nullptr);
 }
 
-// Forward launch of the training step with the Chamfer features inside: 1-D grid of B * (K + gt.ysplit) workgroups
-// decoded like the feature kernel's (sample b on XCD b / (B/8)): slices [0, K) are the sampler's workgroups (primitive =
-// slice, also the slot of the max norm: K <= CFEAT_SLOTS), slices [K, K + gt.ysplit) convert the ground-truth cloud.
+// Forward launch of the training step with the Chamfer features inside: 1-D grid of B * K workgroups decoded like the
+// feature kernel's (sample b on XCD b / (B/8)): workgroup (b, k) samples primitive k (also the slot of its max norm:
+// K <= CFEAT_SLOTS) and then converts slice k of the K slices of the ground-truth cloud (64 points at C3).  The
+// ground-truth slices used to be workgroups of their own: 2560 workgroups of 4 waves are 1.25 rounds of the 8192
+// resident wave slots, 2048 are exactly one.
 __global__ __launch_bounds__(SAMP_BLOCK) void sample_feat_fwd_kernel(
     const float* __restrict__ params, const int32_t* __restrict__ kinds, const float* __restrict__ u,
     uint64_t seed, const uint64_t* __restrict__ seed_dev, uint64_t sample_base, int B, int K, int n,
@@ -167,8 +196,11 @@ __global__ __launch_bounds__(SAMP_BLOCK) void sample_feat_fwd_kernel(
     if (seed_dev) seed += *seed_dev;
     int b, sy;
     feat_decode(blockIdx.x, B, b, sy);
-    if (sy < K) sample_wg(P, red, b, sy, params, kinds, u, seed, sample_base, K, n, points, rp, &pred);
-    else feat_slice(gt, b, sy - K, red);
+    sample_wg(P, red, b, sy, params, kinds, u, seed, sample_base, K, n, points, rp, &pred);
+#ifndef SAMP_EXP_NOGT
+    __syncthreads();                                   // `red` of the sampled cloud's slice has been read
+    feat_slice(gt, b, sy, red);
+#endif
 }
 
 __global__ __launch_bounds__(SAMP_BLOCK) void sample_bwd_kernel(
@@ -710,7 +742,8 @@ extern "C" int vpn_hotpath_sample_fwd(const float* params, const int32_t* kinds,
     int rc = chamfer_feat_jobs(chamfer_ws, chamfer_ws_bytes, B, K * n, M, points, gt_points, &pred, &gt);
     if (rc) return rc;
     pred.ysplit = K;                      // one slice (and one max-norm slot) per primitive
-    VPN_LAUNCH(sample_feat_fwd_kernel, dim3((unsigned)B * (unsigned)(K + gt.ysplit)), dim3(SAMP_BLOCK), 0, (hipStream_t)stream,
+    gt.ysplit = K;                        // ... and the same workgroups share the ground-truth cloud
+    VPN_LAUNCH(sample_feat_fwd_kernel, dim3((unsigned)B * (unsigned)K), dim3(SAMP_BLOCK), 0, (hipStream_t)stream,
                params, kinds, u, seed, seed_dev, sample_base, B, K, n, points, rp, pred, gt);
     VPN_LAUNCH_CHECK();
     return 0;

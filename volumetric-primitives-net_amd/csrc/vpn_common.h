@@ -41,6 +41,9 @@ struct Pose {          // everything derived from q (B,4) that fwd and bwd need
 
 // modules/transform/rotate.py:59-72 (refine_quaternions) + :28-46 (get_rotation_matrices)
 __device__ inline Pose make_pose(float q0, float q1, float q2, float q3) {
+    // every operation rounded by itself: the pose must come out the same bit for bit wherever this is inlined (the
+    // sampler's pose lane, the record kernels, the backward), whatever the compiler would contract in that context
+#pragma clang fp contract(off)
     Pose p;
     float r = q3 - floorf(q3);                 // torch `% 1` == remainder (sign of divisor)
     float h = ((r * 2.0f) * VPN_PI) / 2.0f;    // rotate.py:63

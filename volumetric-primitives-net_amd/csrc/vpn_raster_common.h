@@ -25,6 +25,7 @@ struct Camera {
 
 // look-at camera of vertex_renderer.py:18 (set_look_at_parameters([azim],[elev],[dist]), degrees)
 __device__ inline Camera make_camera(const float* cam) {
+#pragma clang fp contract(off)            // same bits wherever it is inlined (see make_pose)
     Camera C;
     const float d = cam[0];
     const float el = cam[1] * 0.017453292519943295f, az = cam[2] * 0.017453292519943295f;
@@ -48,6 +49,7 @@ struct PrimGeo {   // per-primitive quantities that do not depend on the pixel
 };
 
 __device__ inline void prim_geometry(const Camera& C, const Mat3& R, const float* v, const float* t, PrimGeo& G) {
+#pragma clang fp contract(off)
     float e[3] = {C.eye[0] - t[0], C.eye[1] - t[1], C.eye[2] - t[2]};
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -61,12 +63,23 @@ __device__ inline void prim_geometry(const Camera& C, const Mat3& R, const float
 
 // Record of one primitive for one camera: out[0..3] = (o~|kind, Mr, Mu, Mf) so that d~ = Mf + px Mr + py Mu;
 // out[4] = pixel bounding box of the culling ellipse (jmin, jmax, imin, imax as int bits); out[5..6] = its conic.
+// ... from a camera and a pose that already exist (the sampler's forward launch: its pose lane has made the pose, the
+// record lane the camera, side by side; both come from make_camera / make_pose, so the record is the same bit for bit)
+__device__ inline void make_record_from(const Camera& C, const Pose& P, const float* __restrict__ prm, int kind, int H, int W,
+                                        float sigma, float4 out[R_REC]);
+
 __device__ inline void make_record(const float* __restrict__ prm, int kind, const float* __restrict__ cam, int b, int H,
                                    int W, float sigma, float4 out[R_REC]) {
     const Camera C = make_camera(cam + b * 3);
+    const Pose P = make_pose(prm[3], prm[4], prm[5], prm[6]);
+    make_record_from(C, P, prm, kind, H, W, sigma, out);
+}
+
+__device__ inline void make_record_from(const Camera& C, const Pose& P, const float* __restrict__ prm, int kind, int H, int W,
+                                        float sigma, float4 out[R_REC]) {
+#pragma clang fp contract(off)            // the record does not depend on which kernel builds it
     float v[3] = {prm[0], prm[1], prm[2]};
     float t[3] = {prm[7], prm[8], prm[9]};
-    Pose P = make_pose(prm[3], prm[4], prm[5], prm[6]);
     PrimGeo G;
     prim_geometry(C, P.R, v, t, G);
     // out[7..13]: camera basis and pose as the finishing step of the backward needs them (it used to redo the six
