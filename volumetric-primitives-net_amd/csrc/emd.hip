@@ -80,7 +80,7 @@ __device__ inline bool emd_group_sync(unsigned* counter, unsigned& passed, int G
     // -DEMD_STRICT_ORDER: release / acquire on the counter, i.e. the form the HIP memory model asks for (the compiler
     // adds an L2 write-back before the add and an invalidate after the load: ~70 us per barrier, G > 1 then loses to
     // G = 1).  The default relies on the hardware argument above: all shared state is sc1-accessed and acknowledged.
-#ifdef EMD_STRICT_ORDER
+#if defined(EMD_STRICT_ORDER) || defined(VPN_STRICT_ORDER)
     constexpr int EMD_ADD_ORDER = __ATOMIC_RELEASE, EMD_POLL_ORDER = __ATOMIC_ACQUIRE;
 #else
     constexpr int EMD_ADD_ORDER = __ATOMIC_RELAXED, EMD_POLL_ORDER = __ATOMIC_RELAXED;

@@ -353,6 +353,15 @@ __device__ inline float sign0(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1
 //   losses[4] = (silhouette loss, depth loss, w_cd mean_b cd_b + w_sil [0] + w_dep [1], mean_b cd_b).
 // Hand-off form (MI355X guide, inter-workgroup visibility): payload stored write-through (sc1), the storing wave
 // drains (vmcnt(0)), ONE agent-scope add per workgroup, the last adder reads the payload with sc1 loads.
+// -DVPN_STRICT_ORDER: the two arrival adds carry acquire-release semantics at agent scope, i.e. the form the HIP memory
+// model asks for (the compiler puts an L2 write-back in front of the add and an L1 invalidate behind it); the default
+// relies on the hardware argument above, which the guide lists as a valid form but not as an architectural guarantee.
+#ifdef VPN_STRICT_ORDER
+#define VPN_ARRIVE_ORDER __ATOMIC_ACQ_REL
+#else
+#define VPN_ARRIVE_ORDER __ATOMIC_RELAXED
+#endif
+
 struct FinArgs {
     int enabled = 0;
     int B = 0;
@@ -392,7 +401,7 @@ __device__ inline void finalize_sample(const FinArgs& fin, const LossArgs& la, i
         __hip_atomic_store(ps + 1, a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(ps + 2, cd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        old = __hip_atomic_fetch_add(fin.gcounter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        old = __hip_atomic_fetch_add(fin.gcounter, 1, VPN_ARRIVE_ORDER, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (__builtin_amdgcn_readfirstlane(old) != fin.B - 1) return;
     // every sample is complete
@@ -686,7 +695,7 @@ __global__ __launch_bounds__(64, R_TOTAL_WAVES) void raster_total_kernel(const f
                            (unsigned long long)__float_as_uint(lsil) | ((unsigned long long)__float_as_uint(ldep) << 32),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        arrived = __hip_atomic_fetch_add(reinterpret_cast<int*>(fin.persample + T.b) + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        arrived = __hip_atomic_fetch_add(reinterpret_cast<int*>(fin.persample + T.b) + 3, 1, VPN_ARRIVE_ORDER, __HIP_MEMORY_SCOPE_AGENT);
     }
     tile_backward(T, rec_b, nullptr, words, K, ntile, H, W, srec, words == 1, m0, inv_sigma, inv_gamma, zref, P, zbar, invS,
                   gAtot, gZbar, partial);
