@@ -50,6 +50,15 @@ def test_argument_validation_needs_no_gpu():
     assert L.vpn_raster_bwd_workspace(2, 3, 32, 32) == 2 * 4 * 3 * 12 * 4
     assert L.vpn_raster_bwd_workspace(0, 3, 32, 32) == 0
     assert L.vpn_raster_loss_workspace(2, 32, 32) == 16 + 2 * 16 + 2 * 4 * 2 * 4
+    # round-3 entry points: the fused raster + finalisation and the triangle-mesh path
+    assert L.vpn_raster_total_fwd_fin(None, None, None, 1, 1, 8, 8, 0.1, 0.1, 2.0, None, None, 0, 1.0, 1.0, None, None, None, 0,
+                                      None, 0, 0, 0, 1.0, 1.0, 1.0, None, None, None, None) == -1
+    assert L.vpn_mesh_raster_fwd(None, None, None, 1, 3, 1, 8, 8, 1e-4, None, None, None) == -1
+    assert L.vpn_mesh_raster_bwd(None, None, None, 1, 3, 1, 8, 8, 1e-4, None, None, None, None, None) == -1
+    assert L.vpn_mesh_sample_fwd(None, None, None, 0, 0, 1, 3, 1, 8, None, None, None, None, None) == -1
+    assert L.vpn_mesh_sample_bwd(None, None, None, None, 1, 3, 1, 8, None, None) == -1
+    assert L.vpn_mesh_raster_workspace(2, 10) == 2 * 10 * (16 + 8) and L.vpn_mesh_raster_workspace(0, 10) == 0
+    assert L.vpn_emd_workspace(2, 100) == 2 * 100 * 10 * 4 + 16
     assert b'null pointer' in L.vpn_error_string(-1)
     with pytest.raises(RuntimeError):
         lib.check(-2)
@@ -76,8 +85,12 @@ def test_no_cpu_fallback():
 def test_reference_surface_is_mirrored():
     """Names / argument order of the reference call sites."""
     import vpn_amd
-    from vpn_amd.modules import sampling, loss, render, transform
+    from vpn_amd.modules import sampling, loss, render, transform, meshing
     sig = inspect.signature
+    # kaolin's TriangleMesh as train_sphere.py:50-78 uses it
+    for name in ('from_obj', 'cuda', 'sample', 'vertices', 'faces'):
+        assert hasattr(meshing.TriangleMesh(torch.zeros(3, 3), torch.zeros(1, 3, dtype=torch.int64)), name) or hasattr(meshing.TriangleMesh, name)
+    assert list(sig(meshing.TriangleMesh.sample).parameters)[:2] == ['self', 'num_samples']
     assert list(sig(sampling.Sampling.sphere_sampling).parameters)[:4] == ['v', 'q', 't', 'num_points']
     assert list(sig(sampling.Sampling.cuboid_sampling).parameters)[:4] == ['v', 'q', 't', 'num_points']
     assert sig(sampling.Sampling.sphere_sampling).parameters['num_points'].default == 1000
