@@ -35,3 +35,29 @@ def test_training_step_composes_and_learns():
         opt.step()
         history.append(float(total.detach()))
     assert history[-1] < 0.9 * history[0], history
+
+
+@pytest.mark.gpu
+def test_train_sphere_step_composes_and_learns():
+    """train_sphere.py:104-134 through the drop-in surface (examples/train_sphere_step.py): template meshes deformed in
+    place by a stand-in network, sampled, Chamfer + silhouette losses on the TRIANGLE path, backward, Adam: gradients
+    reach every parameter and a few steps reduce the loss.  BASELINE config C1 sizes (batch 4, 64 x 64)."""
+    import train_sphere_step as T
+    dev = torch.device('cuda')
+    torch.manual_seed(11)
+    import vpn_amd
+    vpn_amd.TriangleMesh._calls = 0                     # the sample draws are keyed by a per-process call counter
+    batch = T.make_batch(4, 2048, 64, dev, seed=5)
+    net = T.Offsets(64, 288).to(dev)
+    opt = torch.optim.Adam(net.parameters(), lr=3e-3)
+    history = []
+    for it in range(15):
+        opt.zero_grad()
+        total, parts = T.training_losses(net, *batch, 1024, 1.0)
+        total.backward()
+        if it == 0:
+            for name, p in net.named_parameters():
+                assert p.grad is not None and bool(torch.isfinite(p.grad).all()) and float(p.grad.abs().max()) > 0, name
+        opt.step()
+        history.append(float(total.detach()))
+    assert history[-1] < 0.9 * history[0], history
