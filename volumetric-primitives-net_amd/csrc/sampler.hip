@@ -275,7 +275,10 @@ __global__ __launch_bounds__(SAMP_BLOCK) void sample_bwd_kernel(
 // the forward pass used (recomputed from the same uniforms / Philox counter).  Fixed summation order: bitwise
 // reproducible, unlike the LDS-atomic scatter of chamfer_bwd_lds_kernel.  Replaces that kernel (one workgroup
 // per sample) plus sample_bwd_kernel and the [B,N,3] gradient between them.
-__global__ __launch_bounds__(SAMP_BLOCK) void sample_chamfer_bwd_kernel(
+#ifndef SCB_WAVES
+#define SCB_WAVES 6
+#endif
+__global__ __launch_bounds__(SAMP_BLOCK, SCB_WAVES) void sample_chamfer_bwd_kernel(
     const float* __restrict__ params, const int32_t* __restrict__ kinds, const float* __restrict__ u,
     uint64_t seed, const uint64_t* __restrict__ seed_dev, uint64_t sample_base, int K, int n,
     const float* __restrict__ points, const float* __restrict__ gt, int M, const float* __restrict__ dist1, const int32_t* __restrict__ idx1,
