@@ -283,3 +283,39 @@ def test_meshing_made_mesh_renders_the_same_silhouette_through_both_paths(vpn):
     _, a_mv, _ = vpn.VertexRenderer.render(meshes, 1.0, 0.0, 0.0, image_size=(H, W))
     cx = lambda im: (im * torch.arange(W, device=im.device)[None, None, :]).sum((1, 2)) / im.sum((1, 2))
     assert bool((cx(a_mv[..., 0]) > cx(a_tri[..., 0]) + 10).all())
+
+
+@pytest.mark.gpu
+def test_mesh_lists_of_mixed_topology_and_a_large_mesh(vpn):
+    """(a) a list whose meshes differ in topology renders group by group and comes back in list order, equal to the
+    single renders; (b) a composed mesh of the C5 size (64 primitives x 128 vertices / 252 faces = 8192 vertices,
+    16128 faces: 252 passes over the face list per tile) against the oracle."""
+    dev = torch.device(DEV)
+    va, fa = icosphere(1, 0.25)
+    vb, fb = icosphere(0, 0.2)
+    ma = vpn.TriangleMesh(va.to(dev), fa.to(dev))
+    mb = vpn.TriangleMesh((vb + torch.tensor([0.1, 0.0, 0.0])).to(dev), fb.to(dev))
+    mc = vpn.TriangleMesh((va * 0.7).to(dev), fa.to(dev))
+    H = W = 48
+    _, alpha, normals = vpn.VertexRenderer.render([ma, mb, mc], 1.0, torch.tensor([0.0, 10.0, -5.0]), 30.0, image_size=(H, W))
+    assert alpha.shape == (3, H, W, 1) and isinstance(normals, list) and normals[1].shape == (fb.shape[0], 3)
+    for i, (m, el) in enumerate(((ma, 0.0), (mb, 10.0), (mc, -5.0))):
+        _, a1, _ = vpn.VertexRenderer.render(m, 1.0, el, 30.0, image_size=(H, W))
+        assert torch.equal(a1[0], alpha[i])
+    ref = O.mesh_raster(vb[None] + torch.tensor([0.1, 0.0, 0.0]), fb, torch.tensor([[1.0, 10.0, 30.0]]), H, W, vpn.config.MESH_RASTER_SIGMA)
+    assert float((alpha[1, :, :, 0].cpu() - ref[0]).abs().max()) <= 2e-5
+    # (b)
+    gen = torch.Generator().manual_seed(8)
+    K = 64
+    v = (torch.rand(1, K, 3, generator=gen) + 0.1) / torch.tensor([8.0, 10.0, 10.0])
+    params = torch.cat([v, torch.rand(1, K, 4, generator=gen), 0.35 * (torch.rand(1, K, 3, generator=gen) * 2 - 1)], 2)
+    verts, faces = vpn.Meshing.mesh_primitives(params.to(dev), [0] * K)
+    assert verts.shape == (1, 8192, 3) and faces.shape == (16128, 3)
+    big = vpn.TriangleMesh(verts[0].detach().clone().requires_grad_(True), faces)
+    loss = vpn.SilhouetteLoss()([big], torch.zeros(1, 1, 64, 64, device=dev), torch.ones(1), torch.zeros(1), torch.zeros(1))
+    loss.backward()
+    vc = verts.detach().cpu().clone().requires_grad_(True)
+    a = O.mesh_raster(vc, faces.cpu(), torch.tensor([[1.0, 0.0, 0.0]]), 64, 64, vpn.config.MESH_RASTER_SIGMA)
+    a.abs().mean().backward()
+    assert abs(float(loss.detach()) - float(a.detach().mean())) / float(a.detach().mean()) <= 1e-4
+    assert rel_err(big.vertices.grad.cpu(), vc.grad[0]) <= 2e-4

@@ -16,6 +16,7 @@ LIB = os.path.join(HERE, 'libvpn_hip.so')
 SOURCES = ['vpn_api.hip', 'sampler.hip', 'chamfer.hip', 'raster.hip', 'emd.hip', 'head.hip', 'mesh.hip']
 COMMON = ['-O3', '--offload-arch=gfx950', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function']
 COMMON += os.environ.get('VPN_EXTRA_FLAGS', '').split()      # experiments only (e.g. -DVPN_CHAMFER_DEBUG)
+RASTER_EXTRA = os.environ.get('VPN_RASTER_FLAGS', '').split()  # experiments only: extra flags for raster.hip alone
 PER_FILE = {
     # index-exact argmin: correctly rounded sqrt (hipcc default) and no contraction (also a pragma in the file)
     # -amdgpu-mfma-vgpr-form: MFMA results straight into VGPRs (no v_accvgpr_read copies before the min-tree)
@@ -25,7 +26,7 @@ PER_FILE = {
     # the raster is compared with a 1e-4 tolerance: 1-ulp v_rcp/v_sqrt instead of the IEEE sequences
     # -fgpu-flush-denormals-to-zero: no denormal-safe scaling around v_rcp / v_sqrt / v_exp
     # -fno-slp-vectorize: packed fp32 is half rate here and the packing costs v_mov shuffles and 25 VGPRs
-    'raster.hip': ['-fno-hip-fp32-correctly-rounded-divide-sqrt', '-fgpu-flush-denormals-to-zero', '-fno-slp-vectorize'],
+    'raster.hip': ['-fno-hip-fp32-correctly-rounded-divide-sqrt', '-fgpu-flush-denormals-to-zero', '-fno-slp-vectorize'] + RASTER_EXTRA,
 }
 
 
