@@ -52,7 +52,7 @@ def test_argument_validation_needs_no_gpu():
     assert L.vpn_raster_loss_workspace(2, 32, 32) == 16 + 2 * 16 + 2 * 4 * 2 * 4
     # round-3 entry points: the fused raster + finalisation and the triangle-mesh path
     assert L.vpn_raster_total_fwd_fin(None, None, None, 1, 1, 8, 8, 0.1, 0.1, 2.0, None, None, 0, 1.0, 1.0, None, None, None, 0,
-                                      None, 0, 0, 0, 1.0, 1.0, 1.0, None, None, None, None) == -1
+                                      None, 0, 0, 0, 1.0, 1.0, 1.0, None, None, None, None, None) == -1
     assert L.vpn_mesh_raster_fwd(None, None, None, 1, 3, 1, 8, 8, 1e-4, None, None, None) == -1
     assert L.vpn_mesh_raster_bwd(None, None, None, 1, 3, 1, 8, 8, 1e-4, None, None, None, None, None) == -1
     assert L.vpn_mesh_sample_fwd(None, None, None, 0, 0, 1, 3, 1, 8, None, None, None, None, None) == -1

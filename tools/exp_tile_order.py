@@ -1,0 +1,55 @@
+"""Does a popcount-sorted launch order of the tiles shorten raster_total_kernel?  The masks of a first call are read
+back, the order is built on the host (per image: tiles by visible primitives, heaviest first) and the same call is timed
+with and without it (C3 shapes; kernel time from the library's launch profiler)."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import vpn_amd
+from vpn_amd import _lib
+from bench import synth_inputs
+dev = torch.device('cuda')
+B, K, H, W = int(os.environ.get('B', 64)), 32, 256, 256
+params, _ = synth_inputs(B, K, 8, 1234, dev)
+p2, _ = synth_inputs(B, K, 8, 4321, dev)
+kinds = vpn_amd.kinds_tensor([0] * K, dev)
+cam = torch.tensor([[1.0, 0.0, 0.0]], device=dev).expand(B, 3).contiguous()
+with torch.no_grad():
+    a2, d2 = vpn_amd.RasterFunction.apply(p2, kinds, cam, H, W, 0.05, 0.1, 2.0)
+gt_sil, gt_dep = (a2 > 0.5).float().contiguous(), d2.contiguous()
+L = _lib.lib()
+rec = torch.zeros((L.vpn_raster_records_size(B, K, H, W) // 4,), dtype=torch.float32, device=dev)
+lws = torch.zeros((L.vpn_raster_loss_workspace(B, H, W) // 4,), dtype=torch.float32, device=dev)
+ws = torch.zeros((L.vpn_raster_bwd_workspace(B, K, H, W) // 4,), dtype=torch.float32, device=dev)
+losses = torch.zeros(4, device=dev)
+
+
+def call(ready, order):
+    _lib.call('vpn_raster_total_fwd_fin', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(cam), B, K, H, W, 0.05, 0.1, 2.0, _lib.ptr(gt_sil),
+              _lib.ptr(gt_dep), 0, 1.0, 1.0, _lib.ptr(rec), _lib.ptr(lws), _lib.ptr(ws), ready, None, 0, 0, 0, 0.0, 0.0, 0.0, _lib.ptr(losses),
+              None, None, _lib.ptr(order) if order is not None else None, _lib.stream())
+
+
+call(0, None)
+torch.cuda.synchronize()
+ref = losses.clone()
+gref = ws.clone()
+ntile = 256
+masks = rec.view(torch.int64)[B * K * 14 * 2:][:B * ntile].cpu()
+pop = torch.tensor([bin(int(m) & ((1 << 64) - 1)).count('1') for m in masks.tolist()]).reshape(B, ntile)
+order = torch.argsort(pop, dim=1, descending=True, stable=True).to(torch.int16).contiguous().to(dev)      # uint16 values < 256
+
+
+def timed(ready, o, n=30):
+    for _ in range(3):
+        call(ready, o)
+    with _lib.KernelProfile() as kp:
+        for _ in range(n):
+            call(ready, o)
+    return {k: round(v[1] * 1e3, 2) for k, v in kp.summary().items()}
+
+
+print('position order (masks computed by the tile waves):', timed(0, None))
+print('position order, records ready (no record launch)  :', timed(1, None))
+print('popcount order, masks read                        :', timed(1, order))
+call(1, order)
+torch.cuda.synchronize()
+print('same losses:', bool(torch.equal(losses, ref)), ' same partials:', bool(torch.equal(ws, gref)))

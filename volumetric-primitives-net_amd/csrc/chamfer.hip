@@ -18,6 +18,7 @@
 //   minimum the wave re-scans the earlier targets with the sqrt compare.
 #include "vpn_common.h"
 #include "vpn_chamfer_feat.h"
+#include "vpn_raster_common.h"      // the tile-order rider of the training step (raster_order_wg)
 #include <stdlib.h>
 #include <string.h>
 
@@ -1061,7 +1062,19 @@ __global__ __launch_bounds__(cm_block<PREC>()) void chamfer_nn_mfma_kernel(
 #else
 __global__ __launch_bounds__(cm_block<PREC>(), PREC == 1 ? 5 : CM_WAVES_PER_EU) void chamfer_nn_mfma_kernel(
 #endif
-    const ScanJob j0, const ScanJob j1, int nsamples) {
+    const ScanJob j0, const ScanJob j1, int nsamples, const RasterOrderJob oj) {
+    // LDS of the fp16 filter's tiles, declared here because the rider below borrows it
+    __shared__ __attribute__((aligned(16))) unsigned char tileH16[PREC == 2 ? 2 * CM_TILE16 * CM_ROWB : 16];
+    if constexpr (PREC == 2) {
+        // Rider of the training step: the workgroups BEHIND the two scan jobs (the last to be dispatched, i.e. in the tail
+        // of the launch, where a third of the slots is idle) sort the raster's tiles, one image each.  The launch sits
+        // between the one that writes the raster records and the one that reads masks and order, so neither a hand-off
+        // nor a launch of its own is needed.
+        if ((int)blockIdx.x >= j0.G + j1.G) {
+            raster_order_wg<cm_block<PREC>()>(oj, (int)blockIdx.x - (j0.G + j1.G), tileH16);
+            return;
+        }
+    }
     const bool other = (int)blockIdx.x >= j0.G;
     const float* __restrict__ qpts = other ? j1.qpts : j0.qpts;
     const float* __restrict__ F = other ? j1.F : j0.F;
@@ -1121,7 +1134,7 @@ __global__ __launch_bounds__(cm_block<PREC>(), PREC == 1 ? 5 : CM_WAVES_PER_EU) 
     const f16v zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if constexpr (PREC == 2) {
         // ---- fp16 filter: ONE v_mfma_f32_32x32x16_f16 per 32x32 block (12 of 16 K slots used), rows of 32 bytes
-        __shared__ __attribute__((aligned(16))) unsigned char tileH[2][CM_TILE16 * CM_ROWB];      // LDS stride 48 B per row
+        unsigned char (*tileH)[CM_TILE16 * CM_ROWB] = reinterpret_cast<unsigned char (*)[CM_TILE16 * CM_ROWB]>(tileH16);   // [2][...], LDS stride 48 B per row
         const unsigned char* Hb = reinterpret_cast<const unsigned char*>(H) + (size_t)b * Ntp * CM_ROWB16;
         h8 bq;                                       // this lane's query: K slots [8 half, +8)
         {
@@ -1873,7 +1886,8 @@ static MfmaWs mfma_carve(float* F, int B, int Nt, int Nq) {
 // both directions: features of both clouds (one launch) -> filtered scan of p1 against p2 and of p2 against p1 with
 // the exact fix-up of the undecided queries inside (one launch)
 static int mfma_both(const float* p1, const float* p2, int B, int N, int M, float* ws, float* d1, int32_t* i1, float* d2,
-                     int32_t* i2, int prec, hipStream_t s, bool features_ready = false) {   // prec 0: fp32 MFMA, 1: bf16 x 3, 2: fp16 x 2
+                     int32_t* i2, int prec, hipStream_t s, bool features_ready = false,
+                     const RasterOrderJob* rider = nullptr) {   // prec 0: fp32 MFMA, 1: bf16 x 3, 2: fp16 x 2 (the only one with a rider)
     const bool fp32_filter = prec == 0;
     const MfmaWs w2 = mfma_carve(ws, B, M, N);                            // p2 = targets of direction 1
     const MfmaWs w1 = mfma_carve(ws + mfma_ws_floats(B, M, N), B, N, M);  // p1 = targets of direction 2
@@ -1894,12 +1908,14 @@ static int mfma_both(const float* p1, const float* p2, int B, int N, int M, floa
         const bool long_first = (long long)N > (long long)M;       // direction 2 scans the N targets: more work per workgroup
         const ScanJob& ja = long_first ? s2 : s1;
         const ScanJob& jb = long_first ? s1 : s2;
+        const RasterOrderJob none{};
         if (prec == 0)
-            VPN_LAUNCH(chamfer_nn_mfma_kernel<0>, dim3(ja.G + jb.G), dim3(CM_BLOCK), 0, s, ja, jb, B);
+            VPN_LAUNCH(chamfer_nn_mfma_kernel<0>, dim3(ja.G + jb.G), dim3(CM_BLOCK), 0, s, ja, jb, B, none);
         else if (prec == 1)
-            VPN_LAUNCH(chamfer_nn_mfma_kernel<1>, dim3(ja.G + jb.G), dim3(CM_BLOCK), 0, s, ja, jb, B);
+            VPN_LAUNCH(chamfer_nn_mfma_kernel<1>, dim3(ja.G + jb.G), dim3(CM_BLOCK), 0, s, ja, jb, B, none);
         else
-            VPN_LAUNCH(chamfer_nn_mfma_kernel<2>, dim3(ja.G + jb.G), dim3(CM_BLOCK16), 0, s, ja, jb, B);
+            VPN_LAUNCH(chamfer_nn_mfma_kernel<2>, dim3(ja.G + jb.G + (rider ? rider->B : 0)), dim3(CM_BLOCK16), 0, s, ja, jb, B,
+                       rider ? *rider : none);
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
     }
@@ -2114,4 +2130,40 @@ extern "C" int vpn_chamfer_fwd_ws(const float* p1, const float* p2, int B, int N
     int rc = pruned_nn(w1, w2, B, N, M, dist1, idx1, s);
     if (rc) return rc;
     return pruned_nn(w2, w1, B, M, N, dist2, idx2, s);
+}
+
+// vpn_chamfer_fwd_ws of the training step with the raster's tile order as a rider of the scan launch (modes 0 / 6 / 7
+// where the fp16 filter is taken: vpn_hotpath_fused_features).  records: as written by vpn_hotpath_sample_fwd earlier
+// on this stream; the tile masks inside them and tile_order [B][tiles] uint16 are written here.
+extern "C" size_t vpn_raster_order_size(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    const size_t ntile = (size_t)((W + R_TW - 1) / R_TW) * ((H + R_TH - 1) / R_TH);
+    return ((size_t)B * ntile * sizeof(unsigned short) + 15) / 16 * 16;
+}
+
+extern "C" int vpn_hotpath_chamfer_fwd(const float* p1, const float* p2, int B, int N, int M, float* dist1, int32_t* idx1,
+                                       float* dist2, int32_t* idx2, void* workspace, size_t workspace_bytes, int mode,
+                                       void* records, int K, int H, int W, void* tile_order, void* stream) {
+    if (!p1 || !p2 || !dist1 || !idx1 || !dist2 || !idx2 || !workspace) return VPN_E_BADARG;
+    if (B <= 0 || N <= 0 || M <= 0) return VPN_E_BADARG;
+    if (B > 65535 || (long long)B * N > 0x7fffffffLL || (long long)B * M > 0x7fffffffLL) return VPN_E_TOOBIG;
+    if (workspace_bytes < vpn_chamfer_workspace(B, N, M) || ((uintptr_t)workspace & 15) != 0) return VPN_E_BADARG;
+    if (mode == 0) mode = chamfer_mode();
+    if (mode == 0) mode = ((long)N * M >= 512L * 512L) ? 6 : 1;
+    if (mode != 6 && mode != 7) return VPN_E_BADARG;                          // the rider lives in the fp16 scan only
+    RasterOrderJob oj;
+    const RasterOrderJob* rider = nullptr;
+    if (tile_order) {
+        if (!records || K <= 0 || K > VPN_MAX_PRIMS || H <= 0 || W <= 0 || ((uintptr_t)records & 15) != 0) return VPN_E_BADARG;
+        oj.rec = (const float4*)records;
+        oj.B = B; oj.K = K; oj.H = H; oj.W = W;
+        oj.tiles_x = (W + R_TW - 1) / R_TW;
+        oj.ntile = oj.tiles_x * ((H + R_TH - 1) / R_TH);
+        oj.words = (K + 63) / 64;
+        oj.masks = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(records) + (size_t)B * K * R_REC * sizeof(float4));
+        oj.order = (unsigned short*)tile_order;
+        if (K > 255 || oj.ntile > R_ORDER_MAX_TILES || raster_order_scratch(K, oj.ntile) > 2 * CM_TILE16 * CM_ROWB) return VPN_E_TOOBIG;
+        rider = &oj;
+    }
+    return mfma_both(p1, p2, B, N, M, (float*)workspace, dist1, idx1, dist2, idx2, 2, (hipStream_t)stream, mode == 7, rider);
 }

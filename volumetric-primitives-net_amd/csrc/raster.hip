@@ -40,28 +40,6 @@
 
 namespace vpn {
 
-// does the region q >= 0 of the conic touch the rectangle [x0,x1] x [y0,y1] (slope units)?  Exact for an
-// ellipse: the centre if it is inside, otherwise the maximum of the concave quadratic over the 4 edges.
-__device__ inline bool conic_hits_rect(const float4 qa, const float4 qb, float x0, float x1, float y0, float y1) {
-    const float A00 = qa.x, A01 = qa.y, A11 = qa.z, b0 = qb.x, b1 = qb.y, c0 = qb.z, det = qb.w;
-    const float idet = R_RCP(det);
-    const float xs = -(A11 * b0 - A01 * b1) * idet, ys = -(A00 * b1 - A01 * b0) * idet;
-    if (xs >= x0 && xs <= x1 && ys >= y0 && ys <= y1) return true;
-    float best = -1.0f;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const float x = e ? x1 : x0;                                         // vertical edges
-        const float lin = A01 * x + b1, cst = (A00 * x + 2.0f * b0) * x + c0;
-        const float yv = fminf(fmaxf(-lin * R_RCP(A11), y0), y1);
-        best = fmaxf(best, (A11 * yv + 2.0f * lin) * yv + cst);
-        const float y = e ? y1 : y0;                                         // horizontal edges
-        const float lin2 = A01 * y + b0, cst2 = (A11 * y + 2.0f * b1) * y + c0;
-        const float xv = fminf(fmaxf(-lin2 * R_RCP(A00), x0), x1);
-        best = fmaxf(best, (A00 * xv + 2.0f * lin2) * xv + cst2);
-    }
-    return best >= 0.0f;
-}
-
 // per pixel x primitive forward quantities
 struct PixPrim {
     float d[3];
@@ -204,21 +182,7 @@ __device__ inline void prim_backward(const float4 r0, const PixPrim& q, float gz
 //   masks[(b * ntile + tile) * words + w] bit j  <=>  primitive 64 w + j may touch the 16x16 tile,
 // which the backward and finishing kernels read back instead of repeating the test.
 
-// does primitive (pixel box bb, conic qa/qb) touch the 16x16 tile at (c0, r0)?
-__device__ inline bool prim_hits_tile(const float4 bb, const float4 qa, const float4 qb, int c0, int r0, int H, int W,
-                                      int R_TW = vpn::R_TW, int R_TH = vpn::R_TH) {       // also used for the 8x8 quadrants
-    const int jmin = __float_as_int(bb.x), jmax = __float_as_int(bb.y);
-    const int imin = __float_as_int(bb.z), imax = __float_as_int(bb.w);
-    bool vis = (jmin <= c0 + R_TW - 1) && (jmax >= c0) && (imin <= r0 + R_TH - 1) && (imax >= r0);
-    if (vis && qa.w != 0.0f) {
-        // tile rectangle in slope units, half a pixel of margin on every side
-        const float sx = 2.0f * (R_TAN_HALF_FOV * (float)W / (float)H) / (float)W, sy = 2.0f * R_TAN_HALF_FOV / (float)H;
-        const float x0 = ((float)c0 - 0.5f * (float)W) * sx, x1 = ((float)(c0 + R_TW) - 0.5f * (float)W) * sx;
-        const float y1 = (0.5f * (float)H - (float)r0) * sy, y0 = (0.5f * (float)H - (float)(r0 + R_TH)) * sy;
-        vis = conic_hits_rect(qa, qb, x0, x1, y0, y1);
-    }
-    return vis;
-}
+// (prim_hits_tile: vpn_raster_common.h -- shared with the launch that sorts the tiles of the training step)
 
 // ---------------------------------------------------------------------------------------------------------------
 // Tile kernels.  ONE WAVEFRONT (= one workgroup) PER 16x16 PIXEL TILE.  The visible primitives of the tile come from
@@ -244,7 +208,12 @@ struct Tile {
 // heavy tile started late runs on alone at the end of the launch: heavy-first order shortens that tail; one-wave
 // workgroups because a 4-wave workgroup holds its 4 slots until its slowest tile is done; id % 8 = b % 8 keeps every
 // XCD on whole images with the same mix of tiles (speed only: any order is correct).
-__device__ inline Tile make_tile(int H, int W, int tiles_x, int tiles_y, int B) {
+// `order` (training step): order[b][r] = the tile of image b with rank r when its tiles are sorted by the number of
+// visible primitives, heaviest first (written by the launch that wrote the tile masks).  A tile's cost is proportional
+// to that number (0 .. 10 at C3, and it varies from image to image at one position), the launch lasts at least as long
+// as its heaviest tile (~30 us), and with the position-based order a heavy tile away from the centre started in the
+// second or third round of waves and WAS the tail.
+__device__ inline Tile make_tile(int H, int W, int tiles_x, int tiles_y, int B, const unsigned short* __restrict__ order = nullptr) {
     Tile T;
     const int lane = threadIdx.x & 63;
     const int id = blockIdx.x;
@@ -252,7 +221,11 @@ __device__ inline Tile make_tile(int H, int W, int tiles_x, int tiles_y, int B) 
     T.b = id - pt * B;
     const int iy = pt / tiles_x, ix = pt - iy * tiles_x;
     auto co = [](int i, int n) { const int c = n >> 1, h = (i + 1) >> 1; return (i & 1) ? c - h : c + h; };
-    const int tx = co(ix, tiles_x), ty = co(iy, tiles_y);
+    int tx = co(ix, tiles_x), ty = co(iy, tiles_y);
+    if (order) {
+        const int t = min((int)order[(size_t)T.b * (tiles_x * tiles_y) + pt], tiles_x * tiles_y - 1);
+        ty = t / tiles_x; tx = t - ty * tiles_x;
+    }
     T.valid = true;
     T.tile = ty * tiles_x + tx;
     T.c0 = tx * R_TW; T.r0 = ty * R_TH;
@@ -427,12 +400,13 @@ __device__ inline void finalize_sample(const FinArgs& fin, const LossArgs& la, i
 // forward composite of the tile's visible primitives: P = prod(1 - a), S0 = sum w, S1 = sum w z
 __device__ inline unsigned long long tile_forward(const Tile& T, const float4* __restrict__ rec_b, unsigned long long* __restrict__ mrow,
                                     int words, int K, int H, int W, float4* srec, float inv_sigma, float inv_gamma,
-                                    float zref, float P[R_PPL], float S0[R_PPL], float S1[R_PPL]) {
+                                    float zref, float P[R_PPL], float S0[R_PPL], float S1[R_PPL], bool masks_ready = false) {
 #pragma unroll
     for (int s = 0; s < R_PPL; ++s) { P[s] = 1.0f; S0[s] = 0.0f; S1[s] = 0.0f; }
     unsigned long long m0 = 0ull;
     for (int w = 0; w < words; ++w) {
-        const unsigned long long m = stage_word(T, rec_b, w, K, H, W, srec, nullptr, mrow);
+        const unsigned long long m = masks_ready ? stage_word(T, rec_b, w, K, H, W, srec, mrow, nullptr)
+                                                   : stage_word(T, rec_b, w, K, H, W, srec, nullptr, mrow);
         if (w == 0) m0 = m;
         const int n = __builtin_popcountll(m);
         unsigned long long qb = 0ull;
@@ -629,8 +603,9 @@ __global__ __launch_bounds__(64, R_TOTAL_WAVES) void raster_total_kernel(const f
                                                            unsigned long long* __restrict__ masks,
                                                            const float* __restrict__ cam, int B, int K, int H, int W,
                                                            int tiles_x, int tiles_y, int words, float sigma, float gamma,
-                                                           float z_far, float* __restrict__ partial, LossArgs la, FinArgs fin) {
-    const Tile T = make_tile(H, W, tiles_x, tiles_y, B);
+                                                           float z_far, float* __restrict__ partial, LossArgs la, FinArgs fin,
+                                                           const unsigned short* __restrict__ order) {
+    const Tile T = make_tile(H, W, tiles_x, tiles_y, B, order);
     if (!T.valid) return;
     const int ntile = tiles_x * tiles_y, lane = threadIdx.x & 63;
     const float4* rec_b = rec + (size_t)T.b * K * R_REC;
@@ -650,7 +625,8 @@ __global__ __launch_bounds__(64, R_TOTAL_WAVES) void raster_total_kernel(const f
     }
     __shared__ __attribute__((aligned(16))) float4 srec[R_LDS_F4];
     float P[R_PPL], S0[R_PPL], S1[R_PPL];
-    const unsigned long long m0 = tile_forward(T, rec_b, mrow, words, K, H, W, srec, inv_sigma, inv_gamma, zref, P, S0, S1);
+    // with an order the tile masks are there too (both come from the sampler's launch): read, not recomputed
+    const unsigned long long m0 = tile_forward(T, rec_b, mrow, words, K, H, W, srec, inv_sigma, inv_gamma, zref, P, S0, S1, order != nullptr);
     float gAtot[R_PPL], gZbar[R_PPL], zbar[R_PPL], invS[R_PPL];
     float lsil = 0.0f, ldep = 0.0f;
 #pragma unroll
@@ -976,7 +952,7 @@ extern "C" int vpn_raster_total_fwd(const float* params, const int32_t* kinds, c
     const Grid G = raster_grid(B, K, H, W);
     LossArgs la{gt_sil, gt_depth, sil_mse, 1.0f / ((float)B * (float)H * (float)W), tile_loss_of(loss_ws, B), nullptr, w_sil, w_dep};
     VPN_LAUNCH(raster_total_kernel, G.g, dim3(64), 0, s, (const float4*)records, masks_of(records, B, K), cam, B, K,
-               H, W, G.tiles_x, G.tiles_y, G.words, sigma, gamma, z_far, (float*)workspace, la, FinArgs{});
+               H, W, G.tiles_x, G.tiles_y, G.words, sigma, gamma, z_far, (float*)workspace, la, FinArgs{}, (const unsigned short*)nullptr);
     VPN_LAUNCH_CHECK();
     return 0;
 }
@@ -990,7 +966,7 @@ extern "C" int vpn_raster_total_fwd_fin(const float* params, const int32_t* kind
                                         void* loss_ws, void* workspace, int records_ready,
                                         const void* chamfer_ws, size_t chamfer_ws_bytes, int N, int M, float cd_w1,
                                         float cd_w2, float w_cd, float* losses, float* loss_b, uint64_t* seed_advance,
-                                        void* stream) {
+                                        const void* tile_order, void* stream) {
     int rc = raster_check(params, kinds, cam, B, K, H, W, sigma, gamma);
     if (rc) return rc;
     if (!records || !loss_ws || !workspace || !losses) return VPN_E_BADARG;
@@ -1008,9 +984,10 @@ extern "C" int vpn_raster_total_fwd_fin(const float* params, const int32_t* kind
     hipStream_t s = (hipStream_t)stream;
     if (!records_ready && (rc = launch_prep(params, kinds, cam, B, K, H, W, sigma, records, (int*)loss_ws, s))) return rc;
     const Grid G = raster_grid(B, K, H, W);
+    if (tile_order && (!records_ready || G.ntile > 65535)) return VPN_E_BADARG;     // the order comes with the masks
     LossArgs la{gt_sil, gt_depth, sil_mse, 1.0f / ((float)B * (float)H * (float)W), tile_loss_of(loss_ws, B), nullptr, w_sil, w_dep};
     VPN_LAUNCH(raster_total_kernel, G.g, dim3(64), 0, s, (const float4*)records, masks_of(records, B, K), cam, B, K,
-               H, W, G.tiles_x, G.tiles_y, G.words, sigma, gamma, z_far, (float*)workspace, la, fin);
+               H, W, G.tiles_x, G.tiles_y, G.words, sigma, gamma, z_far, (float*)workspace, la, fin, (const unsigned short*)tile_order);
     VPN_LAUNCH_CHECK();
     return 0;
 }

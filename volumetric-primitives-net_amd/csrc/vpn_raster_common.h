@@ -184,6 +184,99 @@ __device__ inline float wave_reduce16(float v[16]) {
     return r;
 }
 
+// does the region q >= 0 of the conic touch the rectangle [x0,x1] x [y0,y1] (slope units)?  Exact for an
+// ellipse: the centre if it is inside, otherwise the maximum of the concave quadratic over the 4 edges.
+__device__ inline bool conic_hits_rect(const float4 qa, const float4 qb, float x0, float x1, float y0, float y1) {
+    const float A00 = qa.x, A01 = qa.y, A11 = qa.z, b0 = qb.x, b1 = qb.y, c0 = qb.z, det = qb.w;
+    const float idet = __builtin_amdgcn_rcpf(det);
+    const float xs = -(A11 * b0 - A01 * b1) * idet, ys = -(A00 * b1 - A01 * b0) * idet;
+    if (xs >= x0 && xs <= x1 && ys >= y0 && ys <= y1) return true;
+    float best = -1.0f;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const float x = e ? x1 : x0;                                         // vertical edges
+        const float lin = A01 * x + b1, cst = (A00 * x + 2.0f * b0) * x + c0;
+        const float yv = fminf(fmaxf(-lin * __builtin_amdgcn_rcpf(A11), y0), y1);
+        best = fmaxf(best, (A11 * yv + 2.0f * lin) * yv + cst);
+        const float y = e ? y1 : y0;                                         // horizontal edges
+        const float lin2 = A01 * y + b0, cst2 = (A11 * y + 2.0f * b1) * y + c0;
+        const float xv = fminf(fmaxf(-lin2 * __builtin_amdgcn_rcpf(A00), x0), x1);
+        best = fmaxf(best, (A00 * xv + 2.0f * lin2) * xv + cst2);
+    }
+    return best >= 0.0f;
+}
+
+// does primitive (pixel box bb, conic qa/qb) touch the 16x16 tile at (c0, r0)?
+__device__ inline bool prim_hits_tile(const float4 bb, const float4 qa, const float4 qb, int c0, int r0, int H, int W,
+                                      int R_TW = vpn::R_TW, int R_TH = vpn::R_TH) {       // also used for the 8x8 quadrants
+    const int jmin = __float_as_int(bb.x), jmax = __float_as_int(bb.y);
+    const int imin = __float_as_int(bb.z), imax = __float_as_int(bb.w);
+    bool vis = (jmin <= c0 + R_TW - 1) && (jmax >= c0) && (imin <= r0 + R_TH - 1) && (imax >= r0);
+    if (vis && qa.w != 0.0f) {
+        // tile rectangle in slope units, half a pixel of margin on every side
+        const float sx = 2.0f * (R_TAN_HALF_FOV * (float)W / (float)H) / (float)W, sy = 2.0f * R_TAN_HALF_FOV / (float)H;
+        const float x0 = ((float)c0 - 0.5f * (float)W) * sx, x1 = ((float)(c0 + R_TW) - 0.5f * (float)W) * sx;
+        const float y1 = (0.5f * (float)H - (float)r0) * sy, y0 = (0.5f * (float)H - (float)(r0 + R_TH)) * sy;
+        vis = conic_hits_rect(qa, qb, x0, x1, y0, y1);
+    }
+    return vis;
+}
+
+
+// ---- launch order of the training step's tile waves.  One workgroup per image: every tile is tested against the K
+// primitives of the image (the test of the tile kernels; two lanes share a tile, odd / even primitives), the masks go
+// where the tile kernels expect them, and the tiles are sorted by their number of visible primitives, heaviest first
+// (counting sort in LDS).  Runs as a rider in the tail of the Chamfer scan's launch (chamfer.hip), between the launch
+// that writes the records and the one that reads masks and order.
+struct RasterOrderJob {
+    const float4* rec = nullptr;              // records [B][K][R_REC] (vpn_hotpath_sample_fwd)
+    unsigned long long* masks = nullptr;      // out: [B][ntile][words]
+    unsigned short* order = nullptr;          // out: [B][ntile], tiles by visible primitives, heaviest first
+    int B = 0, K = 0, H = 0, W = 0, tiles_x = 0, ntile = 0, words = 0;
+};
+
+// scratch (LDS): K * 3 float4 of cull records + (K + 2) ints + ntile bytes; R_ORDER_MAX_TILES bounds the last term
+constexpr int R_ORDER_MAX_TILES = 16384;      // 2048 x 2048 pixels
+__host__ __device__ inline size_t raster_order_scratch(int K, int ntile) { return (size_t)K * 48 + (size_t)(K + 2) * 4 + (size_t)ntile; }
+template <int THREADS>
+__device__ inline void raster_order_wg(const RasterOrderJob& J, int b, void* scratch) {
+    float4* cull = reinterpret_cast<float4*>(scratch);
+    int* hist = reinterpret_cast<int*>(cull + 3 * J.K);          // hist[c] -> start of the bucket of popcount c (descending)
+    unsigned char* pops = reinterpret_cast<unsigned char*>(hist + J.K + 2);   // visible primitives per tile (K <= 255)
+    const float4* rec_b = J.rec + (size_t)b * J.K * R_REC;
+    for (int i = threadIdx.x; i < 3 * J.K; i += THREADS) cull[i] = rec_b[(size_t)(i / 3) * R_REC + 4 + i % 3];
+    for (int i = threadIdx.x; i <= J.K + 1; i += THREADS) hist[i] = 0;
+    __syncthreads();
+    unsigned long long* mrow = J.masks + (size_t)b * J.ntile * J.words;
+    // pass 1: masks and the histogram of their popcounts
+    for (int it = threadIdx.x; it < 2 * J.ntile; it += THREADS) {            // pairs of lanes: THREADS and it are even together
+        const int tile = it >> 1, par = it & 1;
+        const int ty = tile / J.tiles_x, tx = tile - ty * J.tiles_x;
+        int pop = 0;
+        for (int w = 0; w < J.words; ++w) {
+            unsigned long long m = 0ull;
+            for (int k = 64 * w + par; k < min(J.K, 64 * w + 64); k += 2)
+                if (prim_hits_tile(cull[3 * k], cull[3 * k + 1], cull[3 * k + 2], tx * R_TW, ty * R_TH, J.H, J.W)) m |= 1ull << (k & 63);
+            m |= ((unsigned long long)__shfl_xor((unsigned)(m >> 32), 1, 64) << 32) | (unsigned)__shfl_xor((unsigned)m, 1, 64);
+            if (par == 0) mrow[(size_t)tile * J.words + w] = m;
+            pop += __builtin_popcountll(m);
+        }
+        if (par == 0) { pops[tile] = (unsigned char)pop; atomicAdd(&hist[J.K - pop], 1); }      // bucket 0 = all K primitives visible
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {                                                   // exclusive prefix over K + 1 buckets
+        int run = 0;
+        for (int c = 0; c <= J.K; ++c) { const int n = hist[c]; hist[c] = run; run += n; }
+    }
+    __syncthreads();
+    // pass 2: every tile takes the next place of its bucket (the order inside a bucket is whatever the atomics give:
+    // it schedules, it does not change a result)
+    unsigned short* orow = J.order + (size_t)b * J.ntile;
+    for (int tile = threadIdx.x; tile < J.ntile; tile += THREADS) {
+        orow[atomicAdd(&hist[J.K - (int)pops[tile]], 1)] = (unsigned short)tile;
+    }
+}
+
 struct RasterPrep {       // what a kernel outside raster.hip needs to write the raster records (rec == nullptr: nothing to do)
     const float* cam = nullptr;
     float4* rec = nullptr;

@@ -526,7 +526,7 @@ class RasterTotalFunction(Function):
         _lib.call('vpn_raster_total_fwd_fin', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(cam), B, K, H, W, float(sigma),
                   float(gamma), float(z_far), _lib.ptr(gt_sil), _lib.ptr(gt_depth), int(bool(sil_mse)), float(w_sil),
                   float(w_dep), _lib.ptr(rec), _lib.ptr(lws), _lib.ptr(ws), 0, None, 0, 0, 0, 0.0, 0.0, 0.0,
-                  _lib.ptr(losses), None, None, s)
+                  _lib.ptr(losses), None, None, None, s)
         ctx.save_for_backward(params, cam, rec, ws)
         ctx.meta = (B, K, H, W)
         sil, dep, tot, _ = losses.unbind(0)
@@ -547,6 +547,7 @@ class RasterTotalFunction(Function):
         return (grad_params,) + (None,) * 12
 
 
+TILE_ORDER = os.environ.get('VPN_TILE_ORDER', '1') != '0'     # 0: position-based launch order of the tile waves (A/B switch)
 _PATTERNS = {}
 FUSED_BWD_MAX_GT = 7680       # vpn_sample_chamfer_bwd keeps per-wave match lists of the GT points in LDS (include/vpn_hip.h)
 _SIDE = {}
@@ -640,16 +641,26 @@ class HotPathLossFunction(Function):
         d2 = torch.empty((B, M), dtype=torch.float32, device=dev)
         i1 = torch.empty((B, N), dtype=torch.int32, device=dev)
         i2 = torch.empty((B, M), dtype=torch.int32, device=dev)
-        _lib.call('vpn_chamfer_fwd_ws', _lib.ptr(points), _lib.ptr(gt_points), B, N, M, _lib.ptr(d1), _lib.ptr(i1),
-                  _lib.ptr(d2), _lib.ptr(i2), _lib.ptr(cws), cws.numel() * 4, chamfer_mode, s)
         fused_fin = side is None and chamfer_mode == 7
+        order = None
+        ntile = ((W + 15) // 16) * ((H + 15) // 16)
+        if fused_fin and TILE_ORDER and K <= 255 and ntile <= 16384 and K * 48 + (K + 2) * 4 + ntile <= 24576:
+            # the scan launch also sorts the raster's tiles by visible primitives (a rider in its tail): the tile waves
+            # then start heaviest first and read their masks instead of testing the primitives again
+            order = torch.empty((L.vpn_raster_order_size(B, H, W) // 2,), dtype=torch.int16, device=dev)
+            _lib.call('vpn_hotpath_chamfer_fwd', _lib.ptr(points), _lib.ptr(gt_points), B, N, M, _lib.ptr(d1), _lib.ptr(i1),
+                      _lib.ptr(d2), _lib.ptr(i2), _lib.ptr(cws), cws.numel() * 4, chamfer_mode, _lib.ptr(rec), K, H, W,
+                      _lib.ptr(order), s)
+        else:
+            _lib.call('vpn_chamfer_fwd_ws', _lib.ptr(points), _lib.ptr(gt_points), B, N, M, _lib.ptr(d1), _lib.ptr(i1),
+                      _lib.ptr(d2), _lib.ptr(i2), _lib.ptr(cws), cws.numel() * 4, chamfer_mode, s)
         if fused_fin:
             # raster forward+backward pass and the loss finalisation (image losses, per-sample Chamfer terms from the
             # scan's per-workgroup sums, total, optional advance of the step counter) in ONE launch
             _lib.call('vpn_raster_total_fwd_fin', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(cam), B, K, H, W, float(sigma),
                       float(gamma), float(z_far), _lib.ptr(gt_sil), _lib.ptr(gt_depth), sil_mse, float(w_sil),
                       float(w_depth), _lib.ptr(rec), _lib.ptr(lws), _lib.ptr(rws), 1, _lib.ptr(cws), cws.numel() * 4, N, M,
-                      cd_w1, cd_w2, float(w_cd), _lib.ptr(losses), None, seed_dev if advance_seed else None, s)
+                      cd_w1, cd_w2, float(w_cd), _lib.ptr(losses), None, seed_dev if advance_seed else None, _lib.ptr(order), s)
         else:
             if side is not None:
                 main.wait_stream(side)
