@@ -1126,6 +1126,62 @@ def test_hot_path_config3_full(vpn):
     assert bool(torch.isfinite(g128).all()) and float(t32) > 0 and float(t128) > 0
 
 
+def test_tile_order_rider(vpn):
+    """vpn_hotpath_chamfer_fwd: the scan's results are those of vpn_chamfer_fwd_ws, the rider's tile masks are the ones
+    the tile waves compute themselves, tile_order is a permutation of every image's tiles sorted by visible primitives
+    (heaviest first), and the raster gives the same bits with and without it.  Odd batch size, ragged image, mixed
+    kinds, and a K > 64 case (two mask words)."""
+    from vpn_amd import _lib
+    L = _lib.lib()
+    dev = torch.device(DEV)
+    gen = torch.Generator().manual_seed(77)
+    for (B, K, n, M, H, W) in ((5, 7, 90, 700, 72, 104), (2, 70, 16, 600, 48, 48)):
+        N = K * n
+        params = g(rand_params(gen, B, K))
+        kinds = vpn.kinds_tensor(sorted((int(x) for x in torch.randint(0, 2, (K,), generator=gen)), reverse=True), dev)
+        gt = g(torch.rand(B, M, 3, generator=gen) - 0.5)
+        cam = g(torch.tensor([[1.0, 5.0, 20.0]]).expand(B, 3).contiguous())
+        gt_sil = g((torch.rand(B, H, W, generator=gen) > 0.5).float())
+        gt_dep = g(2.0 - torch.rand(B, H, W, generator=gen))
+        ntile = ((W + 15) // 16) * ((H + 15) // 16)
+        words = (K + 63) // 64
+        mk = lambda nbytes: torch.zeros((nbytes // 4,), dtype=torch.float32, device=dev)
+        rec, lws, rws = mk(L.vpn_raster_records_size(B, K, H, W)), mk(L.vpn_raster_loss_workspace(B, H, W)), mk(L.vpn_raster_bwd_workspace(B, K, H, W))
+        cws = mk(L.vpn_chamfer_workspace(B, N, M))
+        pts = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
+        fused = bool(L.vpn_hotpath_fused_features(B, K, n, M))
+        _lib.call('vpn_hotpath_sample_fwd', _lib.ptr(params), _lib.ptr(kinds), None, 11, None, 0, B, K, n, _lib.ptr(pts), _lib.ptr(cam),
+                  H, W, 0.05, _lib.ptr(rec), _lib.ptr(lws), _lib.ptr(gt), M, _lib.ptr(cws) if fused else None, cws.numel() * 4, _lib.stream())
+        outs = {}
+        for with_order in (False, True):
+            d1, d2 = torch.empty(B, N, device=dev), torch.empty(B, M, device=dev)
+            i1, i2 = torch.empty(B, N, dtype=torch.int32, device=dev), torch.empty(B, M, dtype=torch.int32, device=dev)
+            order = torch.full((L.vpn_raster_order_size(B, H, W) // 2,), -1, dtype=torch.int16, device=dev) if with_order else None
+            _lib.call('vpn_hotpath_chamfer_fwd', _lib.ptr(pts), _lib.ptr(gt), B, N, M, _lib.ptr(d1), _lib.ptr(i1), _lib.ptr(d2), _lib.ptr(i2),
+                      _lib.ptr(cws), cws.numel() * 4, 7 if fused else 6, _lib.ptr(rec), K, H, W, _lib.ptr(order), _lib.stream())
+            losses = torch.zeros(4, device=dev)
+            rws.zero_()
+            _lib.call('vpn_raster_total_fwd_fin', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(cam), B, K, H, W, 0.05, 0.1, 2.0, _lib.ptr(gt_sil),
+                      _lib.ptr(gt_dep), 0, 1.0, 1.0, _lib.ptr(rec), _lib.ptr(lws), _lib.ptr(rws), 1, _lib.ptr(cws), cws.numel() * 4, N, M, 1.0, 1.0,
+                      1.0, _lib.ptr(losses), None, None, _lib.ptr(order), _lib.stream())
+            torch.cuda.synchronize()
+            masks = rec.view(torch.int64)[B * K * 14 * 2:][:B * ntile * words].clone().cpu().reshape(B, ntile, words)
+            outs[with_order] = (d1.cpu(), i1.cpu(), d2.cpu(), i2.cpu(), losses.cpu(), rws.clone().cpu(), masks,
+                                order.cpu().reshape(-1)[:B * ntile].reshape(B, ntile) if with_order else None)
+        a, b = outs[False], outs[True]
+        for x, y in zip(a[:7], b[:7]):
+            assert torch.equal(x, y)                                   # scan, losses, gradient partials, masks: the same bits
+        r1, j1, r2, j2 = vpn.chamfer_nn(pts, gt, mode='brute')
+        assert torch.equal(b[0], r1.cpu()) and torch.equal(b[1], j1.cpu()) and torch.equal(b[3], j2.cpu())
+        order = b[7].long() & 0xffff
+        pop = torch.tensor([[sum(bin(int(w) & ((1 << 64) - 1)).count('1') for w in t) for t in img] for img in b[6].tolist()])
+        for img in range(B):
+            assert sorted(order[img].tolist()) == list(range(ntile))       # a permutation of the image's tiles
+            p = pop[img][order[img]]
+            assert bool((p[:-1] >= p[1:]).all())                           # heaviest first
+    assert L.vpn_hotpath_chamfer_fwd(None, None, 1, 1, 1, None, None, None, None, None, 0, 6, None, 1, 8, 8, None, None) == -1
+
+
 def test_raster_escape_report():
     """Runs last in this file: how often the fp64 clause of _raster_case was needed (it must stay rare, and only
     where the fp32 oracle itself is noisy)."""
