@@ -275,18 +275,21 @@ __global__ __launch_bounds__(SAMP_BLOCK) void sample_bwd_kernel(
 // the forward pass used (recomputed from the same uniforms / Philox counter).  Fixed summation order: bitwise
 // reproducible, unlike the LDS-atomic scatter of chamfer_bwd_lds_kernel.  Replaces that kernel (one workgroup
 // per sample) plus sample_bwd_kernel and the [B,N,3] gradient between them.
-#ifndef SCB_WAVES
-#define SCB_WAVES 6
+// SCB_BLOCK lanes per workgroup.  128 (two waves) is the default: 2048 workgroups of four waves are 1.33 rounds of the 6144 wave
+// slots this kernel's registers leave, 4096 waves are one round -- the kernel is a chain of latencies, and a wave that
+// does twice the work is far shorter than two rounds of waves.
+#ifndef SCB_BLOCK
+#define SCB_BLOCK 128
 #endif
-__global__ __launch_bounds__(SAMP_BLOCK, SCB_WAVES) void sample_chamfer_bwd_kernel(
+__global__ __launch_bounds__(SCB_BLOCK) void sample_chamfer_bwd_kernel(
     const float* __restrict__ params, const int32_t* __restrict__ kinds, const float* __restrict__ u,
     uint64_t seed, const uint64_t* __restrict__ seed_dev, uint64_t sample_base, int K, int n,
     const float* __restrict__ points, const float* __restrict__ gt, int M, const float* __restrict__ dist1, const int32_t* __restrict__ idx1,
     const float* __restrict__ dist2, const int32_t* __restrict__ idx2, const float* __restrict__ grad_loss_b,
     float w1, float w2, float* __restrict__ grad_params, const RasterFinish rf) {
     __shared__ PrimLds P;
-    __shared__ float red[SAMP_BLOCK / 64][12];
-    __shared__ float fin[SAMP_BLOCK / 64][12];
+    __shared__ float red[SCB_BLOCK / 64][12];
+    __shared__ float fin[SCB_BLOCK / 64][12];
     __shared__ float rgrad[10];
     if (seed_dev) seed += *seed_dev;
     const int k = blockIdx.x, b = blockIdx.y, N = K * n;
@@ -301,7 +304,7 @@ __global__ __launch_bounds__(SAMP_BLOCK, SCB_WAVES) void sample_chamfer_bwd_kern
     }
     if (rf.partial) {
         float fv[16];
-        raster_finish_gather(b * K + k, K, rf.ntile, rf.words, rf.masks, rf.partial, (int)(threadIdx.x >> 6) * 64, SAMP_BLOCK, fv);
+        raster_finish_gather(b * K + k, K, rf.ntile, rf.words, rf.masks, rf.partial, (int)(threadIdx.x >> 6) * 64, SCB_BLOCK, fv);
         const float tot = wave_reduce16(fv);
         if ((threadIdx.x & 3) == 0 && (threadIdx.x & 63) < 48) fin[threadIdx.x >> 6][(threadIdx.x & 63) >> 2] = tot;
     }
@@ -350,7 +353,7 @@ __global__ __launch_bounds__(SAMP_BLOCK, SCB_WAVES) void sample_chamfer_bwd_kern
             acc[9 + r] += g[r];
         }
     };
-    for (int pl = threadIdx.x; pl < n; pl += SAMP_BLOCK) {              // own nearest neighbour
+    for (int pl = threadIdx.x; pl < n; pl += SCB_BLOCK) {              // own nearest neighbour
         const int i = k * n + pl, j = idx1[(size_t)b * N + i];
         const float coef = ca / dist1[(size_t)b * N + i];
         const F3 a = ld3(A + i * 3), g = ld3(G2 + j * 3);
@@ -361,24 +364,24 @@ __global__ __launch_bounds__(SAMP_BLOCK, SCB_WAVES) void sample_chamfer_bwd_kern
     // Philox) ran M/256 times with one or two active lanes.  So each wave first compacts its matches into LDS
     // (ballot prefix: a fixed order) and then handles them densely.
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    extern __shared__ int2 match[];                                     // [SAMP_BLOCK/64][cap] of (GT point, predicted point)
-    const int cap = (M + SAMP_BLOCK - 1) / SAMP_BLOCK * 64;             // entries one wave looks at
+    extern __shared__ int2 match[];                                     // [SCB_BLOCK/64][cap] of (GT point, predicted point)
+    const int cap = (M + SCB_BLOCK - 1) / SCB_BLOCK * 64;             // entries one wave looks at
     int2* mine = match + wave * cap;
     int cnt = 0;
     // 8 passes at a time: their loads are issued together (each pass used to wait out its own L2 round trip)
-    for (int e0 = 0; e0 < M; e0 += 8 * SAMP_BLOCK) {
+    for (int e0 = 0; e0 < M; e0 += 8 * SCB_BLOCK) {
         int iv[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int e = e0 + u * SAMP_BLOCK + threadIdx.x;
+            const int e = e0 + u * SCB_BLOCK + threadIdx.x;
             iv[u] = e < M ? idx2[(size_t)b * M + e] : -1;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            if (e0 + u * SAMP_BLOCK >= M) break;
+            if (e0 + u * SCB_BLOCK >= M) break;
             const bool hit = iv[u] >= k * n && iv[u] < (k + 1) * n;
             const unsigned long long m = __ballot(hit);
-            if (hit) mine[cnt + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = make_int2(e0 + u * SAMP_BLOCK + (int)threadIdx.x, iv[u]);
+            if (hit) mine[cnt + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = make_int2(e0 + u * SCB_BLOCK + (int)threadIdx.x, iv[u]);
             cnt += __builtin_popcountll(m);
         }
     }
@@ -401,7 +404,12 @@ __global__ __launch_bounds__(SAMP_BLOCK, SCB_WAVES) void sample_chamfer_bwd_kern
     if (rf.partial && threadIdx.x == 64) {                              // raster chain rule, beside thread 0's below
         float G[12], r[10];
 #pragma unroll
-        for (int i = 0; i < 12; ++i) G[i] = (fin[0][i] + fin[1][i]) + (fin[2][i] + fin[3][i]);
+        for (int i = 0; i < 12; ++i) {
+            float t = fin[0][i];
+#pragma unroll
+            for (int w = 1; w < SCB_BLOCK / 64; ++w) t += fin[w][i];
+            G[i] = t;
+        }
         raster_finish_chain(params, rf.rec, b * K + k, K, G, r);
         const float sc = rf.scale ? *rf.scale : 1.0f;
 #pragma unroll
@@ -413,11 +421,11 @@ __global__ __launch_bounds__(SAMP_BLOCK, SCB_WAVES) void sample_chamfer_bwd_kern
         for (int r = 0; r < 3; ++r) {
             for (int a = 0; a < 3; ++a) {
                 float s = 0.0f;
-                for (int w = 0; w < SAMP_BLOCK / 64; ++w) s += red[w][r * 3 + a];
+                for (int w = 0; w < SCB_BLOCK / 64; ++w) s += red[w][r * 3 + a];
                 G[r][a] = s;
             }
             float s = 0.0f;
-            for (int w = 0; w < SAMP_BLOCK / 64; ++w) s += red[w][9 + r];
+            for (int w = 0; w < SCB_BLOCK / 64; ++w) s += red[w][9 + r];
             gt3[r] = s;
         }
         const Mat3& R = P.pose.R;
@@ -834,9 +842,10 @@ static int launch_scb(const float* params, const int32_t* kinds, const float* u,
     if (!grad_loss_b && !rf.scale) return VPN_E_BADARG;
     if (B <= 0 || K <= 0 || n <= 0 || M <= 0) return VPN_E_BADARG;
     if (B > 65535 || (long long)K * n > 0x7fffffffLL / 3) return VPN_E_TOOBIG;
-    const size_t lds = (size_t)((M + SAMP_BLOCK - 1) / SAMP_BLOCK) * 64 * (SAMP_BLOCK / 64) * sizeof(int2);  // = 8 B per GT point
+    constexpr int BLK = SCB_BLOCK;
+    const size_t lds = (size_t)((M + BLK - 1) / BLK) * 64 * (BLK / 64) * sizeof(int2);  // = 8 B per GT point
     if (lds > 60 * 1024) return VPN_E_TOOBIG;                           // 7680 GT points; beyond: vpn_chamfer_bwd + vpn_sample_bwd
-    VPN_LAUNCH(sample_chamfer_bwd_kernel, dim3(K, B), dim3(SAMP_BLOCK), lds, (hipStream_t)stream, params, kinds, u, seed,
+    VPN_LAUNCH(sample_chamfer_bwd_kernel, dim3(K, B), dim3(BLK), lds, (hipStream_t)stream, params, kinds, u, seed,
                seed_dev, sample_base, K, n, points, gt_points, M, dist1, idx1, dist2, idx2, grad_loss_b, w1, w2, grad_params, rf);
     VPN_LAUNCH_CHECK();
     return 0;
