@@ -53,3 +53,43 @@ print('popcount order, masks read                        :', timed(1, order))
 call(1, order)
 torch.cuda.synchronize()
 print('same losses:', bool(torch.equal(losses, ref)), ' same partials:', bool(torch.equal(ws, gref)))
+
+# where should the tiles without primitives go?  They cost a wave slot for one latency chain and no arithmetic.
+def variant(after_pop):
+    """descending popcount, the empty tiles moved in front of the tiles with fewer than `after_pop` primitives"""
+    out = []
+    for b in range(B):
+        p = pop[b]
+        idx = torch.argsort(p, descending=True, stable=True)
+        heavy = idx[p[idx] >= after_pop]
+        light = idx[(p[idx] < after_pop) & (p[idx] > 0)]
+        empty = idx[p[idx] == 0]
+        out.append(torch.cat([heavy, empty, light]))
+    return torch.stack(out).to(torch.int16).contiguous().to(dev)
+
+
+def interleave(every):
+    """descending popcount, one empty tile after every `every` non-empty ones (until they run out)"""
+    out = []
+    for b in range(B):
+        p = pop[b]
+        idx = torch.argsort(p, descending=True, stable=True)
+        ne, em = idx[p[idx] > 0].tolist(), idx[p[idx] == 0].tolist()
+        o = []
+        while ne or em:
+            o += ne[:every]; ne = ne[every:]
+            if em:
+                o.append(em.pop())
+        out.append(torch.tensor(o))
+    return torch.stack(out).to(torch.int16).contiguous().to(dev)
+
+
+variants = (('desc (rider)', order), ('empties before pop<4', variant(4)), ('empties before pop<3', variant(3)), ('empties before pop<2', variant(2)),
+            ('one empty per 3', interleave(3)), ('one empty per 4', interleave(4)), ('one empty per 8', interleave(8)))
+res = {name: [] for name, _ in variants}
+for rnd in range(6):                       # round-robin: the box's clock drifts by several % over a run
+    for name, o in variants:
+        res[name].append(timed(1, o, 40)['raster_total_kernel'])
+for name, _ in variants:
+    v = sorted(res[name][1:])
+    print('%-24s median %.2f  min %.2f  all %s' % (name, v[len(v) // 2], v[0], res[name]))
