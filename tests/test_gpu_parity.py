@@ -1153,12 +1153,25 @@ def test_tile_order_rider(vpn):
         _lib.call('vpn_hotpath_sample_fwd', _lib.ptr(params), _lib.ptr(kinds), None, 11, None, 0, B, K, n, _lib.ptr(pts), _lib.ptr(cam),
                   H, W, 0.05, _lib.ptr(rec), _lib.ptr(lws), _lib.ptr(gt), M, _lib.ptr(cws) if fused else None, cws.numel() * 4, _lib.stream())
         outs = {}
-        for with_order in (False, True):
+        rec_sampler = rec
+        for with_order in (False, True, 'rider builds the records'):
             d1, d2 = torch.empty(B, N, device=dev), torch.empty(B, M, device=dev)
             i1, i2 = torch.empty(B, N, dtype=torch.int32, device=dev), torch.empty(B, M, dtype=torch.int32, device=dev)
             order = torch.full((L.vpn_raster_order_size(B, H, W) // 2,), -1, dtype=torch.int16, device=dev) if with_order else None
+            rider_rec = with_order not in (False, True)
+            if rider_rec:         # the sampler launch leaves the records alone (fresh buffers), the rider writes them
+                rec, lws = mk(L.vpn_raster_records_size(B, K, H, W)), mk(L.vpn_raster_loss_workspace(B, H, W))
+                lws.fill_(float('nan'))                                       # the counters must be zeroed by the sampler launch
+                pts2 = torch.empty_like(pts)
+                _lib.call('vpn_hotpath_sample_fwd', _lib.ptr(params), _lib.ptr(kinds), None, 11, None, 0, B, K, n, _lib.ptr(pts2), None,
+                          0, 0, 0.0, None, _lib.ptr(lws), _lib.ptr(gt), M, _lib.ptr(cws) if fused else None, cws.numel() * 4, _lib.stream())
+                assert torch.equal(pts2, pts)
             _lib.call('vpn_hotpath_chamfer_fwd', _lib.ptr(pts), _lib.ptr(gt), B, N, M, _lib.ptr(d1), _lib.ptr(i1), _lib.ptr(d2), _lib.ptr(i2),
-                      _lib.ptr(cws), cws.numel() * 4, 7 if fused else 6, _lib.ptr(rec), K, H, W, _lib.ptr(order), _lib.stream())
+                      _lib.ptr(cws), cws.numel() * 4, 7 if fused else 6, _lib.ptr(rec), K, H, W, _lib.ptr(order),
+                      _lib.ptr(params) if rider_rec else None, _lib.ptr(kinds) if rider_rec else None, _lib.ptr(cam) if rider_rec else None,
+                      0.05 if rider_rec else 0.0, _lib.stream())
+            if rider_rec:         # the same records, bit for bit
+                assert torch.equal(rec[:B * K * 14 * 4].view(torch.int32), rec_sampler[:B * K * 14 * 4].view(torch.int32))
             losses = torch.zeros(4, device=dev)
             rws.zero_()
             _lib.call('vpn_raster_total_fwd_fin', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(cam), B, K, H, W, 0.05, 0.1, 2.0, _lib.ptr(gt_sil),
@@ -1171,6 +1184,8 @@ def test_tile_order_rider(vpn):
         a, b = outs[False], outs[True]
         for x, y in zip(a[:7], b[:7]):
             assert torch.equal(x, y)                                   # scan, losses, gradient partials, masks: the same bits
+        for x, y in zip(a[:7], outs['rider builds the records'][:7]):
+            assert torch.equal(x, y)
         r1, j1, r2, j2 = vpn.chamfer_nn(pts, gt, mode='brute')
         assert torch.equal(b[0], r1.cpu()) and torch.equal(b[1], j1.cpu()) and torch.equal(b[3], j2.cpu())
         order = b[7].long() & 0xffff
@@ -1179,7 +1194,7 @@ def test_tile_order_rider(vpn):
             assert sorted(order[img].tolist()) == list(range(ntile))       # a permutation of the image's tiles
             p = pop[img][order[img]]
             assert bool((p[:-1] >= p[1:]).all())                           # heaviest first
-    assert L.vpn_hotpath_chamfer_fwd(None, None, 1, 1, 1, None, None, None, None, None, 0, 6, None, 1, 8, 8, None, None) == -1
+    assert L.vpn_hotpath_chamfer_fwd(None, None, 1, 1, 1, None, None, None, None, None, 0, 6, None, 1, 8, 8, None, None, None, None, 0.0, None) == -1
 
 
 def test_raster_escape_report():

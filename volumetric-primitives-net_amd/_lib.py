@@ -9,7 +9,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libvpn_hip.so')
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _c_f = ctypes.c_void_p      # device pointers travel as void*
 _i, _f, _u64, _sz = ctypes.c_int, ctypes.c_float, ctypes.c_uint64, ctypes.c_size_t
@@ -44,7 +44,8 @@ SIGNATURES = {
                                     _c_f, _i, _c_f, _sz, _c_f]),
     'vpn_hotpath_fused_features': (_i, [_i, _i, _i, _i]),
     'vpn_raster_order_size': (_sz, [_i, _i, _i]),
-    'vpn_hotpath_chamfer_fwd': (_i, [_c_f, _c_f, _i, _i, _i, _c_f, _c_f, _c_f, _c_f, _c_f, _sz, _i, _c_f, _i, _i, _i, _c_f, _c_f]),
+    'vpn_hotpath_chamfer_fwd': (_i, [_c_f, _c_f, _i, _i, _i, _c_f, _c_f, _c_f, _c_f, _c_f, _sz, _i, _c_f, _i, _i, _i, _c_f, _c_f,
+                                     _c_f, _c_f, _f, _c_f]),
     'vpn_loss_finalize': (_i, [_c_f, _i, _i, _i, _c_f, _c_f, _i, _i, _f, _f, _f, _f, _f, _c_f, _c_f, _c_f]),
     'vpn_raster_total_bwd': (_i, [_c_f, _c_f, _i, _i, _i, _i, _c_f, _c_f, _c_f, _c_f, _i, _c_f]),
     'vpn_hotpath_bwd': (_i, [_c_f, _c_f, _c_f, _u64, _c_f, _u64, _i, _i, _i, _c_f, _c_f, _i, _c_f, _c_f, _c_f, _c_f, _c_f,

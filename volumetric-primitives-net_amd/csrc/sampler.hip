@@ -741,7 +741,10 @@ extern "C" int vpn_hotpath_sample_fwd(const float* params, const int32_t* kinds,
                                       const float* cam, int H, int W, float sigma, void* records, void* loss_ws,
                                       const float* gt_points, int M, void* chamfer_ws, size_t chamfer_ws_bytes,
                                       void* stream) {
-    if (!cam || !records || H <= 0 || W <= 0 || !(sigma > 0.f) || K > VPN_MAX_PRIMS) return VPN_E_BADARG;
+    // records == NULL: the records are built by the rider of vpn_hotpath_chamfer_fwd (given params there); this launch
+    // still zeroes the counters of loss_ws and keeps the seed
+    if (records && (!cam || H <= 0 || W <= 0 || !(sigma > 0.f))) return VPN_E_BADARG;
+    if ((!records && !loss_ws) || K > VPN_MAX_PRIMS) return VPN_E_BADARG;
     if (((uintptr_t)records & 15) != 0) return VPN_E_BADARG;
     RasterPrep rp;
     rp.cam = cam; rp.H = H; rp.W = W; rp.sigma = sigma; rp.rec = (float4*)records; rp.zero_me = (int*)loss_ws;

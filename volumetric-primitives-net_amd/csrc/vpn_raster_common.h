@@ -67,6 +67,11 @@ __device__ inline void prim_geometry(const Camera& C, const Mat3& R, const float
 // record lane the camera, side by side; both come from make_camera / make_pose, so the record is the same bit for bit)
 __device__ inline void make_record_from(const Camera& C, const Pose& P, const float* __restrict__ prm, int kind, int H, int W,
                                         float sigma, float4 out[R_REC]);
+// ... the same with every float4 handed to `put(i, value)` as soon as it exists (a caller short of registers stores it
+// at once instead of holding all 14)
+template <class Put>
+__device__ inline void make_record_put(const Camera& C, const Pose& P, const float* __restrict__ prm, int kind, int H, int W,
+                                       float sigma, Put&& put);
 
 __device__ inline void make_record(const float* __restrict__ prm, int kind, const float* __restrict__ cam, int b, int H,
                                    int W, float sigma, float4 out[R_REC]) {
@@ -77,6 +82,12 @@ __device__ inline void make_record(const float* __restrict__ prm, int kind, cons
 
 __device__ inline void make_record_from(const Camera& C, const Pose& P, const float* __restrict__ prm, int kind, int H, int W,
                                         float sigma, float4 out[R_REC]) {
+    make_record_put(C, P, prm, kind, H, W, sigma, [&](int i, const float4 v) { out[i] = v; });
+}
+
+template <class Put>
+__device__ inline void make_record_put(const Camera& C, const Pose& P, const float* __restrict__ prm, int kind, int H, int W,
+                                       float sigma, Put&& put) {
 #pragma clang fp contract(off)            // the record does not depend on which kernel builds it
     float v[3] = {prm[0], prm[1], prm[2]};
     float t[3] = {prm[7], prm[8], prm[9]};
@@ -84,17 +95,17 @@ __device__ inline void make_record_from(const Camera& C, const Pose& P, const fl
     prim_geometry(C, P.R, v, t, G);
     // out[7..13]: camera basis and pose as the finishing step of the backward needs them (it used to redo the six
     // sin / cos of make_camera and make_pose on one lane: ~1000 dependent instructions on its critical path)
-    out[7] = make_float4(C.eye[0], C.eye[1], C.eye[2], C.right[0]);
-    out[8] = make_float4(C.right[1], C.right[2], C.up[0], C.up[1]);
-    out[9] = make_float4(C.up[2], C.fwd[0], C.fwd[1], C.fwd[2]);
-    out[10] = make_float4(P.R.m[0][0], P.R.m[0][1], P.R.m[0][2], P.R.m[1][0]);
-    out[11] = make_float4(P.R.m[1][1], P.R.m[1][2], P.R.m[2][0], P.R.m[2][1]);
-    out[12] = make_float4(P.R.m[2][2], P.x, P.y, P.z);
-    out[13] = make_float4(P.w, P.sh, P.ch, P.inv_len);
-    out[0] = make_float4(G.o[0], G.o[1], G.o[2], __int_as_float(kind));
-    out[1] = make_float4(G.Mr[0], G.Mr[1], G.Mr[2], 0.f);
-    out[2] = make_float4(G.Mu[0], G.Mu[1], G.Mu[2], 0.f);
-    out[3] = make_float4(G.Mf[0], G.Mf[1], G.Mf[2], 0.f);
+    put(7, make_float4(C.eye[0], C.eye[1], C.eye[2], C.right[0]));
+    put(8, make_float4(C.right[1], C.right[2], C.up[0], C.up[1]));
+    put(9, make_float4(C.up[2], C.fwd[0], C.fwd[1], C.fwd[2]));
+    put(10, make_float4(P.R.m[0][0], P.R.m[0][1], P.R.m[0][2], P.R.m[1][0]));
+    put(11, make_float4(P.R.m[1][1], P.R.m[1][2], P.R.m[2][0], P.R.m[2][1]));
+    put(12, make_float4(P.R.m[2][2], P.x, P.y, P.z));
+    put(13, make_float4(P.w, P.sh, P.ch, P.inv_len));
+    put(0, make_float4(G.o[0], G.o[1], G.o[2], __int_as_float(kind)));
+    put(1, make_float4(G.Mr[0], G.Mr[1], G.Mr[2], 0.f));
+    put(2, make_float4(G.Mu[0], G.Mu[1], G.Mu[2], 0.f));
+    put(3, make_float4(G.Mf[0], G.Mf[1], G.Mf[2], 0.f));
     // Culling region: rays whose squared miss distance m2 (scaled frame) is <= L2 = lam_cut^2, outside
     // of which the coverage logit (1 - m2)/sigma is below -X_CUT.  With d~ = M p, p = (px, py, 1) and
     // M = [Mr Mu Mf]:  m2 <= L2  <=>  q(p) = (u.p)^2 - c p^T G p >= 0,  u = M^T o~, G = M^T M,
@@ -141,9 +152,9 @@ __device__ inline void make_record_from(const Camera& C, const Pose& P, const fl
             valid = 1.0f;
         }
     }
-    out[4] = make_float4(__int_as_float(jmin), __int_as_float(jmax), __int_as_float(imin), __int_as_float(imax));
-    out[5] = make_float4(A00, A01, A11, valid);
-    out[6] = make_float4(b0, b1, c0, det);
+    put(4, make_float4(__int_as_float(jmin), __int_as_float(jmax), __int_as_float(imin), __int_as_float(imax)));
+    put(5, make_float4(A00, A01, A11, valid));
+    put(6, make_float4(b0, b1, c0, det));
 }
 
 // Transposing butterfly: 16 per-lane values -> lane L holds the wave total of value (L >> 2).
@@ -229,7 +240,14 @@ __device__ inline bool prim_hits_tile(const float4 bb, const float4 qa, const fl
 // (counting sort in LDS).  Runs as a rider in the tail of the Chamfer scan's launch (chamfer.hip), between the launch
 // that writes the records and the one that reads masks and order.
 struct RasterOrderJob {
-    const float4* rec = nullptr;              // records [B][K][R_REC] (vpn_hotpath_sample_fwd)
+    const float4* rec = nullptr;              // records [B][K][R_REC] (vpn_hotpath_sample_fwd), or ...
+    // ... built HERE (params != nullptr): one lane per primitive runs the record's ~1000 dependent instructions in this
+    // launch's tail instead of on the critical path of every sampler workgroup (2.6 us of the sampler launch at C3)
+    const float* params = nullptr;            // [B][K][10]
+    const int32_t* kinds = nullptr;           // [K]
+    const float* cam = nullptr;               // [B][3]
+    float sigma = 0.f;
+    float4* rec_out = nullptr;                // == rec, writable
     unsigned long long* masks = nullptr;      // out: [B][ntile][words]
     unsigned short* order = nullptr;          // out: [B][ntile], tiles by visible primitives, heaviest first
     int B = 0, K = 0, H = 0, W = 0, tiles_x = 0, ntile = 0, words = 0;
@@ -244,7 +262,21 @@ __device__ inline void raster_order_wg(const RasterOrderJob& J, int b, void* scr
     int* hist = reinterpret_cast<int*>(cull + 3 * J.K);          // hist[c] -> start of the bucket of popcount c (descending)
     unsigned char* pops = reinterpret_cast<unsigned char*>(hist + J.K + 2);   // visible primitives per tile (K <= 255)
     const float4* rec_b = J.rec + (size_t)b * J.K * R_REC;
-    for (int i = threadIdx.x; i < 3 * J.K; i += THREADS) cull[i] = rec_b[(size_t)(i / 3) * R_REC + 4 + i % 3];
+    if (J.params) {
+        for (int k = threadIdx.x; k < J.K; k += THREADS) {
+            const float* prm = J.params + ((size_t)b * J.K + k) * VPN_PARAM_STRIDE;
+            const Camera C = make_camera(J.cam + b * 3);
+            const Pose P = make_pose(prm[3], prm[4], prm[5], prm[6]);
+            float4* out = J.rec_out + ((size_t)b * J.K + k) * R_REC;
+            // every float4 is stored as soon as it exists: the host kernel's register budget is the scan loop's
+            make_record_put(C, P, prm, J.kinds[k] == VPN_SPHERE ? VPN_SPHERE : VPN_CUBOID, J.H, J.W, J.sigma, [&](int i, const float4 v) {
+                out[i] = v;
+                if (i >= 4 && i < 4 + R_CULL) cull[3 * k + i - 4] = v;
+            });
+        }
+    } else {
+        for (int i = threadIdx.x; i < 3 * J.K; i += THREADS) cull[i] = rec_b[(size_t)(i / 3) * R_REC + 4 + i % 3];
+    }
     for (int i = threadIdx.x; i <= J.K + 1; i += THREADS) hist[i] = 0;
     __syncthreads();
     unsigned long long* mrow = J.masks + (size_t)b * J.ntile * J.words;
