@@ -109,9 +109,12 @@ __device__ inline void load_prim_saved(PrimLds& P, const float* prm, int kind, i
 __device__ inline void sample_wg(PrimLds& P, float* red, int b, int k,
     const float* __restrict__ params, const int32_t* __restrict__ kinds, const float* __restrict__ u,
     uint64_t seed, uint64_t sample_base, int K, int n,
-    float* __restrict__ points, const RasterPrep& rp, const FeatJob* feat) {
+    float* __restrict__ points, const RasterPrep& rp, const FeatJob* feat, const FeatJob* gt = nullptr,
+    float* red_gt = nullptr) {
     const float* prm = params + ((size_t)b * K + k) * VPN_PARAM_STRIDE;
     if (threadIdx.x == 0) load_prim(P, prm, kinds[k], n);
+    // slice k of the ground-truth cloud's features by the waves that would otherwise wait for the pose lane
+    if (gt) feat_slice_early(*gt, b, k, 64, red_gt);
     // the training step renders the same primitives: their raster records (pose, ray coefficients, culling conic) are
     // written by this launch -- one launch less per step.  The record lane (first lane of the second wave) makes the
     // camera while the pose lane makes the pose (two chains of sin / cos side by side in front of the barrier), and
@@ -131,6 +134,7 @@ __device__ inline void sample_wg(PrimLds& P, float* red, int b, int k,
         if (threadIdx.x == 131) rp.zero_me[4 + 4 * b + 3] = 0;
     }
     __syncthreads();
+    if (gt && threadIdx.x == 65) feat_slice_publish(*gt, b, k, 64, red_gt);
     if (rec_lane) {
         float4 r[R_REC];
         make_record_from(C, P.pose, prm, kinds[k] == VPN_SPHERE ? VPN_SPHERE : VPN_CUBOID, rp.H, rp.W, rp.sigma, r);
@@ -196,10 +200,13 @@ __global__ __launch_bounds__(SAMP_BLOCK) void sample_feat_fwd_kernel(
     if (seed_dev) seed += *seed_dev;
     int b, sy;
     feat_decode(blockIdx.x, B, b, sy);
+#ifdef SAMP_GT_AFTER
     sample_wg(P, red, b, sy, params, kinds, u, seed, sample_base, K, n, points, rp, &pred);
-#ifndef SAMP_EXP_NOGT
     __syncthreads();                                   // `red` of the sampled cloud's slice has been read
     feat_slice(gt, b, sy, red);
+#else
+    __shared__ float red_gt[SAMP_BLOCK / 64];
+    sample_wg(P, red, b, sy, params, kinds, u, seed, sample_base, K, n, points, rp, &pred, &gt, red_gt);
 #endif
 }
 

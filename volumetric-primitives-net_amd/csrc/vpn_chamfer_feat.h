@@ -152,6 +152,30 @@ __device__ inline void feat_slice(const FeatJob& J, int b, int by, float* red) {
     feat_finish_slice(J, b, by, nv, red);
 }
 
+// The same slice by the lanes [first, CFEAT_THREADS) of a workgroup and WITHOUT its barrier: the caller has one coming
+// anyway (the sampler's pose barrier: the slice's loads then overlap the pose lane's chain instead of forming a phase of
+// their own behind the sampling).  The waves' max norms go to red[wave]; after the caller's barrier ONE lane calls
+// feat_slice_publish.  `first` is a multiple of 64.
+__device__ inline void feat_slice_early(const FeatJob& J, int b, int by, int first, float* red) {
+    if (by == 0 && (int)threadIdx.x >= J.ysplit && threadIdx.x < CFEAT_SLOTS) J.nmax[b * CFEAT_SLOTS + threadIdx.x] = 0u;
+    if ((int)threadIdx.x < first) return;
+    const float* pb = J.pts + (size_t)b * J.N * 3;
+    float nv = 0.f;
+    const int per = ((J.Np + J.ysplit - 1) / J.ysplit + 63) & ~63;
+    const int jlo = by * per, jhi = min(J.Np, jlo + per), lanes = CFEAT_THREADS - first;
+    for (int j = jlo + (int)threadIdx.x - first; j < jhi; j += lanes) {
+        const F3 v3 = ld3(pb + min(j, J.N - 1) * 3);
+        nv = fmaxf(nv, feat_point(J, b, j, v3.x, v3.y, v3.z));
+    }
+    nv = feat_wave_max(nv);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = nv;
+}
+__device__ inline void feat_slice_publish(const FeatJob& J, int b, int by, int first, const float* red) {
+    float m = red[first >> 6];
+    for (int w = (first >> 6) + 1; w < CFEAT_THREADS / 64; ++w) m = fmaxf(m, red[w]);
+    J.nmax[b * CFEAT_SLOTS + by] = __float_as_uint(m);
+}
+
 // host side (chamfer.hip): the two feature jobs of the fp16 filter inside a caller-provided Chamfer workspace, in the
 // layout vpn_chamfer_fwd_ws(mode 7) expects.  p1 [B,N,3] is the cloud the caller is about to write (pts may be its
 // address or null), p2 [B,M,3] the other one.  Returns 0, or VPN_E_BADARG if the workspace is short / misaligned or the
