@@ -214,6 +214,9 @@ def main():
                     help='fixed GLOBAL batch split evenly over the ranks (C4: 256): strong scaling')
     ap.add_argument('--prims', type=int, default=None)
     ap.add_argument('--points', type=int, default=256, help='sampled points per primitive')
+    ap.add_argument('--kinds', choices=['spheres', 'cuboids', 'mixed'], default='spheres',
+                    help='primitive kinds of the C3 workload: all spheres (reference default, config.py:33-34), all cuboids, or '
+                         'half cuboids then half spheres (the order of train.py:112-116) -- SURVEY.md 8d secondary runs')
     ap.add_argument('--gt-points', type=int, default=2048)
     ap.add_argument('--size', type=int, default=None)
     ap.add_argument('--collective', choices=['allreduce', 'allgather'], default='allreduce',
@@ -291,7 +294,9 @@ def main():
         B = args.batch or 64
         scaling = 'weak'
     Bg = B * world
-    kinds = vpn_amd.kinds_tensor([vpn_amd.SPHERE] * K, dev)      # reference default: all spheres (config.py:33-34)
+    kinds_list = {'spheres': [vpn_amd.SPHERE] * K, 'cuboids': [vpn_amd.CUBOID] * K,
+                  'mixed': [vpn_amd.CUBOID] * (K // 2) + [vpn_amd.SPHERE] * (K - K // 2)}[args.kinds]
+    kinds = vpn_amd.kinds_tensor(kinds_list, dev)               # reference default: all spheres (config.py:33-34)
     # rank r owns global samples [r*B, (r+1)*B)
     params_all, gt_all = synth_inputs(Bg, K, M, 1234, dev)
     params = params_all[rank * B:(rank + 1) * B].clone().requires_grad_(True)
@@ -516,8 +521,12 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
             'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'launch': 'hip-graph replay' if use_graph else 'eager',
-            'config': {'workload': '%s: B=%d/GPU (global %d), K=%d sphere primitives, %dx%d silhouette+depth, n=%d pts/prim '
-                                   '(N=%d) vs M=%d GT points, Chamfer+L1 fwd+bwd' % (name, B, Bg, K, H, W, n, N, M),
+            'config': {'workload': '%s: B=%d/GPU (global %d), K=%d %s, %dx%d silhouette+depth, n=%d pts/prim '
+                                   '(N=%d) vs M=%d GT points, Chamfer+L1 fwd+bwd'
+                                   % (name if args.kinds == 'spheres' else name + ' variant', B, Bg, K,
+                                      {'spheres': 'sphere primitives', 'cuboids': 'cuboid primitives',
+                                       'mixed': 'primitives (%d cuboids then %d spheres)' % (K // 2, K - K // 2)}[args.kinds],
+                                      H, W, n, N, M),
                        'global_batch': Bg, 'parallelism': 'dp%d' % world, 'collective': coll,
                        'sampling': 'fresh Philox draws every step (device step counter, %d steps drawn)' % (seed_after - 1234)},
             'hip_event_ms_per_step': {k: (round(v, 5) if isinstance(v, float) else v) for k, v in ev.items()},
@@ -531,6 +540,44 @@ def main():
             out['cpu_baseline'] = cpu
         if c2 is not None:
             out['c2'] = c2
+        if world == 1 and not args.no_extras and args.kinds == 'spheres':
+            # SURVEY.md 8d secondary runs: the same step with cuboid primitives (their sampler, raster and gradient branches)
+            def variant(klist):
+                kt_ = vpn_amd.kinds_tensor(klist, dev)
+                pv = params.detach().clone().requires_grad_(True)
+                with torch.no_grad():
+                    av, dv = vpn_amd.RasterFunction.apply(p2_all[rank * B:(rank + 1) * B].contiguous(), kt_, cam, H, W, sigma, gamma, z_far)
+                gs, gdp = (av > 0.5).float(), dv.clone()
+                sb = torch.full((1,), 1234, dtype=torch.int64, device=dev)
+
+                def comp(_i=0):
+                    pv.grad = None
+                    o = vpn_amd.HotPathLossFunction.apply(pv, kt_, cam, gt_points, gs, gdp, n, sb, rank * B, H, W, sigma, gamma, z_far,
+                                                          1.0, 1.0, 1.0, 1.0, 1.0, False, True)
+                    o[2].backward(one)
+                    return o[2]
+                sd = torch.cuda.Stream()
+                sd.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(sd):
+                    for i in range(3):
+                        comp(i)
+                torch.cuda.current_stream().wait_stream(sd)
+                torch.cuda.synchronize()
+                gph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gph):
+                    lv = comp(0)
+                for _ in range(10):
+                    gph.replay()
+                e = event_windows(lambda i: gph.replay(), 100, 3)
+                with _lib.KernelProfile() as kpv:
+                    for i in range(10):
+                        comp(i)
+                ku = {k: round(v[1] * 1e3, 2) for k, v in kpv.summary().items()}
+                return {'ms_per_step': round(e['median'], 5), 'images_per_s': round(B / e['median'] * 1e3, 1), 'loss': float(lv),
+                        'finite_grad': bool(torch.isfinite(pv.grad).all()), 'kernel_us': ku}
+            out['kinds_variants'] = {'cuboids': guarded(variant, [vpn_amd.CUBOID] * K),
+                                     'mixed (K/2 cuboids then spheres, train.py:112-116)':
+                                         guarded(variant, [vpn_amd.CUBOID] * (K // 2) + [vpn_amd.SPHERE] * (K - K // 2))}
         if world == 1 and not args.no_extras:      # row f1, outside the metric: the auction EMD loss of the same step
             out['emd'] = guarded(emd_extra, B, M, dev, vpn_amd, cpu is not None and 'error' not in cpu)
         print(json.dumps(out), flush=True)

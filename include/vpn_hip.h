@@ -245,9 +245,8 @@ int vpn_raster_total_fwd_fin(const float* params, const int32_t* kinds, const fl
  * Chamfer workspace (vpn_chamfer_workspace(B, K*n, M) bytes), the matrix-pipe filter's features of the cloud it
  * samples and of gt_points [B,M,3]; the caller then runs vpn_chamfer_fwd_ws(points, gt_points, ..., mode 7) on the same
  * workspace and stream, which skips its feature kernel (the points would be written and immediately re-read).
- * chamfer_ws == NULL: gt_points / M / chamfer_ws_bytes are ignored.
- * records == NULL (ABI 4; loss_ws required): the records are left to the rider of vpn_hotpath_chamfer_fwd (given params
- * there); this launch still zeroes the counters of loss_ws and keeps the seed at loss_ws + 8. */
+ * chamfer_ws == NULL: gt_points / M / chamfer_ws_bytes are ignored.  With a Chamfer workspace the records are built
+ * by workgroups of their own at the head of the launch (one lane per primitive), not by the sampler workgroups. */
 int vpn_hotpath_sample_fwd(const float* params, const int32_t* kinds, const float* u,
                            uint64_t seed, const uint64_t* seed_dev, uint64_t sample_base, int B, int K, int n,
                            float* points, const float* cam, int H, int W, float sigma, void* records, void* loss_ws,
@@ -260,15 +259,11 @@ int vpn_hotpath_fused_features(int B, int K, int n, int M);
  * writes the tile masks into `records` (as written by vpn_hotpath_sample_fwd earlier on this stream) and tile_order
  * [B][tiles] uint16 (vpn_raster_order_size bytes): the tiles sorted by their number of visible primitives, heaviest
  * first -- the launch order vpn_raster_total_fwd_fin takes.  tile_order == NULL: exactly vpn_chamfer_fwd_ws.
- * params / kinds / cam / sigma (ABI 4; all NULL / 0 = as before): the rider also BUILDS the raster records of the
- * primitives (one lane per primitive; vpn_hotpath_sample_fwd was then called with records = NULL and does not spend its
- * critical path on them) -- the same records bit for bit.
  * VPN_E_TOOBIG if K > 255 or the image has more than 16384 tiles (the caller then runs without an order). */
 size_t vpn_raster_order_size(int B, int H, int W);
 int vpn_hotpath_chamfer_fwd(const float* p1, const float* p2, int B, int N, int M, float* dist1, int32_t* idx1,
                             float* dist2, int32_t* idx2, void* workspace, size_t workspace_bytes, int mode,
-                            void* records, int K, int H, int W, void* tile_order, const float* params,
-                            const int32_t* kinds, const float* cam, float sigma, void* stream);
+                            void* records, int K, int H, int W, void* tile_order, void* stream);
 int vpn_loss_finalize(void* loss_ws, int B, int H, int W, const float* dist1, const float* dist2, int N, int M,
                       float cd_w1, float cd_w2, float w_cd, float w_sil, float w_dep, float* losses, float* loss_b,
                       void* stream);

@@ -45,8 +45,8 @@ def test_argument_validation_needs_no_gpu():
     assert L.vpn_loss_finalize(None, 1, 8, 8, None, None, 0, 0, 1.0, 1.0, 1.0, 1.0, 1.0, None, None, None) == -1
     assert L.vpn_raster_total_bwd(None, None, 1, 1, 8, 8, None, None, None, None, 0, None) == -1
     assert L.vpn_camera_transform_fwd(None, None, None, None, None, 1, 8, 1, None, None) == -1
-    assert L.vpn_raster_records_size(2, 3, 32, 32) == 2 * 3 * 14 * 16 + 2 * 4 * 8         # records + one mask word per tile
-    assert L.vpn_raster_records_size(1, 65, 16, 16) == 65 * 14 * 16 + 2 * 8
+    assert L.vpn_raster_records_size(2, 3, 32, 32) == 2 * 3 * 16 * 16 + 2 * 4 * 8         # records + one mask word per tile
+    assert L.vpn_raster_records_size(1, 65, 16, 16) == 65 * 16 * 16 + 2 * 8
     assert L.vpn_raster_bwd_workspace(2, 3, 32, 32) == 2 * 4 * 3 * 12 * 4
     assert L.vpn_raster_bwd_workspace(0, 3, 32, 32) == 0
     assert L.vpn_raster_loss_workspace(2, 32, 32) == 16 + 2 * 16 + 2 * 4 * 2 * 4

@@ -41,7 +41,7 @@ def sampler(s):
 
 def scan_rider(s):
     _lib.call('vpn_hotpath_chamfer_fwd', P(points), P(gt_points), B, N, M, P(d1), P(i1), P(d2), P(i2), P(cws), cws.numel() * 4, 7, P(rec), K, H, W,
-              P(order), None, None, None, 0.0, sp(s))
+              P(order), sp(s))
 
 
 def scan(s):

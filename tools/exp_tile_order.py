@@ -33,7 +33,7 @@ torch.cuda.synchronize()
 ref = losses.clone()
 gref = ws.clone()
 ntile = 256
-masks = rec.view(torch.int64)[B * K * 14 * 2:][:B * ntile].cpu()
+masks = rec.view(torch.int64)[L.vpn_raster_records_size(B, K, H, W) // 8 - B * ntile:].cpu()
 pop = torch.tensor([bin(int(m) & ((1 << 64) - 1)).count('1') for m in masks.tolist()]).reshape(B, ntile)
 order = torch.argsort(pop, dim=1, descending=True, stable=True).to(torch.int16).contiguous().to(dev)      # uint16 values < 256
 

@@ -20,7 +20,7 @@ _lib.call('vpn_raster_total_fwd_fin', _lib.ptr(params), _lib.ptr(kinds), _lib.pt
           1.0, 1.0, _lib.ptr(rec), _lib.ptr(lws), _lib.ptr(ws), 0, None, 0, 0, 0, 0.0, 0.0, 0.0, _lib.ptr(losses), None, None, None, _lib.stream())
 torch.cuda.synchronize()
 ntile = 256
-masks = rec.view(torch.int64)[B * K * 14 * 2:][:B * ntile].cpu()
+masks = rec.view(torch.int64)[L.vpn_raster_records_size(B, K, H, W) // 8 - B * ntile:].cpu()
 pop = torch.tensor([bin(int(m) & ((1 << 64) - 1)).count('1') for m in masks.tolist()]).reshape(B, ntile)
 print('tiles:', pop.numel(), 'mean visible primitives per tile %.2f' % pop.float().mean(), 'max', int(pop.max()))
 h = torch.bincount(pop.flatten(), minlength=12)

@@ -44,8 +44,7 @@ SIGNATURES = {
                                     _c_f, _i, _c_f, _sz, _c_f]),
     'vpn_hotpath_fused_features': (_i, [_i, _i, _i, _i]),
     'vpn_raster_order_size': (_sz, [_i, _i, _i]),
-    'vpn_hotpath_chamfer_fwd': (_i, [_c_f, _c_f, _i, _i, _i, _c_f, _c_f, _c_f, _c_f, _c_f, _sz, _i, _c_f, _i, _i, _i, _c_f, _c_f,
-                                     _c_f, _c_f, _f, _c_f]),
+    'vpn_hotpath_chamfer_fwd': (_i, [_c_f, _c_f, _i, _i, _i, _c_f, _c_f, _c_f, _c_f, _c_f, _sz, _i, _c_f, _i, _i, _i, _c_f, _c_f]),
     'vpn_loss_finalize': (_i, [_c_f, _i, _i, _i, _c_f, _c_f, _i, _i, _f, _f, _f, _f, _f, _c_f, _c_f, _c_f]),
     'vpn_raster_total_bwd': (_i, [_c_f, _c_f, _i, _i, _i, _i, _c_f, _c_f, _c_f, _c_f, _i, _c_f]),
     'vpn_hotpath_bwd': (_i, [_c_f, _c_f, _c_f, _u64, _c_f, _u64, _i, _i, _i, _c_f, _c_f, _i, _c_f, _c_f, _c_f, _c_f, _c_f,

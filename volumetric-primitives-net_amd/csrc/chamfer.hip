@@ -1070,21 +1070,19 @@ __global__ __launch_bounds__(cm_block<PREC>(), PREC == 1 ? 5 : CM_WAVES_PER_EU) 
         // of the launch, where a third of the slots is idle) sort the raster's tiles, one image each.  The launch sits
         // between the one that writes the raster records and the one that reads masks and order, so neither a hand-off
         // nor a launch of its own is needed.
-#ifdef CM_RIDER_LAST
+#ifndef CM_RIDER_FIRST
         if ((int)blockIdx.x >= j0.G + j1.G) {
             raster_order_wg<cm_block<PREC>()>(oj, (int)blockIdx.x - (j0.G + j1.G), tileH16);
             return;
         }
 #else
-        // a rider that also builds the records is a ~9 us chain: dispatched FIRST (ids [0, oj.B)) it ends long before the
-        // scan does; dispatched last it was the launch's tail (+2 us)
         if ((int)blockIdx.x < oj.B) {
             raster_order_wg<cm_block<PREC>()>(oj, (int)blockIdx.x, tileH16);
             return;
         }
 #endif
     }
-#ifdef CM_RIDER_LAST
+#ifndef CM_RIDER_FIRST
     const int wg = (int)blockIdx.x;
 #else
     const int wg = (int)blockIdx.x - (PREC == 2 ? oj.B : 0);
@@ -2148,8 +2146,7 @@ extern "C" int vpn_chamfer_fwd_ws(const float* p1, const float* p2, int B, int N
 
 // vpn_chamfer_fwd_ws of the training step with the raster's tile order as a rider of the scan launch (modes 0 / 6 / 7
 // where the fp16 filter is taken: vpn_hotpath_fused_features).  records: as written by vpn_hotpath_sample_fwd earlier
-// on this stream -- or, with params / kinds / cam / sigma given, written HERE by the rider (vpn_hotpath_sample_fwd was
-// then called with records = NULL); the tile masks inside them and tile_order [B][tiles] uint16 are written here.
+// on this stream; the tile masks inside them and tile_order [B][tiles] uint16 are written here.
 extern "C" size_t vpn_raster_order_size(int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0) return 0;
     const size_t ntile = (size_t)((W + R_TW - 1) / R_TW) * ((H + R_TH - 1) / R_TH);
@@ -2158,8 +2155,7 @@ extern "C" size_t vpn_raster_order_size(int B, int H, int W) {
 
 extern "C" int vpn_hotpath_chamfer_fwd(const float* p1, const float* p2, int B, int N, int M, float* dist1, int32_t* idx1,
                                        float* dist2, int32_t* idx2, void* workspace, size_t workspace_bytes, int mode,
-                                       void* records, int K, int H, int W, void* tile_order, const float* params,
-                                       const int32_t* kinds, const float* cam, float sigma, void* stream) {
+                                       void* records, int K, int H, int W, void* tile_order, void* stream) {
     if (!p1 || !p2 || !dist1 || !idx1 || !dist2 || !idx2 || !workspace) return VPN_E_BADARG;
     if (B <= 0 || N <= 0 || M <= 0) return VPN_E_BADARG;
     if (B > 65535 || (long long)B * N > 0x7fffffffLL || (long long)B * M > 0x7fffffffLL) return VPN_E_TOOBIG;
@@ -2178,10 +2174,6 @@ extern "C" int vpn_hotpath_chamfer_fwd(const float* p1, const float* p2, int B, 
         oj.words = (K + 63) / 64;
         oj.masks = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(records) + (size_t)B * K * R_REC * sizeof(float4));
         oj.order = (unsigned short*)tile_order;
-        if (params) {                                    // the rider also builds the records (the sampler launch did not)
-            if (!kinds || !cam || !(sigma > 0.f)) return VPN_E_BADARG;
-            oj.params = params; oj.kinds = kinds; oj.cam = cam; oj.sigma = sigma; oj.rec_out = (float4*)records;
-        }
         if (K > 255 || oj.ntile > R_ORDER_MAX_TILES || raster_order_scratch(K, oj.ntile) > 2 * CM_TILE16 * CM_ROWB) return VPN_E_TOOBIG;
         rider = &oj;
     }

@@ -258,7 +258,10 @@ __device__ inline unsigned long long uniform64(unsigned long long v) {
 }
 
 constexpr int R_SLOT = 4;            // float4 per staged primitive: (o~|kind, Mr|k, Mu, Mf)
-constexpr int R_LDS_F4 = 64 * R_SLOT + 64 * R_CULL;   // per wave: 64 staged records + their culling records (7 KB)
+// LDS of a tile wave (dynamic): `nslot` staged records, then their culling records.  nslot = min(K, 64): a mask word's
+// worth -- 4.5 KB at K = 32, 9 KB from K = 64 on
+__host__ __device__ inline int raster_nslot(int K) { return K < 64 ? K : 64; }
+__host__ __device__ inline size_t raster_lds_bytes(int K) { return (size_t)raster_nslot(K) * (R_SLOT + R_CULL) * sizeof(float4) + 4 * sizeof(unsigned long long); }
 
 // Mask word w of this tile and staging of its visible primitives in one go: lane i fetches the whole record of
 // primitive 64 w + i (7 float4, one round trip), tests it against the tile, and if visible stores its ray coefficients
@@ -275,16 +278,20 @@ __device__ inline unsigned long long stage_word(const Tile& T, const float4* __r
     if (mask_in) {
         m = uniform64(mask_in[w]);
     } else {
-        const float4 bb = rk[4], qa = rk[5], qb = rk[6];
-        m = __ballot(k < K && prim_hits_tile(bb, qa, qb, T.c0, T.r0, H, W));
+        float4 cr[R_CULL];
+#pragma unroll
+        for (int i = 0; i < R_CULL; ++i) cr[i] = rk[4 + i];
+        m = __ballot(k < K && prim_hits_tile(__float_as_int(a.w), cr, T.c0, T.r0, H, W));
         if (mask_out && lane == 0) mask_out[w] = m;
     }
     if ((m >> lane) & 1ull) {
         const int slot = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
         b.w = __int_as_float(k);
         srec[slot * R_SLOT + 0] = a; srec[slot * R_SLOT + 1] = b; srec[slot * R_SLOT + 2] = c; srec[slot * R_SLOT + 3] = d;
-        float4* scull = srec + 64 * R_SLOT + slot * R_CULL;
-        scull[0] = rk[4]; scull[1] = rk[5]; scull[2] = rk[6];
+        float4* scull = srec + raster_nslot(K) * R_SLOT + slot * R_CULL;
+        const bool box = __float_as_int(a.w) != VPN_SPHERE;                  // an ellipsoid's conic ends at float4 2
+#pragma unroll
+        for (int i = 0; i < R_CULL; ++i) if (i < 3 || box) scull[i] = rk[4 + i];
     }
     __builtin_amdgcn_wave_barrier();
     return m;
@@ -293,15 +300,29 @@ __device__ inline unsigned long long stage_word(const Tile& T, const float4* __r
 // Second level of the cull: which of the tile's four 8x8 quadrants can staged primitive j reach?  Lane l tests
 // (slot l >> 2, quadrant l & 3) of 16 slots per pass; the ballot holds 4 bits per slot.  Returns the ballot of pass
 // `pass` (slots 16 pass .. 16 pass + 15), wave-uniform.
-__device__ inline unsigned long long quadrant_bits(const Tile& T, const float4* srec, int n, int pass, int H, int W) {
+__device__ inline unsigned long long quadrant_bits(const Tile& T, const float4* srec, int n, int pass, int K, int H, int W) {
     const int lane = threadIdx.x & 63;
     const int slot = pass * 16 + (lane >> 2), qd = lane & 3;
     bool vis = false;
     if (slot < n) {
-        const float4* scull = srec + 64 * R_SLOT + slot * R_CULL;
-        vis = prim_hits_tile(scull[0], scull[1], scull[2], T.c0 + 8 * (qd & 1), T.r0 + 8 * (qd >> 1), H, W, 8, 8);
+        const float4* scull = srec + raster_nslot(K) * R_SLOT + slot * R_CULL;
+        vis = prim_hits_tile(__float_as_int(srec[slot * R_SLOT].w), scull, T.c0 + 8 * (qd & 1), T.r0 + 8 * (qd >> 1), H, W, 8, 8);
     }
     return __ballot(vis);
+}
+
+// all passes of the staged word at once, kept in LDS behind the culling records: the forward and the backward loop of a
+// tile read them from there (one copy of the test in the kernel, one evaluation per tile)
+__device__ inline unsigned long long* quadrant_words(float4* srec, int K) {
+    return reinterpret_cast<unsigned long long*>(srec + raster_nslot(K) * (R_SLOT + R_CULL));
+}
+__device__ inline void quadrant_bits_all(const Tile& T, float4* srec, int n, int K, int H, int W) {
+    unsigned long long* sq = quadrant_words(srec, K);
+    for (int pass = 0; pass * 16 < n; ++pass) {
+        const unsigned long long qb = quadrant_bits(T, srec, n, pass, K, H, W);
+        if ((threadIdx.x & 63) == 0) sq[pass] = qb;
+    }
+    __builtin_amdgcn_wave_barrier();
 }
 
 // Fused image losses: SilhouetteLoss (L1 / MSE mean against the GT silhouette, modules/loss/silhouette.py:11,22) and
@@ -409,9 +430,10 @@ __device__ inline unsigned long long tile_forward(const Tile& T, const float4* _
                                                    : stage_word(T, rec_b, w, K, H, W, srec, nullptr, mrow);
         if (w == 0) m0 = m;
         const int n = __builtin_popcountll(m);
+        quadrant_bits_all(T, srec, n, K, H, W);
         unsigned long long qb = 0ull;
         for (int j = 0; j < n; ++j) {
-            if ((j & 15) == 0) qb = quadrant_bits(T, srec, n, j >> 4, H, W);
+            if ((j & 15) == 0) qb = uniform64(quadrant_words(srec, K)[j >> 4]);
             const unsigned qm = (unsigned)(qb >> (4 * (j & 15))) & 15u;
             const float4 q0 = srec[j * R_SLOT], q1 = srec[j * R_SLOT + 1], q2 = srec[j * R_SLOT + 2], q3 = srec[j * R_SLOT + 3];
             auto body = [&](auto kind_c) {
@@ -437,8 +459,8 @@ __device__ inline unsigned long long tile_forward(const Tile& T, const float4* _
 // coefficients, summed over the lane's 4 pixels, reduced over the wave and written as 48 contiguous bytes of
 // partial[b][k][tile] -- only for the (primitive, tile) pairs of the tile masks; raster_bwd_finish_kernel reads
 // exactly those.  No atomics: bitwise reproducible.  `staged`: srec already holds the records of mask word 0 = m0
-// (one-pass kernel with K <= 64); mrow: masks stored by an EARLIER launch, or null to repeat the test (a wave does not
-// read back the mask words it stored itself a moment ago).
+// (one-pass kernel with K <= 64); mrow: the tile's mask words (stored by an earlier launch, or by this wave's lane 0 in
+// its forward half: stage_word takes lane 0's value), or null to repeat the test.
 __device__ inline void tile_backward(const Tile& T, const float4* __restrict__ rec_b, const unsigned long long* __restrict__ mrow,
                                      int words, int K, int ntile, int H, int W, float4* srec, bool staged,
                                      unsigned long long m0, float inv_sigma,
@@ -448,9 +470,10 @@ __device__ inline void tile_backward(const Tile& T, const float4* __restrict__ r
     const int lane = threadIdx.x & 63;
     for (int w = 0; w < words; ++w) {
         const int n = __builtin_popcountll(staged ? m0 : stage_word(T, rec_b, w, K, H, W, srec, mrow, nullptr));
+        if (!staged) quadrant_bits_all(T, srec, n, K, H, W);          // staged: the forward loop left them in LDS
         unsigned long long qb = 0ull;
         for (int j = 0; j < n; ++j) {
-            if ((j & 15) == 0) qb = quadrant_bits(T, srec, n, j >> 4, H, W);
+            if ((j & 15) == 0) qb = uniform64(quadrant_words(srec, K)[j >> 4]);
             const unsigned qm = (unsigned)(qb >> (4 * (j & 15))) & 15u;
             const float4 q0 = srec[j * R_SLOT], q1 = srec[j * R_SLOT + 1], q2 = srec[j * R_SLOT + 2], q3 = srec[j * R_SLOT + 3];
             const int k = __builtin_amdgcn_readfirstlane(__float_as_int(q1.w));
@@ -501,7 +524,7 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(const float4* __restrict
     const int ntile = tiles_x * tiles_y, lane = threadIdx.x & 63;
     const float vz0 = __int_as_float(vzero());
     const float inv_sigma = 1.0f / (sigma + vz0), inv_gamma = 1.0f / (gamma + vz0), zref = cam[T.b * 3] + vz0;
-    __shared__ __attribute__((aligned(16))) float4 srec[R_LDS_F4];
+    extern __shared__ __attribute__((aligned(16))) float4 srec[];      // raster_lds_bytes(K)
     float P[R_PPL], S0[R_PPL], S1[R_PPL];
     tile_forward(T, rec + (size_t)T.b * K * R_REC, masks + ((size_t)T.b * ntile + T.tile) * words, words, K, H, W, srec,
                  inv_sigma, inv_gamma, zref, P, S0, S1);
@@ -583,7 +606,7 @@ __global__ __launch_bounds__(64, 4) void raster_bwd_kernel(const float4* __restr
             gZbar[s] = gD * (1.0f - P[s]);
         }
     }
-    __shared__ __attribute__((aligned(16))) float4 srec[R_LDS_F4];
+    extern __shared__ __attribute__((aligned(16))) float4 srec[];      // raster_lds_bytes(K)
     tile_backward(T, rec + (size_t)T.b * K * R_REC, mrow, words, K, ntile, H, W, srec, false, 0ull, inv_sigma,
                   inv_gamma, zref, P, zbar, invS, gAtot, gZbar, partial);
 }
@@ -623,7 +646,7 @@ __global__ __launch_bounds__(64, R_TOTAL_WAVES) void raster_total_kernel(const f
         gs[s] = (la.gt_sil && in) ? la.gt_sil[T.b * hw + pix] : 0.0f;
         gd[s] = (la.gt_depth && in) ? la.gt_depth[T.b * hw + pix] : 0.0f;
     }
-    __shared__ __attribute__((aligned(16))) float4 srec[R_LDS_F4];
+    extern __shared__ __attribute__((aligned(16))) float4 srec[];      // raster_lds_bytes(K)
     float P[R_PPL], S0[R_PPL], S1[R_PPL];
     // with an order the tile masks are there too (both come from the sampler's launch): read, not recomputed
     const unsigned long long m0 = tile_forward(T, rec_b, mrow, words, K, H, W, srec, inv_sigma, inv_gamma, zref, P, S0, S1, order != nullptr);
@@ -673,7 +696,9 @@ __global__ __launch_bounds__(64, R_TOTAL_WAVES) void raster_total_kernel(const f
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         arrived = __hip_atomic_fetch_add(reinterpret_cast<int*>(fin.persample + T.b) + 3, 1, VPN_ARRIVE_ORDER, __HIP_MEMORY_SCOPE_AGENT);
     }
-    tile_backward(T, rec_b, nullptr, words, K, ntile, H, W, srec, words == 1, m0, inv_sigma, inv_gamma, zref, P, zbar, invS,
+    // K > 64: the backward restages word by word from the masks this wave stored (or read) in the forward half -- lane 0
+    // reads back its own stores, program order -- instead of repeating the visibility test
+    tile_backward(T, rec_b, mrow, words, K, ntile, H, W, srec, words == 1, m0, inv_sigma, inv_gamma, zref, P, zbar, invS,
                   gAtot, gZbar, partial);
     if (fin.enabled && __builtin_amdgcn_readfirstlane(arrived) == ntile - 1) finalize_sample(fin, la, T.b, ntile);
 }
@@ -812,7 +837,7 @@ static int raster_check(const void* params, const void* kinds, const void* cam, 
     return 0;
 }
 
-// records = [B*K][7] float4, then the tile masks [B*ntile][words] uint64
+// records = [B*K][R_REC] float4, then the tile masks [B*ntile][words] uint64
 static inline size_t rec_bytes(int B, int K) { return (size_t)B * K * R_REC * sizeof(float4); }
 extern "C" size_t vpn_raster_records_size(int B, int K, int H, int W) {
     if (B <= 0 || K <= 0 || H <= 0 || W <= 0) return 0;
@@ -844,7 +869,7 @@ extern "C" int vpn_raster_fwd(const float* params, const int32_t* kinds, const f
     if (((uintptr_t)records & 15) != 0) return VPN_E_BADARG;
     if ((rc = launch_prep(params, kinds, cam, B, K, H, W, sigma, records, nullptr, (hipStream_t)stream))) return rc;
     const Grid G = raster_grid(B, K, H, W);
-    VPN_LAUNCH(raster_fwd_kernel<0>, G.g, dim3(64), 0, (hipStream_t)stream, (const float4*)records,
+    VPN_LAUNCH(raster_fwd_kernel<0>, G.g, dim3(64), raster_lds_bytes(K), (hipStream_t)stream, (const float4*)records,
                masks_of(records, B, K), cam, B, K, H, W, G.tiles_x, G.tiles_y, G.words, sigma, gamma, z_far, alpha,
                depth, aux, LossArgs{});
     VPN_LAUNCH_CHECK();
@@ -884,7 +909,7 @@ extern "C" int vpn_raster_loss_fwd(const float* params, const int32_t* kinds, co
     if ((rc = launch_prep(params, kinds, cam, B, K, H, W, sigma, records, (int*)loss_ws, s))) return rc;
     const Grid G = raster_grid(B, K, H, W);
     LossArgs la{gt_sil, gt_depth, sil_mse, 1.0f / ((float)B * (float)H * (float)W), tile_loss_of(loss_ws, B), nullptr, 0.f, 0.f};
-    VPN_LAUNCH(raster_fwd_kernel<1>, G.g, dim3(64), 0, s, (const float4*)records, masks_of(records, B, K), cam, B, K,
+    VPN_LAUNCH(raster_fwd_kernel<1>, G.g, dim3(64), raster_lds_bytes(K), s, (const float4*)records, masks_of(records, B, K), cam, B, K,
                H, W, G.tiles_x, G.tiles_y, G.words, sigma, gamma, z_far, (float*)nullptr, (float*)nullptr, aux, la);
     VPN_LAUNCH_CHECK();
     return launch_finalize(loss_ws, true, B, H, W, nullptr, nullptr, 0, 0, 0.f, 0.f, 0.f, 1.0f, 1.0f, losses, nullptr, s);
@@ -915,7 +940,7 @@ extern "C" int vpn_raster_bwd(const float* params, const int32_t* kinds, const f
     if (!aux || !records || !workspace || !grad_params) return VPN_E_BADARG;
     if (((uintptr_t)records & 15) != 0 || ((uintptr_t)workspace & 15) != 0) return VPN_E_BADARG;
     const Grid G = raster_grid(B, K, H, W);
-    VPN_LAUNCH(raster_bwd_kernel<0>, G.g, dim3(64), 0, (hipStream_t)stream, (const float4*)records, masks_of(records, B, K),
+    VPN_LAUNCH(raster_bwd_kernel<0>, G.g, dim3(64), raster_lds_bytes(K), (hipStream_t)stream, (const float4*)records, masks_of(records, B, K),
                cam, B, K, H, W, G.tiles_x, G.tiles_y, G.words, sigma, gamma, z_far, aux, grad_alpha, grad_depth,
                (float*)workspace, LossArgs{});
     VPN_LAUNCH_CHECK();
@@ -932,7 +957,7 @@ extern "C" int vpn_raster_loss_bwd(const float* params, const int32_t* kinds, co
     if (((uintptr_t)records & 15) != 0 || ((uintptr_t)workspace & 15) != 0) return VPN_E_BADARG;
     const Grid G = raster_grid(B, K, H, W);
     LossArgs la{gt_sil, gt_depth, sil_mse, 1.0f / ((float)B * (float)H * (float)W), nullptr, grad_losses, 0.f, 0.f};
-    VPN_LAUNCH(raster_bwd_kernel<1>, G.g, dim3(64), 0, (hipStream_t)stream, (const float4*)records, masks_of(records, B, K),
+    VPN_LAUNCH(raster_bwd_kernel<1>, G.g, dim3(64), raster_lds_bytes(K), (hipStream_t)stream, (const float4*)records, masks_of(records, B, K),
                cam, B, K, H, W, G.tiles_x, G.tiles_y, G.words, sigma, gamma, z_far, aux, (const float*)nullptr,
                (const float*)nullptr, (float*)workspace, la);
     VPN_LAUNCH_CHECK();
@@ -951,7 +976,7 @@ extern "C" int vpn_raster_total_fwd(const float* params, const int32_t* kinds, c
     if (!records_ready && (rc = launch_prep(params, kinds, cam, B, K, H, W, sigma, records, (int*)loss_ws, s))) return rc;
     const Grid G = raster_grid(B, K, H, W);
     LossArgs la{gt_sil, gt_depth, sil_mse, 1.0f / ((float)B * (float)H * (float)W), tile_loss_of(loss_ws, B), nullptr, w_sil, w_dep};
-    VPN_LAUNCH(raster_total_kernel, G.g, dim3(64), 0, s, (const float4*)records, masks_of(records, B, K), cam, B, K,
+    VPN_LAUNCH(raster_total_kernel, G.g, dim3(64), raster_lds_bytes(K), s, (const float4*)records, masks_of(records, B, K), cam, B, K,
                H, W, G.tiles_x, G.tiles_y, G.words, sigma, gamma, z_far, (float*)workspace, la, FinArgs{}, (const unsigned short*)nullptr);
     VPN_LAUNCH_CHECK();
     return 0;
@@ -986,7 +1011,7 @@ extern "C" int vpn_raster_total_fwd_fin(const float* params, const int32_t* kind
     const Grid G = raster_grid(B, K, H, W);
     if (tile_order && (!records_ready || G.ntile > 65535)) return VPN_E_BADARG;     // the order comes with the masks
     LossArgs la{gt_sil, gt_depth, sil_mse, 1.0f / ((float)B * (float)H * (float)W), tile_loss_of(loss_ws, B), nullptr, w_sil, w_dep};
-    VPN_LAUNCH(raster_total_kernel, G.g, dim3(64), 0, s, (const float4*)records, masks_of(records, B, K), cam, B, K,
+    VPN_LAUNCH(raster_total_kernel, G.g, dim3(64), raster_lds_bytes(K), s, (const float4*)records, masks_of(records, B, K), cam, B, K,
                H, W, G.tiles_x, G.tiles_y, G.words, sigma, gamma, z_far, (float*)workspace, la, fin, (const unsigned short*)tile_order);
     VPN_LAUNCH_CHECK();
     return 0;

@@ -91,9 +91,9 @@ __device__ inline void load_prim(PrimLds& P, const float* prm, int kind, int n) 
     if (P.kind == VPN_CUBOID) cuboid_quota(P.v, n, P.cum);
 }
 
-// the same with the pose the forward launch saved in the raster record (float4 10..13): no sin / cos on the critical path
+// the same with the pose the forward launch saved in the raster record (float4 R_FIN + 3 .. + 6): no sin / cos on the critical path
 __device__ inline void load_prim_saved(PrimLds& P, const float* prm, int kind, int n, const float4* rk) {
-    const float4 p0 = rk[10], p1 = rk[11], p2 = rk[12], p3 = rk[13];
+    const float4 p0 = rk[R_FIN + 3], p1 = rk[R_FIN + 4], p2 = rk[R_FIN + 5], p3 = rk[R_FIN + 6];
     Pose& S = P.pose;
     S.R.m[0][0] = p0.x; S.R.m[0][1] = p0.y; S.R.m[0][2] = p0.z; S.R.m[1][0] = p0.w; S.R.m[1][1] = p1.x; S.R.m[1][2] = p1.y;
     S.R.m[2][0] = p1.z; S.R.m[2][1] = p1.w; S.R.m[2][2] = p2.x; S.x = p2.y; S.y = p2.z; S.z = p2.w;
@@ -185,6 +185,10 @@ __global__ __launch_bounds__(SAMP_BLOCK) void sample_fwd_kernel(
     sample_wg(P, nullptr, blockIdx.y, blockIdx.x, params, kinds, u, seed, sample_base, K, n, points, rp, nullptr);
 }
 
+// record workgroups at the head of sample_feat_fwd_kernel's grid: a multiple of 8, so that the sampler workgroups behind
+// them keep their XCD (feat_decode)
+__host__ __device__ inline int rec_workgroups(int BK) { return ((BK + SAMP_BLOCK - 1) / SAMP_BLOCK + 7) & ~7; }
+
 // Forward launch of the training step with the Chamfer features inside: 1-D grid of B * K workgroups decoded like the
 // feature kernel's (sample b on XCD b / (B/8)): workgroup (b, k) samples primitive k (also the slot of its max norm:
 // K <= CFEAT_SLOTS) and then converts slice k of the K slices of the ground-truth cloud (64 points at C3).  The
@@ -198,15 +202,41 @@ __global__ __launch_bounds__(SAMP_BLOCK) void sample_feat_fwd_kernel(
     __shared__ float red[SAMP_BLOCK / 64];
     static_assert(SAMP_BLOCK == CFEAT_THREADS, "feature slices are written by sampler-sized workgroups");
     if (seed_dev) seed += *seed_dev;
+    // The raster records of the step's primitives: ~1000-1400 dependent instructions each (camera, pose, culling conic or
+    // silhouette hexagon).  One lane per record in workgroups of their own at the HEAD of the grid (dispatched first, done
+    // long before the launch is) -- as the record lane of every sampler workgroup they were that workgroup's critical
+    // path (2.6 us of the launch at C3).
+#ifdef SAMP_REC_IN_WG
+    const int nrec = 0;                                // A/B: the record lane of every sampler workgroup
+#else
+    const int nrec = rp.rec ? rec_workgroups(B * K) : 0;
+#endif
+    if ((int)blockIdx.x < nrec) {
+        const int bk = blockIdx.x * SAMP_BLOCK + threadIdx.x;
+        if (bk < B * K) {
+            const int rb = bk / K, rk = bk - rb * K;
+            const float* prm = params + (size_t)bk * VPN_PARAM_STRIDE;
+            const Camera C = make_camera(rp.cam + rb * 3);
+            const Pose Pq = make_pose(prm[3], prm[4], prm[5], prm[6]);
+            float4* out = rp.rec + (size_t)bk * R_REC;
+            make_record_put(C, Pq, prm, kinds[rk] == VPN_SPHERE ? VPN_SPHERE : VPN_CUBOID, rp.H, rp.W, rp.sigma,
+                            [&](int i, const float4 v) { out[i] = v; });
+        }
+        return;
+    }
+    RasterPrep rq = rp;
+#ifndef SAMP_REC_IN_WG
+    rq.rec = nullptr;                                  // the sampler workgroups keep the counters and the seed only
+#endif
     int b, sy;
-    feat_decode(blockIdx.x, B, b, sy);
+    feat_decode((int)blockIdx.x - nrec, B, b, sy);
 #ifdef SAMP_GT_AFTER
-    sample_wg(P, red, b, sy, params, kinds, u, seed, sample_base, K, n, points, rp, &pred);
+    sample_wg(P, red, b, sy, params, kinds, u, seed, sample_base, K, n, points, rq, &pred);
     __syncthreads();                                   // `red` of the sampled cloud's slice has been read
     feat_slice(gt, b, sy, red);
 #else
     __shared__ float red_gt[SAMP_BLOCK / 64];
-    sample_wg(P, red, b, sy, params, kinds, u, seed, sample_base, K, n, points, rp, &pred, &gt, red_gt);
+    sample_wg(P, red, b, sy, params, kinds, u, seed, sample_base, K, n, points, rq, &pred, &gt, red_gt);
 #endif
 }
 
@@ -748,10 +778,7 @@ extern "C" int vpn_hotpath_sample_fwd(const float* params, const int32_t* kinds,
                                       const float* cam, int H, int W, float sigma, void* records, void* loss_ws,
                                       const float* gt_points, int M, void* chamfer_ws, size_t chamfer_ws_bytes,
                                       void* stream) {
-    // records == NULL: the records are built by the rider of vpn_hotpath_chamfer_fwd (given params there); this launch
-    // still zeroes the counters of loss_ws and keeps the seed
-    if (records && (!cam || H <= 0 || W <= 0 || !(sigma > 0.f))) return VPN_E_BADARG;
-    if ((!records && !loss_ws) || K > VPN_MAX_PRIMS) return VPN_E_BADARG;
+    if (!cam || !records || H <= 0 || W <= 0 || !(sigma > 0.f) || K > VPN_MAX_PRIMS) return VPN_E_BADARG;
     if (((uintptr_t)records & 15) != 0) return VPN_E_BADARG;
     RasterPrep rp;
     rp.cam = cam; rp.H = H; rp.W = W; rp.sigma = sigma; rp.rec = (float4*)records; rp.zero_me = (int*)loss_ws;
@@ -764,7 +791,12 @@ extern "C" int vpn_hotpath_sample_fwd(const float* params, const int32_t* kinds,
     if (rc) return rc;
     pred.ysplit = K;                      // one slice (and one max-norm slot) per primitive
     gt.ysplit = K;                        // ... and the same workgroups share the ground-truth cloud
-    VPN_LAUNCH(sample_feat_fwd_kernel, dim3((unsigned)B * (unsigned)K), dim3(SAMP_BLOCK), 0, (hipStream_t)stream,
+#ifdef SAMP_REC_IN_WG
+    const unsigned nrec = 0;
+#else
+    const unsigned nrec = (unsigned)rec_workgroups(B * K);
+#endif
+    VPN_LAUNCH(sample_feat_fwd_kernel, dim3((unsigned)B * (unsigned)K + nrec), dim3(SAMP_BLOCK), 0, (hipStream_t)stream,
                params, kinds, u, seed, seed_dev, sample_base, B, K, n, points, rp, pred, gt);
     VPN_LAUNCH_CHECK();
     return 0;

@@ -15,8 +15,10 @@ constexpr float R_EPS_D = 1e-9f;
 constexpr float R_X_CUT = 16.0f;     // primitives whose coverage logit is below -X_CUT on a tile are skipped: coverage < 1.2e-7
 constexpr int R_TW = 16, R_TH = 16;  // pixel tile per wave
 constexpr int R_PPL = 4;             // pixels per lane (row groups of 4 rows)
-constexpr int R_REC = 14;            // float4 per primitive record in HBM: 7 for the tile kernels, 7 for the finishing step
-constexpr int R_CULL = 3;            // float4 per primitive staged in LDS for the tile mask (pixel box + conic)
+constexpr int R_CULL = 5;            // float4 per primitive staged in LDS for the tile mask: pixel box + conic (ellipsoid) or
+                                     // + the silhouette hexagon of the inflated box (cuboid)
+constexpr int R_FIN = 4 + R_CULL;    // first float4 of the finishing step's part of a record (camera basis and pose)
+constexpr int R_REC = R_FIN + 7;     // float4 per primitive record in HBM: 4 ray coefficients, R_CULL culling, 7 finishing = 16
 
 struct Camera {
     float eye[3], right[3], up[3], fwd[3];
@@ -62,7 +64,9 @@ __device__ inline void prim_geometry(const Camera& C, const Mat3& R, const float
 }
 
 // Record of one primitive for one camera: out[0..3] = (o~|kind, Mr, Mu, Mf) so that d~ = Mf + px Mr + py Mu;
-// out[4] = pixel bounding box of the culling ellipse (jmin, jmax, imin, imax as int bits); out[5..6] = its conic.
+// out[4] = pixel bounding box of the culling region (jmin, jmax, imin, imax as int bits); out[5..8] = the region itself:
+// ellipsoid: its conic in out[5..6]; cuboid: the silhouette hexagon of the inflated box, six half-planes
+// a (x - cx) + b (y - cy) + 1 >= 0 as (a, b) pairs in out[5..7] and the centre (cx, cy) in out[8].
 // ... from a camera and a pose that already exist (the sampler's forward launch: its pose lane has made the pose, the
 // record lane the camera, side by side; both come from make_camera / make_pose, so the record is the same bit for bit)
 __device__ inline void make_record_from(const Camera& C, const Pose& P, const float* __restrict__ prm, int kind, int H, int W,
@@ -95,13 +99,13 @@ __device__ inline void make_record_put(const Camera& C, const Pose& P, const flo
     prim_geometry(C, P.R, v, t, G);
     // out[7..13]: camera basis and pose as the finishing step of the backward needs them (it used to redo the six
     // sin / cos of make_camera and make_pose on one lane: ~1000 dependent instructions on its critical path)
-    put(7, make_float4(C.eye[0], C.eye[1], C.eye[2], C.right[0]));
-    put(8, make_float4(C.right[1], C.right[2], C.up[0], C.up[1]));
-    put(9, make_float4(C.up[2], C.fwd[0], C.fwd[1], C.fwd[2]));
-    put(10, make_float4(P.R.m[0][0], P.R.m[0][1], P.R.m[0][2], P.R.m[1][0]));
-    put(11, make_float4(P.R.m[1][1], P.R.m[1][2], P.R.m[2][0], P.R.m[2][1]));
-    put(12, make_float4(P.R.m[2][2], P.x, P.y, P.z));
-    put(13, make_float4(P.w, P.sh, P.ch, P.inv_len));
+    put(R_FIN + 0, make_float4(C.eye[0], C.eye[1], C.eye[2], C.right[0]));
+    put(R_FIN + 1, make_float4(C.right[1], C.right[2], C.up[0], C.up[1]));
+    put(R_FIN + 2, make_float4(C.up[2], C.fwd[0], C.fwd[1], C.fwd[2]));
+    put(R_FIN + 3, make_float4(P.R.m[0][0], P.R.m[0][1], P.R.m[0][2], P.R.m[1][0]));
+    put(R_FIN + 4, make_float4(P.R.m[1][1], P.R.m[1][2], P.R.m[2][0], P.R.m[2][1]));
+    put(R_FIN + 5, make_float4(P.R.m[2][2], P.x, P.y, P.z));
+    put(R_FIN + 6, make_float4(P.w, P.sh, P.ch, P.inv_len));
     put(0, make_float4(G.o[0], G.o[1], G.o[2], __int_as_float(kind)));
     put(1, make_float4(G.Mr[0], G.Mr[1], G.Mr[2], 0.f));
     put(2, make_float4(G.Mu[0], G.Mu[1], G.Mu[2], 0.f));
@@ -110,10 +114,84 @@ __device__ inline void make_record_put(const Camera& C, const Pose& P, const flo
     // of which the coverage logit (1 - m2)/sigma is below -X_CUT.  With d~ = M p, p = (px, py, 1) and
     // M = [Mr Mu Mf]:  m2 <= L2  <=>  q(p) = (u.p)^2 - c p^T G p >= 0,  u = M^T o~, G = M^T M,
     // c = |o~|^2 - L2: a conic in the image plane (an ellipse when the camera is outside the inflated
-    // primitive).  A cuboid is bounded by the sphere of radius sqrt(3) lam in its scaled frame.
-    float L2 = (1.0f + R_X_CUT * sigma) * 1.004f;
-    if (kind != VPN_SPHERE) L2 *= 3.0f;
+    // primitive).
+    const float L2 = (1.0f + R_X_CUT * sigma) * 1.004f;
     const float txs = R_TAN_HALF_FOV * (float)W / (float)H;
+    if (kind != VPN_SPHERE) {
+        // Cuboid: lam <= lam_cut <=> the pixel's line meets the box inflated by lam_cut <=> the pixel lies in the
+        // projection of that box, the convex hull of its 8 projected corners (all in front of the camera): a hexagon
+        // (or quadrilateral) bounded by the box edges between a face that looks at the eye and one that does not.  (The
+        // circumscribed sphere the ellipsoid path would use covers 1.5x the 8x8 quadrants this does at C3.)
+        const float lamc = sqrtf(L2);
+        float cc[3], ax[3][3];                       // box centre and inflated half-axis vectors in camera coordinates
+        {
+            const float w[3] = {t[0] - C.eye[0], t[1] - C.eye[1], t[2] - C.eye[2]};
+            cc[0] = w[0] * C.right[0] + w[1] * C.right[1] + w[2] * C.right[2];
+            cc[1] = w[0] * C.up[0] + w[1] * C.up[1] + w[2] * C.up[2];
+            cc[2] = w[0] * C.fwd[0] + w[1] * C.fwd[1] + w[2] * C.fwd[2];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float h = lamc * v[i];
+                ax[i][0] = (P.R.m[0][i] * C.right[0] + P.R.m[1][i] * C.right[1] + P.R.m[2][i] * C.right[2]) * h;
+                ax[i][1] = (P.R.m[0][i] * C.up[0] + P.R.m[1][i] * C.up[1] + P.R.m[2][i] * C.up[2]) * h;
+                ax[i][2] = (P.R.m[0][i] * C.fwd[0] + P.R.m[1][i] * C.fwd[1] + P.R.m[2][i] * C.fwd[2]) * h;
+            }
+        }
+        // all 8 corners must be in front of the camera (and the eye outside the inflated box) for the hull argument
+        const float reach = fabsf(ax[0][2]) + fabsf(ax[1][2]) + fabsf(ax[2][2]);
+        const float fo[3] = {G.o[0] > lamc ? 1.0f : (G.o[0] < -lamc ? -1.0f : 0.0f), G.o[1] > lamc ? 1.0f : (G.o[1] < -lamc ? -1.0f : 0.0f),
+                             G.o[2] > lamc ? 1.0f : (G.o[2] < -lamc ? -1.0f : 0.0f)};     // which face of each axis looks at the eye
+        const bool ok = cc[2] - reach > 1.0e-3f * (fabsf(cc[2]) + reach) && (fo[0] != 0.0f || fo[1] != 0.0f || fo[2] != 0.0f);
+        // every float4 leaves as soon as it exists (few live registers: this runs inside kernels with tight budgets)
+        const float cx = ok ? cc[0] / cc[2] : 0.0f, cy = ok ? cc[1] / cc[2] : 0.0f;
+        // silhouette edges: the axis pair (i, j) owns two of them unless neither axis has a face that looks at the eye
+#pragma unroll
+        for (int pr = 0; pr < 3; ++pr) {
+            const int i = pr == 2 ? 1 : 0, j = pr == 0 ? 1 : 2, k = 3 - i - j;
+            const float fi = fo[i], fj = fo[j];
+            float l[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};            // trivial half-planes
+            if (ok && (fi != 0.0f || fj != 0.0f)) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    float si, sj;
+                    if (e == 0) { si = fi != 0.0f ? fi : 1.0f; sj = fj != 0.0f ? (fi != 0.0f ? -fj : fj) : 1.0f; }
+                    else { si = fi != 0.0f ? (fj != 0.0f ? -fi : fi) : -1.0f; sj = fj != 0.0f ? fj : -1.0f; }
+                    float m[3];
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) m[a] = cc[a] + si * ax[i][a] + sj * ax[j][a];
+                    const float z0 = m[2] - ax[k][2], z1 = m[2] + ax[k][2];
+                    const float x0 = (m[0] - ax[k][0]) / z0, y0 = (m[1] - ax[k][1]) / z0;
+                    const float x1 = (m[0] + ax[k][0]) / z1, y1 = (m[1] + ax[k][1]) / z1;
+                    const float la = y1 - y0, lb = x0 - x1;
+                    const float vc = la * (cx - x0) + lb * (cy - y0);        // the projected centre lies strictly inside the hull
+                    // a degenerate edge (seen end-on) keeps the trivial half-plane
+                    if (fabsf(vc) > 1.0e-30f && fabsf(vc) < 3.0e38f) { l[e][0] = la / vc; l[e][1] = lb / vc; }
+                }
+            }
+            put(5 + pr, make_float4(l[0][0], l[0][1], l[1][0], l[1][1]));
+        }
+        put(8, make_float4(cx, cy, 0.0f, 0.0f));
+        int jmin = 0, jmax = W - 1, imin = 0, imax = H - 1;
+        if (ok) {
+            float xlo = 3.0e38f, xhi = -3.0e38f, ylo = 3.0e38f, yhi = -3.0e38f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float s0 = (q & 1) ? 1.0f : -1.0f, s1 = (q & 2) ? 1.0f : -1.0f, s2 = (q & 4) ? 1.0f : -1.0f;
+                const float z = cc[2] + s0 * ax[0][2] + s1 * ax[1][2] + s2 * ax[2][2];
+                const float x = (cc[0] + s0 * ax[0][0] + s1 * ax[1][0] + s2 * ax[2][0]) / z;
+                const float y = (cc[1] + s0 * ax[0][1] + s1 * ax[1][1] + s2 * ax[2][1]) / z;
+                xlo = fminf(xlo, x); xhi = fmaxf(xhi, x); ylo = fminf(ylo, y); yhi = fmaxf(yhi, y);
+            }
+            const float jl = (xlo / txs + 1.0f) * (0.5f * W) - 0.5f, jh = (xhi / txs + 1.0f) * (0.5f * W) - 0.5f;
+            const float il = (1.0f - yhi / R_TAN_HALF_FOV) * (0.5f * H) - 0.5f, ih = (1.0f - ylo / R_TAN_HALF_FOV) * (0.5f * H) - 0.5f;
+            jmin = (int)fminf(fmaxf(floorf(jl) - 1.0f, -1.0e6f), 1.0e6f);
+            jmax = (int)fminf(fmaxf(ceilf(jh) + 1.0f, -1.0e6f), 1.0e6f);
+            imin = (int)fminf(fmaxf(floorf(il) - 1.0f, -1.0e6f), 1.0e6f);
+            imax = (int)fminf(fmaxf(ceilf(ih) + 1.0f, -1.0e6f), 1.0e6f);
+        }
+        put(4, make_float4(__int_as_float(jmin), __int_as_float(jmax), __int_as_float(imin), __int_as_float(imax)));
+        return;
+    }
     const float* col[3] = {G.Mr, G.Mu, G.Mf};
     float u[3], Gm[3][3];
 #pragma unroll
@@ -155,6 +233,8 @@ __device__ inline void make_record_put(const Camera& C, const Pose& P, const flo
     put(4, make_float4(__int_as_float(jmin), __int_as_float(jmax), __int_as_float(imin), __int_as_float(imax)));
     put(5, make_float4(A00, A01, A11, valid));
     put(6, make_float4(b0, b1, c0, det));
+    put(7, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+    put(8, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
 }
 
 // Transposing butterfly: 16 per-lane values -> lane L holds the wave total of value (L >> 2).
@@ -217,18 +297,34 @@ __device__ inline bool conic_hits_rect(const float4 qa, const float4 qb, float x
     return best >= 0.0f;
 }
 
-// does primitive (pixel box bb, conic qa/qb) touch the 16x16 tile at (c0, r0)?
-__device__ inline bool prim_hits_tile(const float4 bb, const float4 qa, const float4 qb, int c0, int r0, int H, int W,
+// does the convex region  a_e (x - cx) + b_e (y - cy) + 1 >= 0, e < 6  (lines in l0, l1, l2 as (a, b) pairs, centre in ctr.xy)
+// touch the rectangle?  Separating axes of a convex polygon and a rectangle: the polygon's edges (here) and the
+// rectangle's (the pixel-box test of the caller).  A trivial line (0, 0) never rejects.
+__device__ inline bool hexagon_hits_rect(const float4 l0, const float4 l1, const float4 l2, const float4 ctr, float x0, float x1,
+                                         float y0, float y1) {
+    const float dx0 = x0 - ctr.x, dx1 = x1 - ctr.x, dy0 = y0 - ctr.y, dy1 = y1 - ctr.y;
+    auto out = [&](float a, float b) { return fmaxf(a * dx0, a * dx1) + fmaxf(b * dy0, b * dy1) + 1.0f < 0.0f; };   // the whole rectangle outside
+    return !(out(l0.x, l0.y) || out(l0.z, l0.w) || out(l1.x, l1.y) || out(l1.z, l1.w) || out(l2.x, l2.y) || out(l2.z, l2.w));
+}
+
+// does the primitive whose culling record is cr[0 .. R_CULL) (pixel box, then conic or hexagon) touch the 16x16 tile at (c0, r0)?
+__device__ inline bool prim_hits_tile(int kind, const float4* cr, int c0, int r0, int H, int W,
                                       int R_TW = vpn::R_TW, int R_TH = vpn::R_TH) {       // also used for the 8x8 quadrants
+    const float4 bb = cr[0];
     const int jmin = __float_as_int(bb.x), jmax = __float_as_int(bb.y);
     const int imin = __float_as_int(bb.z), imax = __float_as_int(bb.w);
     bool vis = (jmin <= c0 + R_TW - 1) && (jmax >= c0) && (imin <= r0 + R_TH - 1) && (imax >= r0);
-    if (vis && qa.w != 0.0f) {
+    if (vis) {
         // tile rectangle in slope units, half a pixel of margin on every side
         const float sx = 2.0f * (R_TAN_HALF_FOV * (float)W / (float)H) / (float)W, sy = 2.0f * R_TAN_HALF_FOV / (float)H;
         const float x0 = ((float)c0 - 0.5f * (float)W) * sx, x1 = ((float)(c0 + R_TW) - 0.5f * (float)W) * sx;
         const float y1 = (0.5f * (float)H - (float)r0) * sy, y0 = (0.5f * (float)H - (float)(r0 + R_TH)) * sy;
-        vis = conic_hits_rect(qa, qb, x0, x1, y0, y1);
+        if (kind == VPN_SPHERE) {
+            const float4 qa = cr[1];
+            if (qa.w != 0.0f) vis = conic_hits_rect(qa, cr[2], x0, x1, y0, y1);
+        } else {
+            vis = hexagon_hits_rect(cr[1], cr[2], cr[3], cr[4], x0, x1, y0, y1);
+        }
     }
     return vis;
 }
@@ -240,43 +336,26 @@ __device__ inline bool prim_hits_tile(const float4 bb, const float4 qa, const fl
 // (counting sort in LDS).  Runs as a rider in the tail of the Chamfer scan's launch (chamfer.hip), between the launch
 // that writes the records and the one that reads masks and order.
 struct RasterOrderJob {
-    const float4* rec = nullptr;              // records [B][K][R_REC] (vpn_hotpath_sample_fwd), or ...
-    // ... built HERE (params != nullptr): one lane per primitive runs the record's ~1000 dependent instructions in this
-    // launch's tail instead of on the critical path of every sampler workgroup (2.6 us of the sampler launch at C3)
-    const float* params = nullptr;            // [B][K][10]
-    const int32_t* kinds = nullptr;           // [K]
-    const float* cam = nullptr;               // [B][3]
-    float sigma = 0.f;
-    float4* rec_out = nullptr;                // == rec, writable
+    const float4* rec = nullptr;              // records [B][K][R_REC] (vpn_hotpath_sample_fwd)
     unsigned long long* masks = nullptr;      // out: [B][ntile][words]
     unsigned short* order = nullptr;          // out: [B][ntile], tiles by visible primitives, heaviest first
     int B = 0, K = 0, H = 0, W = 0, tiles_x = 0, ntile = 0, words = 0;
 };
 
-// scratch (LDS): K * 3 float4 of cull records + (K + 2) ints + ntile bytes; R_ORDER_MAX_TILES bounds the last term
+// scratch (LDS): K * R_CULL float4 of cull records + K kinds + (K + 2) ints + ntile bytes; R_ORDER_MAX_TILES bounds the last term
 constexpr int R_ORDER_MAX_TILES = 16384;      // 2048 x 2048 pixels
-__host__ __device__ inline size_t raster_order_scratch(int K, int ntile) { return (size_t)K * 48 + (size_t)(K + 2) * 4 + (size_t)ntile; }
+__host__ __device__ inline size_t raster_order_scratch(int K, int ntile) {
+    return (size_t)K * R_CULL * 16 + (size_t)K * 4 + (size_t)(K + 2) * 4 + (size_t)ntile;
+}
 template <int THREADS>
 __device__ inline void raster_order_wg(const RasterOrderJob& J, int b, void* scratch) {
     float4* cull = reinterpret_cast<float4*>(scratch);
-    int* hist = reinterpret_cast<int*>(cull + 3 * J.K);          // hist[c] -> start of the bucket of popcount c (descending)
+    int* knd = reinterpret_cast<int*>(cull + R_CULL * J.K);      // kind of every primitive
+    int* hist = knd + J.K;                                       // hist[c] -> start of the bucket of popcount c (descending)
     unsigned char* pops = reinterpret_cast<unsigned char*>(hist + J.K + 2);   // visible primitives per tile (K <= 255)
     const float4* rec_b = J.rec + (size_t)b * J.K * R_REC;
-    if (J.params) {
-        for (int k = threadIdx.x; k < J.K; k += THREADS) {
-            const float* prm = J.params + ((size_t)b * J.K + k) * VPN_PARAM_STRIDE;
-            const Camera C = make_camera(J.cam + b * 3);
-            const Pose P = make_pose(prm[3], prm[4], prm[5], prm[6]);
-            float4* out = J.rec_out + ((size_t)b * J.K + k) * R_REC;
-            // every float4 is stored as soon as it exists: the host kernel's register budget is the scan loop's
-            make_record_put(C, P, prm, J.kinds[k] == VPN_SPHERE ? VPN_SPHERE : VPN_CUBOID, J.H, J.W, J.sigma, [&](int i, const float4 v) {
-                out[i] = v;
-                if (i >= 4 && i < 4 + R_CULL) cull[3 * k + i - 4] = v;
-            });
-        }
-    } else {
-        for (int i = threadIdx.x; i < 3 * J.K; i += THREADS) cull[i] = rec_b[(size_t)(i / 3) * R_REC + 4 + i % 3];
-    }
+    for (int i = threadIdx.x; i < R_CULL * J.K; i += THREADS) cull[i] = rec_b[(size_t)(i / R_CULL) * R_REC + 4 + i % R_CULL];
+    for (int k = threadIdx.x; k < J.K; k += THREADS) knd[k] = __float_as_int(rec_b[(size_t)k * R_REC].w);
     for (int i = threadIdx.x; i <= J.K + 1; i += THREADS) hist[i] = 0;
     __syncthreads();
     unsigned long long* mrow = J.masks + (size_t)b * J.ntile * J.words;
@@ -288,7 +367,7 @@ __device__ inline void raster_order_wg(const RasterOrderJob& J, int b, void* scr
         for (int w = 0; w < J.words; ++w) {
             unsigned long long m = 0ull;
             for (int k = 64 * w + par; k < min(J.K, 64 * w + 64); k += 2)
-                if (prim_hits_tile(cull[3 * k], cull[3 * k + 1], cull[3 * k + 2], tx * R_TW, ty * R_TH, J.H, J.W)) m |= 1ull << (k & 63);
+                if (prim_hits_tile(knd[k], cull + R_CULL * k, tx * R_TW, ty * R_TH, J.H, J.W)) m |= 1ull << (k & 63);
             m |= ((unsigned long long)__shfl_xor((unsigned)(m >> 32), 1, 64) << 32) | (unsigned)__shfl_xor((unsigned)m, 1, 64);
             if (par == 0) mrow[(size_t)tile * J.words + w] = m;
             pop += __builtin_popcountll(m);
@@ -366,7 +445,7 @@ __device__ inline void raster_finish_gather(int bk, int K, int ntile, int words,
 __device__ inline void raster_finish_chain(const float* __restrict__ params, const float4* __restrict__ rec, int bk, int K,
                                            const float G[12], float r[10]) {
     const float* prm = params + (size_t)bk * VPN_PARAM_STRIDE;
-    const float4* rk = rec + (size_t)bk * R_REC + 7;                  // camera basis and pose saved by make_record
+    const float4* rk = rec + (size_t)bk * R_REC + R_FIN;              // camera basis and pose saved by make_record
     const float4 c0 = rk[0], c1 = rk[1], c2 = rk[2], p0 = rk[3], p1 = rk[4], p2 = rk[5], p3 = rk[6];
     Camera C;
     C.eye[0] = c0.x; C.eye[1] = c0.y; C.eye[2] = c0.z; C.right[0] = c0.w; C.right[1] = c1.x; C.right[2] = c1.y;

@@ -548,7 +548,6 @@ class RasterTotalFunction(Function):
 
 
 TILE_ORDER = os.environ.get('VPN_TILE_ORDER', '1') != '0'     # 0: position-based launch order of the tile waves (A/B switch)
-RIDER_RECORDS = os.environ.get('VPN_RIDER_RECORDS', '1') != '0'   # 0: the sampler launch builds the raster records (A/B switch)
 _PATTERNS = {}
 FUSED_BWD_MAX_GT = 7680       # vpn_sample_chamfer_bwd keeps per-wave match lists of the GT points in LDS (include/vpn_hip.h)
 _SIDE = {}
@@ -633,12 +632,11 @@ class HotPathLossFunction(Function):
         if side is None:        # one stream: the sampler's launch also writes the raster records of the same primitives
             # ... and, when the Chamfer scan will be the matrix-pipe filter, that filter's features of both clouds
             fused = bool(L.vpn_hotpath_fused_features(B, K, n, M))
-            # the scan launch can carry a rider that builds the records, tests the tiles and sorts them by weight: the
-            # sampler launch then leaves the records alone (they are its critical path)
-            use_order = fused and TILE_ORDER and K <= 255 and ntile <= 16384 and K * 48 + (K + 2) * 4 + ntile <= 24576
+            # the scan launch can carry a rider that tests the tiles against the primitives and sorts them by weight
+            use_order = fused and TILE_ORDER and K <= 255 and ntile <= 16384 and K * 84 + (K + 2) * 4 + ntile <= 24576
             _lib.call('vpn_hotpath_sample_fwd', _lib.ptr(params), _lib.ptr(kinds), None, seed_host, seed_dev,
                       int(sample_base), B, K, n, _lib.ptr(points), _lib.ptr(cam), H, W, float(sigma),
-                      None if use_order and RIDER_RECORDS else _lib.ptr(rec),
+                      _lib.ptr(rec),
                       _lib.ptr(lws), _lib.ptr(gt_points), M, _lib.ptr(cws) if fused else None, cws.numel() * 4, s)
             chamfer_mode = 7 if fused else 0
         else:
@@ -654,11 +652,9 @@ class HotPathLossFunction(Function):
             # the scan launch also sorts the raster's tiles by visible primitives (a rider in its tail): the tile waves
             # then start heaviest first and read their masks instead of testing the primitives again
             order = torch.empty((L.vpn_raster_order_size(B, H, W) // 2,), dtype=torch.int16, device=dev)
-            rr = RIDER_RECORDS
             _lib.call('vpn_hotpath_chamfer_fwd', _lib.ptr(points), _lib.ptr(gt_points), B, N, M, _lib.ptr(d1), _lib.ptr(i1),
                       _lib.ptr(d2), _lib.ptr(i2), _lib.ptr(cws), cws.numel() * 4, chamfer_mode, _lib.ptr(rec), K, H, W,
-                      _lib.ptr(order), _lib.ptr(params) if rr else None, _lib.ptr(kinds) if rr else None,
-                      _lib.ptr(cam) if rr else None, float(sigma) if rr else 0.0, s)
+                      _lib.ptr(order), s)
         else:
             _lib.call('vpn_chamfer_fwd_ws', _lib.ptr(points), _lib.ptr(gt_points), B, N, M, _lib.ptr(d1), _lib.ptr(i1),
                       _lib.ptr(d2), _lib.ptr(i2), _lib.ptr(cws), cws.numel() * 4, chamfer_mode, s)
