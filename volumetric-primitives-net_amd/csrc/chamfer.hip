@@ -1193,12 +1193,22 @@ __global__ __launch_bounds__(cm_block<PREC>(), PREC == 1 ? 5 : CM_WAVES_PER_EU) 
 // The tracked unit is a PAIR of blocks (64 targets): one 16-instruction tree over both accumulators and one
 // 4-instruction update per pair, 10 VALU instructions per block instead of 12 in a loop bound by VALU issue; the
 // exact finish then works on the winning half-wave's 32 rows of the pair (CM_CELL below).
+#ifdef CM_EXP_PRIO
+#define CM_PRIO(p) __builtin_amdgcn_s_setprio(p);
+#else
+#define CM_PRIO(p)
+#endif
 #define CM_PAIR(oa, ob, J)                                                                     \
     {                                                                                          \
+        CM_PRIO(1)                                                                             \
         const f16v accA = block(oa), accB = block(ob);                                         \
+        CM_PRIO(0)                                                                             \
         const float mAB = min32(accA, accB);                                                   \
         CM_UPDATE_C(mAB, J)                                                                    \
     }
+#ifdef CM_EXP_PRIO_STATIC
+        if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
+#endif
         Pre pre = fetch(0);
         stash(0, pre);
         __syncthreads();
