@@ -84,8 +84,43 @@ def interleave(every):
     return torch.stack(out).to(torch.int16).contiguous().to(dev)
 
 
-variants = (('desc (rider)', order), ('empties before pop<4', variant(4)), ('empties before pop<3', variant(3)), ('empties before pop<2', variant(2)),
-            ('one empty per 3', interleave(3)), ('one empty per 4', interleave(4)), ('one empty per 8', interleave(8)))
+def halves(nparts):
+    """descending popcount dealt round-robin from `nparts` equal parts of the sorted list: H M L H M L ..."""
+    out = []
+    for b in range(B):
+        idx = torch.argsort(pop[b], descending=True, stable=True).tolist()
+        parts = [idx[i * ntile // nparts:(i + 1) * ntile // nparts] for i in range(nparts)]
+        o = []
+        for i in range(max(len(p) for p in parts)):
+            for p in parts:
+                if i < len(p):
+                    o.append(p[i])
+        out.append(torch.tensor(o))
+    return torch.stack(out).to(torch.int16).contiguous().to(dev)
+
+
+def head_then_mix(frac):
+    """the heaviest `frac` of the tiles first (descending), the rest heavy / light alternating"""
+    out = []
+    for b in range(B):
+        idx = torch.argsort(pop[b], descending=True, stable=True).tolist()
+        h = int(ntile * frac)
+        head, rest = idx[:h], idx[h:]
+        a, c = rest[:len(rest) // 2], rest[len(rest) // 2:][::-1]
+        o = list(head)
+        for i in range(max(len(a), len(c))):
+            if i < len(a):
+                o.append(a[i])
+            if i < len(c):
+                o.append(c[i])
+        out.append(torch.tensor(o))
+    return torch.stack(out).to(torch.int16).contiguous().to(dev)
+
+
+g = torch.Generator().manual_seed(1)
+shuffled = torch.stack([torch.randperm(ntile, generator=g) for _ in range(B)]).to(torch.int16).contiguous().to(dev)
+variants = (('desc (rider)', order), ('dealt from 2 halves', halves(2)), ('dealt from 3 parts', halves(3)), ('dealt from 5 parts', halves(5)),
+            ('heaviest 10% then mix', head_then_mix(0.1)), ('heaviest 30% then mix', head_then_mix(0.3)), ('random', shuffled))
 res = {name: [] for name, _ in variants}
 for rnd in range(6):                       # round-robin: the box's clock drifts by several % over a run
     for name, o in variants:

@@ -430,6 +430,9 @@ __device__ inline unsigned long long tile_forward(const Tile& T, const float4* _
                                                    : stage_word(T, rec_b, w, K, H, W, srec, nullptr, mrow);
         if (w == 0) m0 = m;
         const int n = __builtin_popcountll(m);
+#ifdef R_EXP_PRIO
+        if (n >= R_EXP_PRIO) __builtin_amdgcn_s_setprio(2);          // heavy tiles: the launch's critical path
+#endif
         quadrant_bits_all(T, srec, n, K, H, W);
         unsigned long long qb = 0ull;
         for (int j = 0; j < n; ++j) {
@@ -622,12 +625,23 @@ __global__ __launch_bounds__(64, 4) void raster_bwd_kernel(const float4* __restr
 #ifndef R_TOTAL_WAVES
 #define R_TOTAL_WAVES 5
 #endif
+#ifdef R_EXP_TRACE
+// timeline experiment (tools/raster_timeline.py): per tile wave (blockIdx) its start and end on the 100 MHz wall clock,
+// the number of visible primitives and the hardware id of the SIMD it ran on
+__device__ unsigned long long g_rtrace[65536 * 8];
+extern "C" int vpn_debug_raster_trace(void* dst, int nwaves) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_rtrace), (size_t)nwaves * 8 * sizeof(unsigned long long), 0, hipMemcpyDeviceToDevice);
+}
+#endif
 __global__ __launch_bounds__(64, R_TOTAL_WAVES) void raster_total_kernel(const float4* __restrict__ rec,
                                                            unsigned long long* __restrict__ masks,
                                                            const float* __restrict__ cam, int B, int K, int H, int W,
                                                            int tiles_x, int tiles_y, int words, float sigma, float gamma,
                                                            float z_far, float* __restrict__ partial, LossArgs la, FinArgs fin,
                                                            const unsigned short* __restrict__ order) {
+#ifdef R_EXP_TRACE
+    const unsigned long long t_start = wall_clock64();
+#endif
     const Tile T = make_tile(H, W, tiles_x, tiles_y, B, order);
     if (!T.valid) return;
     const int ntile = tiles_x * tiles_y, lane = threadIdx.x & 63;
@@ -650,6 +664,9 @@ __global__ __launch_bounds__(64, R_TOTAL_WAVES) void raster_total_kernel(const f
     float P[R_PPL], S0[R_PPL], S1[R_PPL];
     // with an order the tile masks are there too (both come from the sampler's launch): read, not recomputed
     const unsigned long long m0 = tile_forward(T, rec_b, mrow, words, K, H, W, srec, inv_sigma, inv_gamma, zref, P, S0, S1, order != nullptr);
+#ifdef R_EXP_TRACE
+    const unsigned long long t_fwd = wall_clock64();
+#endif
     float gAtot[R_PPL], gZbar[R_PPL], zbar[R_PPL], invS[R_PPL];
     float lsil = 0.0f, ldep = 0.0f;
 #pragma unroll
@@ -696,11 +713,26 @@ __global__ __launch_bounds__(64, R_TOTAL_WAVES) void raster_total_kernel(const f
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         arrived = __hip_atomic_fetch_add(reinterpret_cast<int*>(fin.persample + T.b) + 3, 1, VPN_ARRIVE_ORDER, __HIP_MEMORY_SCOPE_AGENT);
     }
+#ifdef R_EXP_TRACE
+    const unsigned long long t_loss = wall_clock64();
+#endif
     // K > 64: the backward restages word by word from the masks this wave stored (or read) in the forward half -- lane 0
     // reads back its own stores, program order -- instead of repeating the visibility test
     tile_backward(T, rec_b, mrow, words, K, ntile, H, W, srec, words == 1, m0, inv_sigma, inv_gamma, zref, P, zbar, invS,
                   gAtot, gZbar, partial);
+#ifdef R_EXP_TRACE
+    const unsigned long long t_bwd = wall_clock64();
+#endif
     if (fin.enabled && __builtin_amdgcn_readfirstlane(arrived) == ntile - 1) finalize_sample(fin, la, T.b, ntile);
+#ifdef R_EXP_TRACE
+    if (lane == 0 && blockIdx.x < 65536) {
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        unsigned long long* g = g_rtrace + (size_t)blockIdx.x * 8;
+        g[0] = t_start; g[1] = wall_clock64(); g[2] = (unsigned long long)__builtin_popcountll(m0); g[3] = hwid;
+        g[4] = t_fwd; g[5] = t_loss; g[6] = t_bwd; g[7] = 0;
+    }
+#endif
 }
 
 // one wave per (b,k): raster_finish_wave (vpn_raster_common.h), then write / accumulate the gradient
