@@ -229,9 +229,9 @@ int vpn_raster_total_fwd(const float* params, const int32_t* kinds, const float*
  * (cd = 0).  loss_b [B] (optional) receives cd_b.  seed_advance (optional): a device uint64 that is incremented once
  * when the batch is complete -- the step counter vpn_hotpath_sample_fwd was given as seed_dev, so the next step draws
  * fresh surface points without a kernel of its own; the seed this step used stays readable at (char*)loss_ws + 8.
- * tile_order (optional, needs records_ready): uint16 [B][tiles], for each image its 16x16 tiles sorted by the number of
- * visible primitives, heaviest first -- the launch order of the tile waves; the tile masks inside `records` are then
- * taken as written too (vpn_hotpath_sample_fwd produces both when it is given order buffers). */
+ * tile_order (optional, needs records_ready and K <= 64): the tile entries vpn_hotpath_chamfer_fwd wrote -- launch order
+ * of the tile waves (heaviest tile first), tile masks and quadrant masks; the tile masks inside `records` are then taken
+ * as written too. */
 int vpn_raster_total_fwd_fin(const float* params, const int32_t* kinds, const float* cam,
                              int B, int K, int H, int W, float sigma, float gamma, float z_far,
                              const float* gt_sil, const float* gt_depth, int sil_mse, float w_sil, float w_dep,
@@ -255,11 +255,13 @@ int vpn_hotpath_sample_fwd(const float* params, const int32_t* kinds, const floa
 int vpn_hotpath_fused_features(int B, int K, int n, int M);
 /* The Chamfer scan of the training step (vpn_chamfer_fwd_ws with the fp16 filter: mode 0 where it resolves to it, 6 or 7)
  * with a RIDER in the same launch: behind the scan's workgroups, in the tail of the launch where slots idle, one
- * workgroup per image tests that image's 16x16 tiles against its K primitives (the visibility test of the tile kernels),
- * writes the tile masks into `records` (as written by vpn_hotpath_sample_fwd earlier on this stream) and tile_order
- * [B][tiles] uint16 (vpn_raster_order_size bytes): the tiles sorted by their number of visible primitives, heaviest
- * first -- the launch order vpn_raster_total_fwd_fin takes.  tile_order == NULL: exactly vpn_chamfer_fwd_ws.
- * VPN_E_TOOBIG if K > 255 or the image has more than 16384 tiles (the caller then runs without an order). */
+ * workgroup per image tests that image's 16x16 tiles and their 8x8 quadrants against its K primitives (the visibility
+ * test of the tile kernels), writes the tile masks into `records` (as written by vpn_hotpath_sample_fwd earlier on this
+ * stream) and tile_order (vpn_raster_order_size bytes, 16-byte aligned): one 48-byte entry per (image, launch rank) =
+ * (tile, number of visible primitives, their mask, four quadrant masks), the tiles of every image sorted by visible
+ * primitives, heaviest first -- what a tile wave of vpn_raster_total_fwd_fin needs to know, in one load (the second half
+ * of the buffer is the rider's scratch: the same entries by tile).  tile_order == NULL: exactly vpn_chamfer_fwd_ws.
+ * VPN_E_TOOBIG if K > 64 or the image has more than 16384 tiles (the caller then runs without it). */
 size_t vpn_raster_order_size(int B, int H, int W);
 int vpn_hotpath_chamfer_fwd(const float* p1, const float* p2, int B, int N, int M, float* dist1, int32_t* idx1,
                             float* dist2, int32_t* idx2, void* workspace, size_t workspace_bytes, int mode,

@@ -1127,15 +1127,16 @@ def test_hot_path_config3_full(vpn):
 
 
 def test_tile_order_rider(vpn):
-    """vpn_hotpath_chamfer_fwd: the scan's results are those of vpn_chamfer_fwd_ws, the rider's tile masks are the ones
-    the tile waves compute themselves, tile_order is a permutation of every image's tiles sorted by visible primitives
-    (heaviest first), and the raster gives the same bits with and without it.  Odd batch size, ragged image, mixed
-    kinds, and a K > 64 case (two mask words)."""
+    """vpn_hotpath_chamfer_fwd: the scan's results are those of vpn_chamfer_fwd_ws; the rider's tile masks are the ones the
+    tile waves compute themselves; its entries are a permutation of every image's tiles sorted by visible primitives
+    (heaviest first), each with its tile's mask and with quadrant masks that are subsets of it whose union is the mask
+    wherever the tile-level test passed through a quadrant; and the raster gives the same bits with and without them.
+    Odd batch size, ragged image, mixed kinds, K = 64 (a full mask word); K = 70 is refused (the caller runs without)."""
     from vpn_amd import _lib
     L = _lib.lib()
     dev = torch.device(DEV)
     gen = torch.Generator().manual_seed(77)
-    for (B, K, n, M, H, W) in ((5, 7, 90, 700, 72, 104), (2, 70, 16, 600, 48, 48)):
+    for (B, K, n, M, H, W) in ((5, 7, 90, 700, 72, 104), (2, 64, 16, 600, 48, 48), (2, 70, 16, 600, 48, 48)):
         N = K * n
         params = g(rand_params(gen, B, K))
         kinds = vpn.kinds_tensor(sorted((int(x) for x in torch.randint(0, 2, (K,), generator=gen)), reverse=True), dev)
@@ -1152,11 +1153,19 @@ def test_tile_order_rider(vpn):
         fused = bool(L.vpn_hotpath_fused_features(B, K, n, M))
         _lib.call('vpn_hotpath_sample_fwd', _lib.ptr(params), _lib.ptr(kinds), None, 11, None, 0, B, K, n, _lib.ptr(pts), _lib.ptr(cam),
                   H, W, 0.05, _lib.ptr(rec), _lib.ptr(lws), _lib.ptr(gt), M, _lib.ptr(cws) if fused else None, cws.numel() * 4, _lib.stream())
+        if K > 64:                                                         # more than one mask word per tile: no entries
+            order = torch.zeros((L.vpn_raster_order_size(B, H, W) // 8,), dtype=torch.int64, device=dev)
+            d1, d2 = torch.empty(B, N, device=dev), torch.empty(B, M, device=dev)
+            i1, i2 = torch.empty(B, N, dtype=torch.int32, device=dev), torch.empty(B, M, dtype=torch.int32, device=dev)
+            rc = L.vpn_hotpath_chamfer_fwd(_lib.ptr(pts), _lib.ptr(gt), B, N, M, _lib.ptr(d1), _lib.ptr(i1), _lib.ptr(d2), _lib.ptr(i2), _lib.ptr(cws),
+                                           cws.numel() * 4, 7 if fused else 6, _lib.ptr(rec), K, H, W, _lib.ptr(order), _lib.stream())
+            assert rc == -2                                                # VPN_E_TOOBIG
+            continue
         outs = {}
         for with_order in (False, True):
             d1, d2 = torch.empty(B, N, device=dev), torch.empty(B, M, device=dev)
             i1, i2 = torch.empty(B, N, dtype=torch.int32, device=dev), torch.empty(B, M, dtype=torch.int32, device=dev)
-            order = torch.full((L.vpn_raster_order_size(B, H, W) // 2,), -1, dtype=torch.int16, device=dev) if with_order else None
+            order = torch.full((L.vpn_raster_order_size(B, H, W) // 8,), -1, dtype=torch.int64, device=dev) if with_order else None
             _lib.call('vpn_hotpath_chamfer_fwd', _lib.ptr(pts), _lib.ptr(gt), B, N, M, _lib.ptr(d1), _lib.ptr(i1), _lib.ptr(d2), _lib.ptr(i2),
                       _lib.ptr(cws), cws.numel() * 4, 7 if fused else 6, _lib.ptr(rec), K, H, W, _lib.ptr(order), _lib.stream())
             losses = torch.zeros(4, device=dev)
@@ -1166,20 +1175,33 @@ def test_tile_order_rider(vpn):
                       1.0, _lib.ptr(losses), None, None, _lib.ptr(order), _lib.stream())
             torch.cuda.synchronize()
             mask_words = B * ntile * words                              # the tile masks are the tail of the records buffer
-            masks = rec.view(torch.int64)[L.vpn_raster_records_size(B, K, H, W) // 8 - mask_words:].clone().cpu().reshape(B, ntile, words)
+            masks = rec.view(torch.int64)[L.vpn_raster_records_size(B, K, H, W) // 8 - mask_words:].clone().cpu().reshape(B, ntile)
             outs[with_order] = (d1.cpu(), i1.cpu(), d2.cpu(), i2.cpu(), losses.cpu(), rws.clone().cpu(), masks,
-                                order.cpu().reshape(-1)[:B * ntile].reshape(B, ntile) if with_order else None)
+                                order.cpu().reshape(2, B, ntile, 6) if with_order else None)
         a, b = outs[False], outs[True]
         for x, y in zip(a[:7], b[:7]):
             assert torch.equal(x, y)                                   # scan, losses, gradient partials, masks: the same bits
         r1, j1, r2, j2 = vpn.chamfer_nn(pts, gt, mode='brute')
         assert torch.equal(b[0], r1.cpu()) and torch.equal(b[1], j1.cpu()) and torch.equal(b[3], j2.cpu())
-        order = b[7].long() & 0xffff
-        pop = torch.tensor([[sum(bin(int(w) & ((1 << 64) - 1)).count('1') for w in t) for t in img] for img in b[6].tolist()])
+        by_rank, by_tile = b[7][0], b[7][1]                            # int64 words: (tile | n << 32, mask, q0, q1, q2, q3)
+        tiles, ns = by_rank[..., 0] & 0xffffffff, by_rank[..., 0] >> 32
+        popc = lambda t: torch.tensor([[bin(int(w) & ((1 << 64) - 1)).count('1') for w in row] for row in t.tolist()])
         for img in range(B):
-            assert sorted(order[img].tolist()) == list(range(ntile))       # a permutation of the image's tiles
-            p = pop[img][order[img]]
-            assert bool((p[:-1] >= p[1:]).all())                           # heaviest first
+            assert sorted(tiles[img].tolist()) == list(range(ntile))       # a permutation of the image's tiles
+            assert bool((ns[img][:-1] >= ns[img][1:]).all())               # heaviest first
+            assert torch.equal(by_rank[img][:, 1], b[6][img][tiles[img]])  # every entry carries its tile's mask ...
+            assert torch.equal(by_tile[img][:, 1], b[6][img])
+        assert torch.equal(ns, popc(by_rank[..., 1]))                      # ... and its popcount
+        # quadrant words: four bits per staged slot (slot j = j-th visible primitive), sixteen slots per word: nothing
+        # beyond slot n, and a visible primitive reaches at least one quadrant (the four quadrant rectangles cover the tile's)
+        empty_slots = 0
+        for img in range(B):
+            for r in range(ntile):
+                nn, qw = int(ns[img, r]), [int(x) & ((1 << 64) - 1) for x in by_rank[img, r, 2:6].tolist()]
+                nibs = [(qw[j >> 4] >> (4 * (j & 15))) & 15 for j in range(64)]
+                assert all(v == 0 for v in nibs[nn:])
+                empty_slots += sum(1 for v in nibs[:nn] if v == 0)
+        assert empty_slots <= 0.02 * int(ns.sum()) + 2
     assert L.vpn_hotpath_chamfer_fwd(None, None, 1, 1, 1, None, None, None, None, None, 0, 6, None, 1, 8, 8, None, None) == -1
 
 

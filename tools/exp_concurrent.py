@@ -24,7 +24,7 @@ cws = f32(L.vpn_chamfer_workspace(B, N, M))
 points = torch.empty(B, N, 3, device=dev)
 d1, d2 = torch.empty(B, N, device=dev), torch.empty(B, M, device=dev)
 i1, i2 = torch.empty(B, N, dtype=torch.int32, device=dev), torch.empty(B, M, dtype=torch.int32, device=dev)
-order = torch.empty((L.vpn_raster_order_size(B, H, W) // 2,), dtype=torch.int16, device=dev)
+order = torch.empty((L.vpn_raster_order_size(B, H, W) // 8,), dtype=torch.int64, device=dev)
 losses = torch.zeros(4, device=dev)
 P = _lib.ptr
 

@@ -35,7 +35,32 @@ gref = ws.clone()
 ntile = 256
 masks = rec.view(torch.int64)[L.vpn_raster_records_size(B, K, H, W) // 8 - B * ntile:].cpu()
 pop = torch.tensor([bin(int(m) & ((1 << 64) - 1)).count('1') for m in masks.tolist()]).reshape(B, ntile)
-order = torch.argsort(pop, dim=1, descending=True, stable=True).to(torch.int16).contiguous().to(dev)      # uint16 values < 256
+# the tile entries come from the rider of the scan's launch (tile, popcount, mask, quadrant masks); a launch order is a
+# permutation of the by-tile half of its buffer
+n, M = 256, 2048
+N = K * n
+gt_points = torch.rand(B, M, 3, device=dev) - 0.5
+cws = torch.zeros((L.vpn_chamfer_workspace(B, N, M) // 4,), dtype=torch.float32, device=dev)
+pts = torch.empty(B, N, 3, device=dev)
+d1, d2 = torch.empty(B, N, device=dev), torch.empty(B, M, device=dev)
+i1, i2 = torch.empty(B, N, dtype=torch.int32, device=dev), torch.empty(B, M, dtype=torch.int32, device=dev)
+ent = torch.zeros((L.vpn_raster_order_size(B, H, W) // 8,), dtype=torch.int64, device=dev)
+_lib.call('vpn_hotpath_sample_fwd', _lib.ptr(params), _lib.ptr(kinds), None, 1234, None, 0, B, K, n, _lib.ptr(pts), _lib.ptr(cam), H, W, 0.05,
+          _lib.ptr(rec), _lib.ptr(lws), _lib.ptr(gt_points), M, _lib.ptr(cws), cws.numel() * 4, _lib.stream())
+_lib.call('vpn_hotpath_chamfer_fwd', _lib.ptr(pts), _lib.ptr(gt_points), B, N, M, _lib.ptr(d1), _lib.ptr(i1), _lib.ptr(d2), _lib.ptr(i2),
+          _lib.ptr(cws), cws.numel() * 4, 7, _lib.ptr(rec), K, H, W, _lib.ptr(ent), _lib.stream())
+torch.cuda.synchronize()
+by_tile = ent.view(2, B, ntile, 6)[1].clone()
+
+
+def entries_of(perm):
+    """perm [B][ntile] (tile of every rank) -> an entries buffer the raster takes"""
+    e = torch.zeros_like(ent).view(2, B, ntile, 6)
+    e[0] = torch.gather(by_tile, 1, perm.to(dev).long()[:, :, None].expand(B, ntile, 6))
+    return e.reshape(-1).contiguous()
+
+
+order = ent.clone()                                    # the rider's own order (descending popcount)
 
 
 def timed(ready, o, n=30):
@@ -65,7 +90,7 @@ def variant(after_pop):
         light = idx[(p[idx] < after_pop) & (p[idx] > 0)]
         empty = idx[p[idx] == 0]
         out.append(torch.cat([heavy, empty, light]))
-    return torch.stack(out).to(torch.int16).contiguous().to(dev)
+    return entries_of(torch.stack(out))
 
 
 def interleave(every):
@@ -81,7 +106,7 @@ def interleave(every):
             if em:
                 o.append(em.pop())
         out.append(torch.tensor(o))
-    return torch.stack(out).to(torch.int16).contiguous().to(dev)
+    return entries_of(torch.stack(out))
 
 
 def halves(nparts):
@@ -96,7 +121,7 @@ def halves(nparts):
                 if i < len(p):
                     o.append(p[i])
         out.append(torch.tensor(o))
-    return torch.stack(out).to(torch.int16).contiguous().to(dev)
+    return entries_of(torch.stack(out))
 
 
 def head_then_mix(frac):
@@ -114,11 +139,11 @@ def head_then_mix(frac):
             if i < len(c):
                 o.append(c[i])
         out.append(torch.tensor(o))
-    return torch.stack(out).to(torch.int16).contiguous().to(dev)
+    return entries_of(torch.stack(out))
 
 
 g = torch.Generator().manual_seed(1)
-shuffled = torch.stack([torch.randperm(ntile, generator=g) for _ in range(B)]).to(torch.int16).contiguous().to(dev)
+shuffled = entries_of(torch.stack([torch.randperm(ntile, generator=g) for _ in range(B)]))
 variants = (('desc (rider)', order), ('dealt from 2 halves', halves(2)), ('dealt from 3 parts', halves(3)), ('dealt from 5 parts', halves(5)),
             ('heaviest 10% then mix', head_then_mix(0.1)), ('heaviest 30% then mix', head_then_mix(0.3)), ('random', shuffled))
 res = {name: [] for name, _ in variants}

@@ -1070,19 +1070,21 @@ __global__ __launch_bounds__(cm_block<PREC>(), PREC == 1 ? 5 : CM_WAVES_PER_EU) 
         // of the launch, where a third of the slots is idle) sort the raster's tiles, one image each.  The launch sits
         // between the one that writes the raster records and the one that reads masks and order, so neither a hand-off
         // nor a launch of its own is needed.
-#ifndef CM_RIDER_FIRST
+#ifdef CM_RIDER_LAST
         if ((int)blockIdx.x >= j0.G + j1.G) {
             raster_order_wg<cm_block<PREC>()>(oj, (int)blockIdx.x - (j0.G + j1.G), tileH16);
             return;
         }
 #else
+        // the rider (~10 us since it also tests the quadrants) is dispatched FIRST: ids [0, oj.B).  Last, it was the tail of
+        // the launch (+10 us); first it costs 64 of 768 slots for its lifetime (not measurable)
         if ((int)blockIdx.x < oj.B) {
             raster_order_wg<cm_block<PREC>()>(oj, (int)blockIdx.x, tileH16);
             return;
         }
 #endif
     }
-#ifndef CM_RIDER_FIRST
+#ifdef CM_RIDER_LAST
     const int wg = (int)blockIdx.x;
 #else
     const int wg = (int)blockIdx.x - (PREC == 2 ? oj.B : 0);
@@ -2160,7 +2162,7 @@ extern "C" int vpn_chamfer_fwd_ws(const float* p1, const float* p2, int B, int N
 extern "C" size_t vpn_raster_order_size(int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0) return 0;
     const size_t ntile = (size_t)((W + R_TW - 1) / R_TW) * ((H + R_TH - 1) / R_TH);
-    return ((size_t)B * ntile * sizeof(unsigned short) + 15) / 16 * 16;
+    return 2 * (size_t)B * ntile * sizeof(TileEntry);              // entries by launch rank + the same by tile (scratch of the rider)
 }
 
 extern "C" int vpn_hotpath_chamfer_fwd(const float* p1, const float* p2, int B, int N, int M, float* dist1, int32_t* idx1,
@@ -2181,10 +2183,10 @@ extern "C" int vpn_hotpath_chamfer_fwd(const float* p1, const float* p2, int B, 
         oj.B = B; oj.K = K; oj.H = H; oj.W = W;
         oj.tiles_x = (W + R_TW - 1) / R_TW;
         oj.ntile = oj.tiles_x * ((H + R_TH - 1) / R_TH);
-        oj.words = (K + 63) / 64;
         oj.masks = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(records) + (size_t)B * K * R_REC * sizeof(float4));
-        oj.order = (unsigned short*)tile_order;
-        if (K > 255 || oj.ntile > R_ORDER_MAX_TILES || raster_order_scratch(K, oj.ntile) > 2 * CM_TILE16 * CM_ROWB) return VPN_E_TOOBIG;
+        oj.entries = (TileEntry*)tile_order;
+        if (((uintptr_t)tile_order & 15) != 0) return VPN_E_BADARG;
+        if (K > R_ORDER_MAX_PRIMS || oj.ntile > R_ORDER_MAX_TILES || raster_order_scratch(K, oj.ntile) > 2 * CM_TILE16 * CM_ROWB) return VPN_E_TOOBIG;
         rider = &oj;
     }
     return mfma_both(p1, p2, B, N, M, (float*)workspace, dist1, idx1, dist2, idx2, 2, (hipStream_t)stream, mode == 7, rider);

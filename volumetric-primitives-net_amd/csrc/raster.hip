@@ -208,12 +208,12 @@ struct Tile {
 // heavy tile started late runs on alone at the end of the launch: heavy-first order shortens that tail; one-wave
 // workgroups because a 4-wave workgroup holds its 4 slots until its slowest tile is done; id % 8 = b % 8 keeps every
 // XCD on whole images with the same mix of tiles (speed only: any order is correct).
-// `order` (training step): order[b][r] = the tile of image b with rank r when its tiles are sorted by the number of
+// `tile_of_entry` (training step): the tile of image b with rank r when its tiles are sorted by the number of
 // visible primitives, heaviest first (written by the launch that wrote the tile masks).  A tile's cost is proportional
 // to that number (0 .. 10 at C3, and it varies from image to image at one position), the launch lasts at least as long
 // as its heaviest tile (~30 us), and with the position-based order a heavy tile away from the centre started in the
 // second or third round of waves and WAS the tail.
-__device__ inline Tile make_tile(int H, int W, int tiles_x, int tiles_y, int B, const unsigned short* __restrict__ order = nullptr) {
+__device__ inline Tile make_tile(int H, int W, int tiles_x, int tiles_y, int B, int tile_of_entry = -1) {
     Tile T;
     const int lane = threadIdx.x & 63;
     const int id = blockIdx.x;
@@ -222,8 +222,8 @@ __device__ inline Tile make_tile(int H, int W, int tiles_x, int tiles_y, int B, 
     const int iy = pt / tiles_x, ix = pt - iy * tiles_x;
     auto co = [](int i, int n) { const int c = n >> 1, h = (i + 1) >> 1; return (i & 1) ? c - h : c + h; };
     int tx = co(ix, tiles_x), ty = co(iy, tiles_y);
-    if (order) {
-        const int t = min((int)order[(size_t)T.b * (tiles_x * tiles_y) + pt], tiles_x * tiles_y - 1);
+    if (tile_of_entry >= 0) {
+        const int t = min(tile_of_entry, tiles_x * tiles_y - 1);
         ty = t / tiles_x; tx = t - ty * tiles_x;
     }
     T.valid = true;
@@ -267,15 +267,24 @@ __host__ __device__ inline size_t raster_lds_bytes(int K) { return (size_t)raste
 // primitive 64 w + i (7 float4, one round trip), tests it against the tile, and if visible stores its ray coefficients
 // at slot = number of visible primitives below i.  `mask_in`: a mask computed earlier (backward kernels) instead of the
 // test; `mask_out`: where lane 0 stores the mask (forward kernels).  Returns the mask (wave-uniform).
+// quadrant words of the tile that arrived with its entry (training step): they are put where quadrant_bits_all would
+// have left them (LDS, behind the culling records) and the loops read them from there
+struct QuadMasks {
+    bool on = false;
+};
+
 __device__ inline unsigned long long stage_word(const Tile& T, const float4* __restrict__ rec_b, int w, int K, int H, int W,
                                                 float4* srec, const unsigned long long* mask_in,
-                                                unsigned long long* mask_out) {
+                                                unsigned long long* mask_out, bool need_cull = true, bool has_m = false,
+                                                unsigned long long m_val = 0ull) {
     const int lane = threadIdx.x & 63;
     const int k = w * 64 + lane;
     const float4* rk = rec_b + (size_t)(k < K ? k : 0) * R_REC;
     unsigned long long m;
     float4 a = rk[0], b = rk[1], c = rk[2], d = rk[3];
-    if (mask_in) {
+    if (has_m) {
+        m = m_val;                                                   // came with the tile's entry (wave-uniform)
+    } else if (mask_in) {
         m = uniform64(mask_in[w]);
     } else {
         float4 cr[R_CULL];
@@ -290,8 +299,10 @@ __device__ inline unsigned long long stage_word(const Tile& T, const float4* __r
         srec[slot * R_SLOT + 0] = a; srec[slot * R_SLOT + 1] = b; srec[slot * R_SLOT + 2] = c; srec[slot * R_SLOT + 3] = d;
         float4* scull = srec + raster_nslot(K) * R_SLOT + slot * R_CULL;
         const bool box = __float_as_int(a.w) != VPN_SPHERE;                  // an ellipsoid's conic ends at float4 2
+        if (need_cull) {
 #pragma unroll
-        for (int i = 0; i < R_CULL; ++i) if (i < 3 || box) scull[i] = rk[4 + i];
+            for (int i = 0; i < R_CULL; ++i) if (i < 3 || box) scull[i] = rk[4 + i];
+        }
     }
     __builtin_amdgcn_wave_barrier();
     return m;
@@ -421,19 +432,20 @@ __device__ inline void finalize_sample(const FinArgs& fin, const LossArgs& la, i
 // forward composite of the tile's visible primitives: P = prod(1 - a), S0 = sum w, S1 = sum w z
 __device__ inline unsigned long long tile_forward(const Tile& T, const float4* __restrict__ rec_b, unsigned long long* __restrict__ mrow,
                                     int words, int K, int H, int W, float4* srec, float inv_sigma, float inv_gamma,
-                                    float zref, float P[R_PPL], float S0[R_PPL], float S1[R_PPL], bool masks_ready = false) {
+                                    float zref, float P[R_PPL], float S0[R_PPL], float S1[R_PPL], bool masks_ready = false,
+                                    const QuadMasks qk = QuadMasks{}, bool has_m = false, unsigned long long m_val = 0ull) {
 #pragma unroll
     for (int s = 0; s < R_PPL; ++s) { P[s] = 1.0f; S0[s] = 0.0f; S1[s] = 0.0f; }
     unsigned long long m0 = 0ull;
     for (int w = 0; w < words; ++w) {
-        const unsigned long long m = masks_ready ? stage_word(T, rec_b, w, K, H, W, srec, mrow, nullptr)
+        const unsigned long long m = masks_ready ? stage_word(T, rec_b, w, K, H, W, srec, mrow, nullptr, !qk.on, has_m && w == 0, m_val)
                                                    : stage_word(T, rec_b, w, K, H, W, srec, nullptr, mrow);
         if (w == 0) m0 = m;
         const int n = __builtin_popcountll(m);
 #ifdef R_EXP_PRIO
         if (n >= R_EXP_PRIO) __builtin_amdgcn_s_setprio(2);          // heavy tiles: the launch's critical path
 #endif
-        quadrant_bits_all(T, srec, n, K, H, W);
+        if (!qk.on) quadrant_bits_all(T, srec, n, K, H, W);          // on: the entry's words are in LDS already
         unsigned long long qb = 0ull;
         for (int j = 0; j < n; ++j) {
             if ((j & 15) == 0) qb = uniform64(quadrant_words(srec, K)[j >> 4]);
@@ -469,10 +481,11 @@ __device__ inline void tile_backward(const Tile& T, const float4* __restrict__ r
                                      unsigned long long m0, float inv_sigma,
                                      float inv_gamma, float zref, const float P[R_PPL], const float zbar[R_PPL],
                                      const float invS[R_PPL], const float gAtot[R_PPL], const float gZbar[R_PPL],
-                                     float* __restrict__ partial) {
+                                     float* __restrict__ partial, const QuadMasks qk = QuadMasks{}) {
     const int lane = threadIdx.x & 63;
     for (int w = 0; w < words; ++w) {
-        const int n = __builtin_popcountll(staged ? m0 : stage_word(T, rec_b, w, K, H, W, srec, mrow, nullptr));
+        const unsigned long long mw = staged ? m0 : stage_word(T, rec_b, w, K, H, W, srec, mrow, nullptr);
+        const int n = __builtin_popcountll(mw);
         if (!staged) quadrant_bits_all(T, srec, n, K, H, W);          // staged: the forward loop left them in LDS
         unsigned long long qb = 0ull;
         for (int j = 0; j < n; ++j) {
@@ -638,13 +651,31 @@ __global__ __launch_bounds__(64, R_TOTAL_WAVES) void raster_total_kernel(const f
                                                            const float* __restrict__ cam, int B, int K, int H, int W,
                                                            int tiles_x, int tiles_y, int words, float sigma, float gamma,
                                                            float z_far, float* __restrict__ partial, LossArgs la, FinArgs fin,
-                                                           const unsigned short* __restrict__ order) {
+                                                           const TileEntry* __restrict__ entries) {
 #ifdef R_EXP_TRACE
     const unsigned long long t_start = wall_clock64();
 #endif
-    const Tile T = make_tile(H, W, tiles_x, tiles_y, B, order);
-    if (!T.valid) return;
+    // training step: ONE 48-byte entry (written by the rider of the scan's launch) says which tile this wave takes, which
+    // primitives it sees and which quadrants each of them reaches
     const int ntile = tiles_x * tiles_y, lane = threadIdx.x & 63;
+    QuadMasks qk;
+    unsigned long long m_entry = 0ull;
+    int tile_of_entry = -1;
+    uint4 e1q = make_uint4(0u, 0u, 0u, 0u), e2q = e1q;
+    if (entries) {
+        const int pt = blockIdx.x / B, eb = blockIdx.x - pt * B;
+        const uint4* e = reinterpret_cast<const uint4*>(entries + (size_t)eb * ntile + pt);
+        const uint4 e0 = e[0], e1 = e[1], e2 = e[2];
+        auto u64 = [](unsigned lo, unsigned hi) {
+            return ((unsigned long long)__builtin_amdgcn_readfirstlane(hi) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(lo);
+        };
+        tile_of_entry = __builtin_amdgcn_readfirstlane((int)e0.x);
+        m_entry = u64(e0.z, e0.w);
+        qk.on = words == 1;
+        e1q = e1; e2q = e2;
+    }
+    const Tile T = make_tile(H, W, tiles_x, tiles_y, B, tile_of_entry);
+    if (!T.valid) return;
     const float4* rec_b = rec + (size_t)T.b * K * R_REC;
     unsigned long long* mrow = masks + ((size_t)T.b * ntile + T.tile) * words;
     const float vz0 = __int_as_float(vzero());           // +0.0f in a VGPR: keeps the loop's uniform scalars out of SGPRs
@@ -661,9 +692,14 @@ __global__ __launch_bounds__(64, R_TOTAL_WAVES) void raster_total_kernel(const f
         gd[s] = (la.gt_depth && in) ? la.gt_depth[T.b * hw + pix] : 0.0f;
     }
     extern __shared__ __attribute__((aligned(16))) float4 srec[];      // raster_lds_bytes(K)
+    if (qk.on && lane == 0) {                                           // every lane holds the same two uint4
+        uint4* sq = reinterpret_cast<uint4*>(quadrant_words(srec, K));
+        sq[0] = e1q; sq[1] = e2q;
+    }
     float P[R_PPL], S0[R_PPL], S1[R_PPL];
-    // with an order the tile masks are there too (both come from the sampler's launch): read, not recomputed
-    const unsigned long long m0 = tile_forward(T, rec_b, mrow, words, K, H, W, srec, inv_sigma, inv_gamma, zref, P, S0, S1, order != nullptr);
+    // with entries the tile's mask is known (words == 1 there): stage_word takes it from `m_entry`
+    const unsigned long long m0 = tile_forward(T, rec_b, mrow, words, K, H, W, srec, inv_sigma, inv_gamma, zref, P, S0, S1, entries != nullptr,
+                                               qk, entries != nullptr, m_entry);
 #ifdef R_EXP_TRACE
     const unsigned long long t_fwd = wall_clock64();
 #endif
@@ -719,7 +755,7 @@ __global__ __launch_bounds__(64, R_TOTAL_WAVES) void raster_total_kernel(const f
     // K > 64: the backward restages word by word from the masks this wave stored (or read) in the forward half -- lane 0
     // reads back its own stores, program order -- instead of repeating the visibility test
     tile_backward(T, rec_b, mrow, words, K, ntile, H, W, srec, words == 1, m0, inv_sigma, inv_gamma, zref, P, zbar, invS,
-                  gAtot, gZbar, partial);
+                  gAtot, gZbar, partial, qk);
 #ifdef R_EXP_TRACE
     const unsigned long long t_bwd = wall_clock64();
 #endif
@@ -1009,7 +1045,7 @@ extern "C" int vpn_raster_total_fwd(const float* params, const int32_t* kinds, c
     const Grid G = raster_grid(B, K, H, W);
     LossArgs la{gt_sil, gt_depth, sil_mse, 1.0f / ((float)B * (float)H * (float)W), tile_loss_of(loss_ws, B), nullptr, w_sil, w_dep};
     VPN_LAUNCH(raster_total_kernel, G.g, dim3(64), raster_lds_bytes(K), s, (const float4*)records, masks_of(records, B, K), cam, B, K,
-               H, W, G.tiles_x, G.tiles_y, G.words, sigma, gamma, z_far, (float*)workspace, la, FinArgs{}, (const unsigned short*)nullptr);
+               H, W, G.tiles_x, G.tiles_y, G.words, sigma, gamma, z_far, (float*)workspace, la, FinArgs{}, (const TileEntry*)nullptr);
     VPN_LAUNCH_CHECK();
     return 0;
 }
@@ -1041,10 +1077,10 @@ extern "C" int vpn_raster_total_fwd_fin(const float* params, const int32_t* kind
     hipStream_t s = (hipStream_t)stream;
     if (!records_ready && (rc = launch_prep(params, kinds, cam, B, K, H, W, sigma, records, (int*)loss_ws, s))) return rc;
     const Grid G = raster_grid(B, K, H, W);
-    if (tile_order && (!records_ready || G.ntile > 65535)) return VPN_E_BADARG;     // the order comes with the masks
+    if (tile_order && (!records_ready || G.words != 1 || ((uintptr_t)tile_order & 15) != 0)) return VPN_E_BADARG;   // entries come with the masks, K <= 64
     LossArgs la{gt_sil, gt_depth, sil_mse, 1.0f / ((float)B * (float)H * (float)W), tile_loss_of(loss_ws, B), nullptr, w_sil, w_dep};
     VPN_LAUNCH(raster_total_kernel, G.g, dim3(64), raster_lds_bytes(K), s, (const float4*)records, masks_of(records, B, K), cam, B, K,
-               H, W, G.tiles_x, G.tiles_y, G.words, sigma, gamma, z_far, (float*)workspace, la, fin, (const unsigned short*)tile_order);
+               H, W, G.tiles_x, G.tiles_y, G.words, sigma, gamma, z_far, (float*)workspace, la, fin, (const TileEntry*)tile_order);
     VPN_LAUNCH_CHECK();
     return 0;
 }

@@ -335,15 +335,27 @@ __device__ inline bool prim_hits_tile(int kind, const float4* cr, int c0, int r0
 // where the tile kernels expect them, and the tiles are sorted by their number of visible primitives, heaviest first
 // (counting sort in LDS).  Runs as a rider in the tail of the Chamfer scan's launch (chamfer.hip), between the launch
 // that writes the records and the one that reads masks and order.
+// One entry per (image, launch rank) of the training step's tile waves: which tile, its visible primitives, and which of
+// them reach each of its four 8x8 quadrants -- everything a tile wave used to find out for itself (order -> mask ->
+// staged culling records -> quadrant test) in ONE 48-byte load.
+struct TileEntry {
+    unsigned int tile, n;                     // tile index inside the image; number of visible primitives
+    unsigned long long mask;                  // bit k <=> primitive k may touch the tile (K <= 64)
+    unsigned long long q[4];                  // four bits per STAGED SLOT (slot j = the j-th visible primitive; bit qd = column half
+                                              // + 2 * row half of the quadrant), sixteen slots per word: the words quadrant_bits makes
+};
+static_assert(sizeof(TileEntry) == 48, "three 16-byte loads");
+
 struct RasterOrderJob {
     const float4* rec = nullptr;              // records [B][K][R_REC] (vpn_hotpath_sample_fwd)
-    unsigned long long* masks = nullptr;      // out: [B][ntile][words]
-    unsigned short* order = nullptr;          // out: [B][ntile], tiles by visible primitives, heaviest first
-    int B = 0, K = 0, H = 0, W = 0, tiles_x = 0, ntile = 0, words = 0;
+    unsigned long long* masks = nullptr;      // out: [B][ntile] (K <= 64: one word per tile), read by the finishing step
+    TileEntry* entries = nullptr;             // out: [B][ntile] by launch rank (heaviest tile first), then [B][ntile] by tile (scratch)
+    int B = 0, K = 0, H = 0, W = 0, tiles_x = 0, ntile = 0;
 };
 
 // scratch (LDS): K * R_CULL float4 of cull records + K kinds + (K + 2) ints + ntile bytes; R_ORDER_MAX_TILES bounds the last term
 constexpr int R_ORDER_MAX_TILES = 16384;      // 2048 x 2048 pixels
+constexpr int R_ORDER_MAX_PRIMS = 64;         // one mask word per tile
 __host__ __device__ inline size_t raster_order_scratch(int K, int ntile) {
     return (size_t)K * R_CULL * 16 + (size_t)K * 4 + (size_t)(K + 2) * 4 + (size_t)ntile;
 }
@@ -352,29 +364,52 @@ __device__ inline void raster_order_wg(const RasterOrderJob& J, int b, void* scr
     float4* cull = reinterpret_cast<float4*>(scratch);
     int* knd = reinterpret_cast<int*>(cull + R_CULL * J.K);      // kind of every primitive
     int* hist = knd + J.K;                                       // hist[c] -> start of the bucket of popcount c (descending)
-    unsigned char* pops = reinterpret_cast<unsigned char*>(hist + J.K + 2);   // visible primitives per tile (K <= 255)
+    unsigned char* pops = reinterpret_cast<unsigned char*>(hist + J.K + 2);   // visible primitives per tile (K <= 64)
     const float4* rec_b = J.rec + (size_t)b * J.K * R_REC;
     for (int i = threadIdx.x; i < R_CULL * J.K; i += THREADS) cull[i] = rec_b[(size_t)(i / R_CULL) * R_REC + 4 + i % R_CULL];
     for (int k = threadIdx.x; k < J.K; k += THREADS) knd[k] = __float_as_int(rec_b[(size_t)k * R_REC].w);
     for (int i = threadIdx.x; i <= J.K + 1; i += THREADS) hist[i] = 0;
     __syncthreads();
-    unsigned long long* mrow = J.masks + (size_t)b * J.ntile * J.words;
-    // pass 1: masks and the histogram of their popcounts
+    unsigned long long* mrow = J.masks + (size_t)b * J.ntile;
+    TileEntry* by_rank = J.entries + (size_t)b * J.ntile;
+    TileEntry* by_tile = J.entries + ((size_t)J.B + b) * J.ntile;
+    auto both = [](unsigned long long v) {                                    // OR over the two lanes of a tile
+        return v | ((unsigned long long)__shfl_xor((unsigned)(v >> 32), 1, 64) << 32) | (unsigned)__shfl_xor((unsigned)v, 1, 64);
+    };
+    // pass 1: masks (tile level, then the four quadrants of the visible pairs) and the histogram of the popcounts
     for (int it = threadIdx.x; it < 2 * J.ntile; it += THREADS) {            // pairs of lanes: THREADS and it are even together
         const int tile = it >> 1, par = it & 1;
         const int ty = tile / J.tiles_x, tx = tile - ty * J.tiles_x;
-        int pop = 0;
-        for (int w = 0; w < J.words; ++w) {
-            unsigned long long m = 0ull;
-            for (int k = 64 * w + par; k < min(J.K, 64 * w + 64); k += 2)
-                if (prim_hits_tile(knd[k], cull + R_CULL * k, tx * R_TW, ty * R_TH, J.H, J.W)) m |= 1ull << (k & 63);
-            m |= ((unsigned long long)__shfl_xor((unsigned)(m >> 32), 1, 64) << 32) | (unsigned)__shfl_xor((unsigned)m, 1, 64);
-            if (par == 0) mrow[(size_t)tile * J.words + w] = m;
-            pop += __builtin_popcountll(m);
+        unsigned long long m = 0ull, q[4] = {0ull, 0ull, 0ull, 0ull};
+        for (int k = par; k < J.K; k += 2)
+            if (prim_hits_tile(knd[k], cull + R_CULL * k, tx * R_TW, ty * R_TH, J.H, J.W)) m |= 1ull << k;
+        unsigned long long own = m;                                          // this lane's visible primitives (its parity)
+        m = both(m);
+        // quadrants of the visible pairs only (a handful per lane): slot j = rank of primitive k among the tile's visible
+        // ones = the slot the tile wave stages it in; four bits per slot, sixteen slots per word
+        for (; own; own &= own - 1ull) {
+            const int k = __builtin_ctzll(own), j = __builtin_popcountll(m & ((1ull << k) - 1ull));
+            unsigned nib = 0u;
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd)
+                if (prim_hits_tile(knd[k], cull + R_CULL * k, tx * R_TW + 8 * (qd & 1), ty * R_TH + 8 * (qd >> 1), J.H, J.W, 8, 8)) nib |= 1u << qd;
+            const unsigned long long sh = (unsigned long long)nib << (4 * (j & 15));
+            q[0] |= (j >> 4) == 0 ? sh : 0ull; q[1] |= (j >> 4) == 1 ? sh : 0ull; q[2] |= (j >> 4) == 2 ? sh : 0ull; q[3] |= (j >> 4) == 3 ? sh : 0ull;
         }
-        if (par == 0) { pops[tile] = (unsigned char)pop; atomicAdd(&hist[J.K - pop], 1); }      // bucket 0 = all K primitives visible
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) q[qd] = both(q[qd]);
+        if (par == 0) {
+            const int pop = __builtin_popcountll(m);
+            mrow[tile] = m;
+            TileEntry e;
+            e.tile = (unsigned)tile; e.n = (unsigned)pop; e.mask = m;
+            e.q[0] = q[0]; e.q[1] = q[1]; e.q[2] = q[2]; e.q[3] = q[3];
+            by_tile[tile] = e;
+            pops[tile] = (unsigned char)pop;
+            atomicAdd(&hist[J.K - pop], 1);                                    // bucket 0 = all K primitives visible
+        }
     }
-    __syncthreads();
+    __syncthreads();                                                          // also orders this workgroup's by_tile writes before its reads below
     if (threadIdx.x == 0) {                                                   // exclusive prefix over K + 1 buckets
         int run = 0;
         for (int c = 0; c <= J.K; ++c) { const int n = hist[c]; hist[c] = run; run += n; }
@@ -382,9 +417,12 @@ __device__ inline void raster_order_wg(const RasterOrderJob& J, int b, void* scr
     __syncthreads();
     // pass 2: every tile takes the next place of its bucket (the order inside a bucket is whatever the atomics give:
     // it schedules, it does not change a result)
-    unsigned short* orow = J.order + (size_t)b * J.ntile;
+    const uint4* src = reinterpret_cast<const uint4*>(by_tile);
+    uint4* dst = reinterpret_cast<uint4*>(by_rank);
     for (int tile = threadIdx.x; tile < J.ntile; tile += THREADS) {
-        orow[atomicAdd(&hist[J.K - (int)pops[tile]], 1)] = (unsigned short)tile;
+        const int pos = atomicAdd(&hist[J.K - (int)pops[tile]], 1);
+        const uint4 e0 = src[3 * tile], e1 = src[3 * tile + 1], e2 = src[3 * tile + 2];
+        dst[3 * pos] = e0; dst[3 * pos + 1] = e1; dst[3 * pos + 2] = e2;
     }
 }
 

@@ -633,7 +633,7 @@ class HotPathLossFunction(Function):
             # ... and, when the Chamfer scan will be the matrix-pipe filter, that filter's features of both clouds
             fused = bool(L.vpn_hotpath_fused_features(B, K, n, M))
             # the scan launch can carry a rider that tests the tiles against the primitives and sorts them by weight
-            use_order = fused and TILE_ORDER and K <= 255 and ntile <= 16384 and K * 84 + (K + 2) * 4 + ntile <= 24576
+            use_order = fused and TILE_ORDER and K <= 64 and ntile <= 16384 and K * 84 + (K + 2) * 4 + ntile <= 24576
             _lib.call('vpn_hotpath_sample_fwd', _lib.ptr(params), _lib.ptr(kinds), None, seed_host, seed_dev,
                       int(sample_base), B, K, n, _lib.ptr(points), _lib.ptr(cam), H, W, float(sigma),
                       _lib.ptr(rec),
@@ -649,9 +649,10 @@ class HotPathLossFunction(Function):
         fused_fin = side is None and chamfer_mode == 7
         order = None
         if use_order:
-            # the scan launch also sorts the raster's tiles by visible primitives (a rider in its tail): the tile waves
-            # then start heaviest first and read their masks instead of testing the primitives again
-            order = torch.empty((L.vpn_raster_order_size(B, H, W) // 2,), dtype=torch.int16, device=dev)
+            # the scan launch also prepares the raster's tiles (a rider in its tail): one entry per tile wave -- which tile
+            # (heaviest first), which primitives it sees, which quadrants each of them reaches -- instead of every tile wave
+            # finding that out for itself
+            order = torch.empty((L.vpn_raster_order_size(B, H, W) // 8,), dtype=torch.int64, device=dev)   # 48-byte tile entries
             _lib.call('vpn_hotpath_chamfer_fwd', _lib.ptr(points), _lib.ptr(gt_points), B, N, M, _lib.ptr(d1), _lib.ptr(i1),
                       _lib.ptr(d2), _lib.ptr(i2), _lib.ptr(cws), cws.numel() * 4, chamfer_mode, _lib.ptr(rec), K, H, W,
                       _lib.ptr(order), s)
