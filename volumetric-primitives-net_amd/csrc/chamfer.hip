@@ -31,6 +31,14 @@ constexpr int CH_WTILE = 256;    // targets per wave-private LDS tile (SoA, 3 KB
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
+#ifdef CM_EXP_TRACE
+// timeline experiment (tools/scan_timeline.py): per scan workgroup start, end of the tile loop, end of the per-query
+// finish, end (after its fix-up) on the 100 MHz wall clock, job (direction) and the number of undecided queries it resolved
+__device__ unsigned long long g_ctrace[8192 * 8];
+extern "C" int vpn_debug_scan_trace(void* dst, int nwg) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_ctrace), (size_t)nwg * 8 * sizeof(unsigned long long), 0, hipMemcpyDeviceToDevice);
+}
+#endif
 #ifdef VPN_CHAMFER_DEBUG
 __device__ unsigned long long g_dbg[8];
 #endif
@@ -1089,6 +1097,9 @@ __global__ __launch_bounds__(cm_block<PREC>(), PREC == 1 ? 5 : CM_WAVES_PER_EU) 
 #else
     const int wg = (int)blockIdx.x - (PREC == 2 ? oj.B : 0);
 #endif
+#ifdef CM_EXP_TRACE
+    const unsigned long long t_start = wall_clock64();
+#endif
     const bool other = wg >= j0.G;
     const float* __restrict__ qpts = other ? j1.qpts : j0.qpts;
     const float* __restrict__ F = other ? j1.F : j0.F;
@@ -1396,6 +1407,9 @@ __global__ __launch_bounds__(cm_block<PREC>(), PREC == 1 ? 5 : CM_WAVES_PER_EU) 
         __syncthreads();                            // everybody done with `buf`, next tile landed
     }
     }
+#ifdef CM_EXP_TRACE
+    const unsigned long long t_loop = wall_clock64();
+#endif
     // The tracked unit (cell) is what ONE half-wave saw of CM_CELL consecutive targets: lane (jq, half) holds the
     // accumulator rows 8 g + 4 half + r (g = 0 .. CM_CELL/8 - 1, r = 0..3) of every block.  The winner is the cell with
     // the smallest filtered minimum over both half-waves of the query; V2 = the smallest filtered minimum over ALL other
@@ -1529,6 +1543,9 @@ __global__ __launch_bounds__(cm_block<PREC>(), PREC == 1 ? 5 : CM_WAVES_PER_EU) 
     }
     __syncthreads();
     const int cnt = s_cnt;
+#ifdef CM_EXP_TRACE
+    const unsigned long long t_epi = wall_clock64();
+#endif
     float sfin = (half == 0 && qi < Nq) ? s : 0.0f;                 // this query's final minimum (once per query)
 #ifndef CM_EXP_NOFIX
     if (cnt != 0) {
@@ -1556,6 +1573,12 @@ __global__ __launch_bounds__(cm_block<PREC>(), PREC == 1 ? 5 : CM_WAVES_PER_EU) 
 #pragma unroll
         for (int v = 1; v < cm_block<PREC>() / 64; ++v) t += s_ws[v];
         wgsum[(size_t)b * gx + bx] = t;
+#ifdef CM_EXP_TRACE
+        if (PREC == 2 && wg < 8192) {
+            unsigned long long* g = g_ctrace + (size_t)wg * 8;
+            g[0] = t_start; g[1] = t_loop; g[2] = t_epi; g[3] = wall_clock64(); g[4] = other ? 1ull : 0ull; g[5] = (unsigned long long)cnt;
+        }
+#endif
     }
 }
 
