@@ -1100,6 +1100,8 @@ __global__ __launch_bounds__(cm_block<PREC>(), PREC == 1 ? 5 : CM_WAVES_PER_EU) 
 #ifdef CM_EXP_TRACE
     const unsigned long long t_start = wall_clock64();
 #endif
+    __shared__ int s_cnt;                                           // length of the workgroup's list of undecided queries (epilogue)
+    if (threadIdx.x == 0) s_cnt = 0;
     const bool other = wg >= j0.G;
     const float* __restrict__ qpts = other ? j1.qpts : j0.qpts;
     const float* __restrict__ F = other ? j1.F : j0.F;
@@ -1522,13 +1524,10 @@ __global__ __launch_bounds__(cm_block<PREC>(), PREC == 1 ? 5 : CM_WAVES_PER_EU) 
     // index inside the best cell) and is resolved exactly by this workgroup before it exits (fixup_own): no list in
     // memory, no second launch, nothing shared between workgroups.
     constexpr int QPW = cm_block<PREC>() / 2;                       // queries per workgroup = capacity of the list
-    __shared__ int s_cnt;
     __shared__ float4 s_qd[QPW];
     __shared__ int2 s_qi[QPW];
     __shared__ float s_ws[cm_block<PREC>() / 64];
-    if (threadIdx.x == 0) s_cnt = 0;
-    __syncthreads();
-    int pos = -1;
+    int pos = -1;                                                   // (s_cnt was zeroed before the tile loop, whose barriers order it)
     if (half == 0 && qi < Nq) {
         if (!ambiguous) {
             out_dist[(size_t)b * Nq + qi] = s;
