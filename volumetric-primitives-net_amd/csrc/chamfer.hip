@@ -1087,6 +1087,9 @@ __global__ __launch_bounds__(cm_block<PREC>(), PREC == 1 ? 5 : CM_WAVES_PER_EU) 
         // the rider (~10 us since it also tests the quadrants) is dispatched FIRST: ids [0, oj.B).  Last, it was the tail of
         // the launch (+10 us); first it costs 64 of 768 slots for its lifetime (not measurable)
         if ((int)blockIdx.x < oj.B) {
+#ifndef CM_RIDER_NOPRIO
+            __builtin_amdgcn_s_setprio(3);               // few waves with a long dependent chain among scan waves at full tilt
+#endif
             raster_order_wg<cm_block<PREC>()>(oj, (int)blockIdx.x, tileH16);
             return;
         }
