@@ -34,6 +34,9 @@
 extern "C" {
 #endif
 
+/* 4 (round 3): raster records are 16 float4 per primitive (vpn_raster_records_size grew), tile_order is a buffer of
+ * 48-byte tile entries (vpn_raster_order_size, K <= 64).  3: vpn_raster_total_fwd_fin, vpn_hotpath_chamfer_fwd, the mesh
+ * entry points. */
 #define VPN_ABI_VERSION 4
 
 /* primitive kinds (reference: train.py:106-116 cuboids first, then spheres, cones are stubs) */
