@@ -828,12 +828,15 @@ def test_raster_full_size_properties(vpn):
     a, d = vpn.RasterFunction.apply(pg, kinds, g(cam), H, W, 0.05, 0.1, 2.0)
     a_ref, d_ref = O.raster(params[:2], [0] * K, cam[:2], H, W, 0.05, 0.1, 2.0)
     assert rel_err(a[:2].detach().cpu(), a_ref) <= RTOL and rel_err(d[:2].detach().cpu(), d_ref) <= RTOL
-    Wa, Wd = torch.randn(B, H, W, device=DEV), torch.randn(B, H, W, device=DEV)
+    Wa, Wd = g(torch.randn(B, H, W, generator=gen)), g(torch.randn(B, H, W, generator=gen))     # seeded: the same case every run
     g1, = torch.autograd.grad([a, d], [pg], [Wa, Wd], retain_graph=True)
     g1b, = torch.autograd.grad([a, d], [pg], [Wa, Wd], retain_graph=True)
     g2, = torch.autograd.grad([a, d], [pg], [2 * Wa, 2 * Wd], retain_graph=True)
     assert torch.equal(g1, g1b), 'backward is not deterministic'
-    assert torch.equal(g2, 2 * g1), 'backward is not linear in the incoming gradient'
+    # doubling is exact in every operation except where a product falls into the flushed denormal range in one run and not
+    # in the other (the kernels flush denormals; with unseeded weights this used to fail once in a few dozen runs):
+    # bit-equal up to 1e-30 of the largest entry
+    assert float((g2 - 2 * g1).abs().max()) <= 1e-30 * float(g1.abs().max()), 'backward is not linear in the incoming gradient'
     assert bool(torch.isfinite(g1).all())
     assert 0.02 < float(a.mean()) < 0.9
 
@@ -915,11 +918,12 @@ def test_raster_config5_shape(vpn, kinds_name):
     _assert_grad(pg.grad.cpu(), gref, g64)
     pb = g(params).requires_grad_(True)
     a, d = vpn.RasterFunction.apply(pb, kt, g(cam), H, W, 0.05, 0.1, 2.0)
-    Wa, Wd = torch.randn(B, H, W, device=DEV), torch.randn(B, H, W, device=DEV)
+    Wa, Wd = g(torch.randn(B, H, W, generator=gen)), g(torch.randn(B, H, W, generator=gen))     # seeded: the same case every run
     g1, = torch.autograd.grad([a, d], [pb], [Wa, Wd], retain_graph=True)
     g1b, = torch.autograd.grad([a, d], [pb], [Wa, Wd], retain_graph=True)
     g2, = torch.autograd.grad([a, d], [pb], [2 * Wa, 2 * Wd], retain_graph=True)
-    assert torch.equal(g1, g1b) and torch.equal(g2, 2 * g1) and bool(torch.isfinite(g1).all())
+    # (linearity up to flushed denormals: see test_raster_full_size_properties)
+    assert torch.equal(g1, g1b) and float((g2 - 2 * g1).abs().max()) <= 1e-30 * float(g1.abs().max()) and bool(torch.isfinite(g1).all())
     # a shard rendered alone equals the same rows of the batch
     a2, d2 = vpn.RasterFunction.apply(g(params[3:5]), kt, g(cam[3:5]), H, W, 0.05, 0.1, 2.0)
     assert torch.equal(a2, a[3:5].detach()) and torch.equal(d2, d[3:5].detach())

@@ -646,12 +646,19 @@ extern "C" int vpn_debug_raster_trace(void* dst, int nwaves) {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_rtrace), (size_t)nwaves * 8 * sizeof(unsigned long long), 0, hipMemcpyDeviceToDevice);
 }
 #endif
-__global__ __launch_bounds__(64, R_TOTAL_WAVES) void raster_total_kernel(const float4* __restrict__ rec,
+// ENT: the training step's form -- every wave gets its tile entry (K <= 64: one mask word, masks and quadrant words given),
+// so the visibility tests, the multi-word loops and the culling records are compiled OUT of that instantiation
+#ifndef R_ENT_WAVES
+#define R_ENT_WAVES 5
+#endif
+template <bool ENT>
+__global__ __launch_bounds__(64, ENT ? R_ENT_WAVES : R_TOTAL_WAVES) void raster_total_kernel(const float4* __restrict__ rec,
                                                            unsigned long long* __restrict__ masks,
                                                            const float* __restrict__ cam, int B, int K, int H, int W,
-                                                           int tiles_x, int tiles_y, int words, float sigma, float gamma,
+                                                           int tiles_x, int tiles_y, int words_arg, float sigma, float gamma,
                                                            float z_far, float* __restrict__ partial, LossArgs la, FinArgs fin,
                                                            const TileEntry* __restrict__ entries) {
+    const int words = ENT ? 1 : words_arg;
 #ifdef R_EXP_TRACE
     const unsigned long long t_start = wall_clock64();
 #endif
@@ -662,7 +669,7 @@ __global__ __launch_bounds__(64, R_TOTAL_WAVES) void raster_total_kernel(const f
     unsigned long long m_entry = 0ull;
     int tile_of_entry = -1;
     uint4 e1q = make_uint4(0u, 0u, 0u, 0u), e2q = e1q;
-    if (entries) {
+    if (ENT) {
         const int pt = blockIdx.x / B, eb = blockIdx.x - pt * B;
         const uint4* e = reinterpret_cast<const uint4*>(entries + (size_t)eb * ntile + pt);
         const uint4 e0 = e[0], e1 = e[1], e2 = e[2];
@@ -671,7 +678,7 @@ __global__ __launch_bounds__(64, R_TOTAL_WAVES) void raster_total_kernel(const f
         };
         tile_of_entry = __builtin_amdgcn_readfirstlane((int)e0.x);
         m_entry = u64(e0.z, e0.w);
-        qk.on = words == 1;
+        qk.on = true;
         e1q = e1; e2q = e2;
     }
     const Tile T = make_tile(H, W, tiles_x, tiles_y, B, tile_of_entry);
@@ -692,14 +699,13 @@ __global__ __launch_bounds__(64, R_TOTAL_WAVES) void raster_total_kernel(const f
         gd[s] = (la.gt_depth && in) ? la.gt_depth[T.b * hw + pix] : 0.0f;
     }
     extern __shared__ __attribute__((aligned(16))) float4 srec[];      // raster_lds_bytes(K)
-    if (qk.on && lane == 0) {                                           // every lane holds the same two uint4
+    if (ENT && lane == 0) {                                             // every lane holds the same two uint4
         uint4* sq = reinterpret_cast<uint4*>(quadrant_words(srec, K));
         sq[0] = e1q; sq[1] = e2q;
     }
     float P[R_PPL], S0[R_PPL], S1[R_PPL];
     // with entries the tile's mask is known (words == 1 there): stage_word takes it from `m_entry`
-    const unsigned long long m0 = tile_forward(T, rec_b, mrow, words, K, H, W, srec, inv_sigma, inv_gamma, zref, P, S0, S1, entries != nullptr,
-                                               qk, entries != nullptr, m_entry);
+    const unsigned long long m0 = tile_forward(T, rec_b, mrow, words, K, H, W, srec, inv_sigma, inv_gamma, zref, P, S0, S1, ENT, qk, ENT, m_entry);
 #ifdef R_EXP_TRACE
     const unsigned long long t_fwd = wall_clock64();
 #endif
@@ -754,7 +760,7 @@ __global__ __launch_bounds__(64, R_TOTAL_WAVES) void raster_total_kernel(const f
 #endif
     // K > 64: the backward restages word by word from the masks this wave stored (or read) in the forward half -- lane 0
     // reads back its own stores, program order -- instead of repeating the visibility test
-    tile_backward(T, rec_b, mrow, words, K, ntile, H, W, srec, words == 1, m0, inv_sigma, inv_gamma, zref, P, zbar, invS,
+    tile_backward(T, rec_b, mrow, words, K, ntile, H, W, srec, ENT || words == 1, m0, inv_sigma, inv_gamma, zref, P, zbar, invS,
                   gAtot, gZbar, partial, qk);
 #ifdef R_EXP_TRACE
     const unsigned long long t_bwd = wall_clock64();
@@ -1044,7 +1050,7 @@ extern "C" int vpn_raster_total_fwd(const float* params, const int32_t* kinds, c
     if (!records_ready && (rc = launch_prep(params, kinds, cam, B, K, H, W, sigma, records, (int*)loss_ws, s))) return rc;
     const Grid G = raster_grid(B, K, H, W);
     LossArgs la{gt_sil, gt_depth, sil_mse, 1.0f / ((float)B * (float)H * (float)W), tile_loss_of(loss_ws, B), nullptr, w_sil, w_dep};
-    VPN_LAUNCH(raster_total_kernel, G.g, dim3(64), raster_lds_bytes(K), s, (const float4*)records, masks_of(records, B, K), cam, B, K,
+    VPN_LAUNCH_AS("raster_total_kernel", raster_total_kernel<false>, G.g, dim3(64), raster_lds_bytes(K), s, (const float4*)records, masks_of(records, B, K), cam, B, K,
                H, W, G.tiles_x, G.tiles_y, G.words, sigma, gamma, z_far, (float*)workspace, la, FinArgs{}, (const TileEntry*)nullptr);
     VPN_LAUNCH_CHECK();
     return 0;
@@ -1079,8 +1085,12 @@ extern "C" int vpn_raster_total_fwd_fin(const float* params, const int32_t* kind
     const Grid G = raster_grid(B, K, H, W);
     if (tile_order && (!records_ready || G.words != 1 || ((uintptr_t)tile_order & 15) != 0)) return VPN_E_BADARG;   // entries come with the masks, K <= 64
     LossArgs la{gt_sil, gt_depth, sil_mse, 1.0f / ((float)B * (float)H * (float)W), tile_loss_of(loss_ws, B), nullptr, w_sil, w_dep};
-    VPN_LAUNCH(raster_total_kernel, G.g, dim3(64), raster_lds_bytes(K), s, (const float4*)records, masks_of(records, B, K), cam, B, K,
-               H, W, G.tiles_x, G.tiles_y, G.words, sigma, gamma, z_far, (float*)workspace, la, fin, (const TileEntry*)tile_order);
+    if (tile_order)
+        VPN_LAUNCH_AS("raster_total_kernel", raster_total_kernel<true>, G.g, dim3(64), raster_lds_bytes(K), s, (const float4*)records, masks_of(records, B, K), cam, B, K,
+                      H, W, G.tiles_x, G.tiles_y, G.words, sigma, gamma, z_far, (float*)workspace, la, fin, (const TileEntry*)tile_order);
+    else
+        VPN_LAUNCH_AS("raster_total_kernel", raster_total_kernel<false>, G.g, dim3(64), raster_lds_bytes(K), s, (const float4*)records, masks_of(records, B, K), cam, B, K,
+                      H, W, G.tiles_x, G.tiles_y, G.words, sigma, gamma, z_far, (float*)workspace, la, fin, (const TileEntry*)nullptr);
     VPN_LAUNCH_CHECK();
     return 0;
 }

@@ -28,6 +28,14 @@ void prof_end(hipStream_t s);
         vpn::prof_end(strm);                                                           \
     } while (0)
 
+// the same under a given profile label (template instantiations of one kernel keep one name in the launch profile)
+#define VPN_LAUNCH_AS(label, kern, grid, block, lds, strm, ...)                        \
+    do {                                                                               \
+        vpn::prof_begin(label, strm);                                                  \
+        hipLaunchKernelGGL(kern, grid, block, lds, strm, __VA_ARGS__);                 \
+        vpn::prof_end(strm);                                                           \
+    } while (0)
+
 namespace vpn {
 
 struct Mat3 { float m[3][3]; };
