@@ -55,7 +55,10 @@ def main(tag):
             cur = None
         elif cur and line.startswith('\t') and not line.startswith(('\t.', '\t;')):
             funcs[cur].append(line.strip())
-    names = {'raster_total_kernel': 'raster_total_kernel', 'raster_fwd_kernelILi0': 'raster_fwd_kernel<0>',
+    # raster_total_kernel<true> is the training step's instantiation (tile entries) = the name the launch profile uses;
+    # <false> (module path, C2) is listed beside it (the two mixes differ in the third digit)
+    names = {'raster_total_kernelILb1': 'raster_total_kernel', 'raster_total_kernelILb0': 'raster_total_kernel<common>',
+             'raster_fwd_kernelILi0': 'raster_fwd_kernel<0>',
              'raster_fwd_kernelILi1': 'raster_fwd_kernel<1>', 'raster_bwd_kernelILi0': 'raster_bwd_kernel<0>',
              'raster_bwd_kernelILi1': 'raster_bwd_kernel<1>'}
     out, lines = {}, ['# static VALU issue-class mix of raster.hip (tools/isa_mix.py); cycles per class: %s' % COST]
