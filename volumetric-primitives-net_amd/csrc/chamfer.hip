@@ -968,7 +968,7 @@ __device__ inline float sqrt_up(float x) { return __builtin_amdgcn_sqrtf(x) * (1
 #define CM_FUN 2
 #endif
 template <int THREADS>
-__device__ inline void fixup_own(const float* __restrict__ Fb, float snb, int Nq, int Nt, int Ntp,
+__device__ __forceinline__ void fixup_own(const float* __restrict__ Fb, float snb, int Nq, int Nt, int Ntp,
                                  float* __restrict__ out_dist, int32_t* __restrict__ out_idx,
                                  float4* lqd, const int2* lqi, int count) {
     constexpr int FQ = THREADS >= 512 ? CM_FQ : 2;   // listed queries per pass over the targets (register budget of the host kernel)

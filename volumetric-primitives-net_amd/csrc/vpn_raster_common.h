@@ -360,7 +360,7 @@ __host__ __device__ inline size_t raster_order_scratch(int K, int ntile) {
     return (size_t)K * R_CULL * 16 + (size_t)K * 4 + (size_t)(K + 2) * 4 + (size_t)ntile;
 }
 template <int THREADS>
-__device__ inline void raster_order_wg(const RasterOrderJob& J, int b, void* scratch) {
+__device__ __forceinline__ void raster_order_wg(const RasterOrderJob& J, int b, void* scratch) {
     float4* cull = reinterpret_cast<float4*>(scratch);
     int* knd = reinterpret_cast<int*>(cull + R_CULL * J.K);      // kind of every primitive
     int* hist = knd + J.K;                                       // hist[c] -> start of the bucket of popcount c (descending)
