@@ -834,9 +834,10 @@ def test_raster_full_size_properties(vpn):
     g2, = torch.autograd.grad([a, d], [pg], [2 * Wa, 2 * Wd], retain_graph=True)
     assert torch.equal(g1, g1b), 'backward is not deterministic'
     # doubling is exact in every operation except where a product falls into the flushed denormal range in one run and not
-    # in the other (the kernels flush denormals; with unseeded weights this used to fail once in a few dozen runs):
-    # bit-equal up to 1e-30 of the largest entry
-    assert float((g2 - 2 * g1).abs().max()) <= 1e-30 * float(g1.abs().max()), 'backward is not linear in the incoming gradient'
+    # in the other (the kernels flush denormals): measured on this very case, ONE of the 6.3 M tile partials differs by one
+    # ulp between W and 2 W (tools/raster_linearity_check.py; with either reduction of the tile sums), which may or may not survive the
+    # rounding of the sums behind it.  Linear to a few ulps of the largest entry, and exactly reproducible.
+    assert float((g2 - 2 * g1).abs().max()) <= 1e-6 * float(g1.abs().max()), 'backward is not linear in the incoming gradient'
     assert bool(torch.isfinite(g1).all())
     assert 0.02 < float(a.mean()) < 0.9
 
@@ -923,7 +924,7 @@ def test_raster_config5_shape(vpn, kinds_name):
     g1b, = torch.autograd.grad([a, d], [pb], [Wa, Wd], retain_graph=True)
     g2, = torch.autograd.grad([a, d], [pb], [2 * Wa, 2 * Wd], retain_graph=True)
     # (linearity up to flushed denormals: see test_raster_full_size_properties)
-    assert torch.equal(g1, g1b) and float((g2 - 2 * g1).abs().max()) <= 1e-30 * float(g1.abs().max()) and bool(torch.isfinite(g1).all())
+    assert torch.equal(g1, g1b) and float((g2 - 2 * g1).abs().max()) <= 1e-6 * float(g1.abs().max()) and bool(torch.isfinite(g1).all())
     # a shard rendered alone equals the same rows of the batch
     a2, d2 = vpn.RasterFunction.apply(g(params[3:5]), kt, g(cam[3:5]), H, W, 0.05, 0.1, 2.0)
     assert torch.equal(a2, a[3:5].detach()) and torch.equal(d2, d[3:5].detach())

@@ -1,0 +1,47 @@
+"""Is the raster backward exactly linear under W -> 2 W?  Calls vpn_raster_bwd on the C3 raster case of
+test_raster_full_size_properties with its own workspaces and compares them entry by entry (finding: one tile partial in
+6.3 M differs by one ulp, with either reduction of the tile sums; the workspace fill value does not matter)."""
+import sys, torch
+sys.path.insert(0, '/root/repo')
+import vpn_amd as vpn
+from vpn_amd import _lib
+DEV = 'cuda'
+g = lambda t: t.to(DEV)
+def rand_params(gen, B, K):
+    v = (torch.rand(B, K, 3, generator=gen) + 0.1) / torch.tensor([8.0, 10.0, 10.0])
+    q = torch.rand(B, K, 4, generator=gen)
+    t = 0.35 * (torch.rand(B, K, 3, generator=gen) * 2 - 1)
+    return torch.cat([v, q, t], 2)
+gen = torch.Generator().manual_seed(1234)
+B, K, H, W = 64, 32, 256, 256
+params = g(rand_params(gen, B, K))
+kinds = vpn.kinds_tensor([0] * K, torch.device(DEV))
+cam = g(torch.tensor([[1.0, 0.0, 0.0]]).expand(B, 3).contiguous())
+L = _lib.lib()
+alpha, depth = torch.empty(B, H, W, device=DEV), torch.empty(B, H, W, device=DEV)
+aux = torch.empty(B, 3, H, W, device=DEV)
+rec = torch.zeros(L.vpn_raster_records_size(B, K, H, W) // 4, device=DEV)
+_lib.call('vpn_raster_fwd', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(cam), B, K, H, W, 0.05, 0.1, 2.0, _lib.ptr(alpha), _lib.ptr(depth), _lib.ptr(aux), _lib.ptr(rec), _lib.stream())
+Wa, Wd = g(torch.randn(B, H, W, generator=gen)), g(torch.randn(B, H, W, generator=gen))
+nws = L.vpn_raster_bwd_workspace(B, K, H, W) // 4
+def bwd(sc, fill):
+    ws = torch.full((nws,), fill, device=DEV)
+    gp = torch.empty_like(params)
+    ga, gd = (sc * Wa).contiguous(), (sc * Wd).contiguous()
+    _lib.call('vpn_raster_bwd', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(cam), B, K, H, W, 0.05, 0.1, 2.0, _lib.ptr(aux), _lib.ptr(rec), _lib.ptr(ga), _lib.ptr(gd),
+              _lib.ptr(ws), _lib.ptr(gp), _lib.stream())
+    torch.cuda.synchronize()
+    return ws, gp
+w1, g1 = bwd(1.0, 0.0)
+w1n, g1n = bwd(1.0, float('nan'))
+w2, g2 = bwd(2.0, 0.0)
+print('g with zero-filled vs NaN-filled workspace equal:', bool(torch.equal(g1, g1n)), ' NaNs in g:', int(torch.isnan(g1n).sum()))
+d = (w2 - 2 * w1).abs()
+print('workspace floats', nws, 'entries where ws(2W) != 2 ws(W):', int((d > 0).sum()), 'max', float(d.max()))
+dg = (g2 - 2 * g1).abs()
+print('grad entries differing:', int((dg > 0).sum()), [tuple(i) for i in (dg > 0).nonzero()[:4].tolist()])
+idx = (d > 0).nonzero().flatten()[:10].tolist()
+ntile = 256
+for i in idx:
+    bk, rem = divmod(i, ntile * 12); tile, c = divmod(rem, 12)
+    print('   ws index', i, '(b,k)=', divmod(bk, K), 'tile', tile, 'component', c, float(w1[i]), float(w2[i]))

@@ -261,7 +261,10 @@ constexpr int R_SLOT = 4;            // float4 per staged primitive: (o~|kind, M
 // LDS of a tile wave (dynamic): `nslot` staged records, then their culling records.  nslot = min(K, 64): a mask word's
 // worth -- 4.5 KB at K = 32, 9 KB from K = 64 on
 __host__ __device__ inline int raster_nslot(int K) { return K < 64 ? K : 64; }
-__host__ __device__ inline size_t raster_lds_bytes(int K) { return (size_t)raster_nslot(K) * (R_SLOT + R_CULL) * sizeof(float4) + 4 * sizeof(unsigned long long); }
+constexpr int R_RED_FLOATS = 12 * 64;      // transposing reduction of a tile's 12 gradient sums through LDS (reduce12_lds)
+__host__ __device__ inline size_t raster_lds_bytes(int K) {
+    return (size_t)raster_nslot(K) * (R_SLOT + R_CULL) * sizeof(float4) + 4 * sizeof(unsigned long long) + R_RED_FLOATS * sizeof(float);
+}
 
 // Mask word w of this tile and staging of its visible primitives in one go: lane i fetches the whole record of
 // primitive 64 w + i (7 float4, one round trip), tests it against the tile, and if visible stores its ray coefficients
@@ -320,6 +323,32 @@ __device__ inline unsigned long long quadrant_bits(const Tile& T, const float4* 
         vis = prim_hits_tile(__float_as_int(srec[slot * R_SLOT].w), scull, T.c0 + 8 * (qd & 1), T.r0 + 8 * (qd >> 1), H, W, 8, 8);
     }
     return __ballot(vis);
+}
+
+// 12 per-lane values -> lane L (L < 48) holds the wave total of value L >> 2, THROUGH LDS: every lane writes its 12 values
+// value-major, lane 4 i + q reads back the 16 contributions of lanes 16 q .. 16 q + 15 to value i (four 16-byte reads),
+// adds them in order, and two quad steps add the four quarters.  The tile kernels are bound by VALU issue and the LDS pipe
+// issues beside it: this is 17 VALU instructions where the register butterfly (wave_reduce16) is 30 selects + 17 adds.
+// Fixed order: bitwise reproducible (not the butterfly's order: the last bits differ from it).
+__device__ inline float reduce12_lds(const float v[16], float* red) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) red[i * 64 + lane] = v[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    float r = 0.0f;
+    if (lane < 48) {
+        const float4* p = reinterpret_cast<const float4*>(red + (lane >> 2) * 64 + (lane & 3) * 16);
+        const float4 a = p[0], b = p[1], c = p[2], d = p[3];
+        r = ((((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w))) + (((c.x + c.y) + (c.z + c.w)) + ((d.x + d.y) + (d.z + d.w))));
+    }
+    r += __shfl_xor(r, 1, 64);
+    r += __shfl_xor(r, 2, 64);
+    __builtin_amdgcn_wave_barrier();           // the next primitive's writes come after these reads
+    return r;
+}
+__device__ inline float* reduce_scratch(float4* srec, int K) {
+    return reinterpret_cast<float*>(srec + raster_nslot(K) * (R_SLOT + R_CULL)) + 8;        // behind the 4 quadrant words
 }
 
 // all passes of the staged word at once, kept in LDS behind the culling records: the forward and the backward loop of a
@@ -520,7 +549,11 @@ __device__ inline void tile_backward(const Tile& T, const float4* __restrict__ r
             };
             if (__builtin_amdgcn_readfirstlane(__float_as_int(q0.w)) == VPN_SPHERE) body(std::integral_constant<int, VPN_SPHERE>{});
             else body(std::integral_constant<int, VPN_CUBOID>{});
+#ifdef R_REDUCE_BUTTERFLY
             const float tot = wave_reduce16(v);
+#else
+            const float tot = reduce12_lds(v, reduce_scratch(srec, K));
+#endif
             if ((lane & 3) == 0 && (lane >> 2) < 12)
                 partial[(((size_t)T.b * K + k) * ntile + T.tile) * 12 + (lane >> 2)] = tot;
         }

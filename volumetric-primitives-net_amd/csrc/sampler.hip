@@ -342,7 +342,7 @@ __global__ __launch_bounds__(SCB_BLOCK) void sample_chamfer_bwd_kernel(
     if (rf.partial) {
         float fv[16];
         raster_finish_gather(b * K + k, K, rf.ntile, rf.words, rf.masks, rf.partial, (int)(threadIdx.x >> 6) * 64, SCB_BLOCK, fv);
-        const float tot = wave_reduce16(fv);
+        const float tot = wave_reduce16_swap(fv);
         if ((threadIdx.x & 3) == 0 && (threadIdx.x & 63) < 48) fin[threadIdx.x >> 6][(threadIdx.x & 63) >> 2] = tot;
     }
     __syncthreads();
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(SCB_BLOCK) void sample_chamfer_bwd_kernel(
         float v16[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) v16[i] = i < 12 ? acc[i] : 0.0f;
-        const float tot = wave_reduce16(v16);                           // lane L: wave total of value L >> 2
+        const float tot = wave_reduce16_swap(v16);                           // lane L: wave total of value L >> 2
         if ((lane & 3) == 0 && lane < 48) red[wave][lane >> 2] = tot;
     }
     __syncthreads();

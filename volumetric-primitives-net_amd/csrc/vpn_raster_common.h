@@ -238,6 +238,52 @@ __device__ inline void make_record_put(const Camera& C, const Pose& P, const flo
 }
 
 // Transposing butterfly: 16 per-lane values -> lane L holds the wave total of value (L >> 2).
+// wave_reduce16_swap: same pairs and the same additions as the shuffle form below (a level sends half of the values to the partner lane
+// and keeps the other half: bit-identical sums), but without the LDS crossbar: gfx950's half exchanges
+// (v_permlane32_swap / v_permlane16_swap: ONE instruction does the send and the receive of a pair of values) for the
+// partners 32 and 16 lanes away, DPP row rotations and quad permutations inside the 16-lane rows.  The shuffle form was 17
+// ds_bpermute + 30 selects per call, six LDS round trips deep, once per (tile, primitive) in the tile kernels.
+// Two forms: the tile kernels are bound by VALU issue, where the shuffles' LDS-pipe instructions are free and the swaps are
+// not (raster 45.0 us with shuffles, 46.8 with swaps); the fused backward is a chain of latencies, where it is the other way
+// round (17.4 -> 16.7 us).
+__device__ inline float wave_reduce16_swap(float v[16]) {
+    const int lane = threadIdx.x & 63;
+    auto swap32 = [](float& a, float& b) {     // lanes 32-63 of a <-> lanes 0-31 of b
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+        a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
+    };
+    auto swap16 = [](float& a, float& b) {     // odd 16-lane rows of a <-> even rows of b
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+        a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
+    };
+#define VPN_DPP(x, ctrl, bank) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, 0xf, bank, false))
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { float a = v[i], b = v[i + 8]; swap32(a, b); v[i] = a + b; }     // lower half: values 0-7, upper: 8-15
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { float a = v[i], b = v[i + 4]; swap16(a, b); v[i] = a + b; }     // even rows: i, odd rows: i + 4
+    {   // partner 8 lanes away inside the row (a rotation by 8 is its own inverse)
+        const bool hi = lane & 8;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float a = v[i] + VPN_DPP(v[i], 0x128, 0xf), b = v[i + 2] + VPN_DPP(v[i + 2], 0x128, 0xf);
+            v[i] = hi ? b : a;
+        }
+    }
+    float r;
+    {   // partner 4 lanes away: a rotation by 4 for one half of the 4-lane banks, by 12 for the other
+        auto x4 = [](float x) {
+            int t = __builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x124, 0xf, 0xa, false);
+            t = __builtin_amdgcn_update_dpp(t, __float_as_int(x), 0x12c, 0xf, 0x5, false);
+            return __int_as_float(t);
+        };
+        const float a = v[0] + x4(v[0]), b = v[1] + x4(v[1]);
+        r = (lane & 4) ? b : a;
+    }
+    r += VPN_DPP(r, 0x4e, 0xf);                // quad_perm [2,3,0,1]: partner 2 lanes away
+    r += VPN_DPP(r, 0xb1, 0xf);                // quad_perm [1,0,3,2]: partner 1 lane away
+#undef VPN_DPP
+    return r;
+}
 __device__ inline float wave_reduce16(float v[16]) {
     const int lane = threadIdx.x & 63;
     {
