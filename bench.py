@@ -180,6 +180,109 @@ def raster_only(vpn_amd, _lib, dev, B, K, H, steps, warmup, windows, pmc_key, us
             'pmc_source': os.path.relpath(PMC_FILE, ROOT) if pmc else None}
 
 
+def c5_inputs(vpn_amd, B, K, n, H, dev):
+    """Synthetic batch of the reference's training step (train.py:227-262) at a given shape: packed primitive parameters,
+    view-centred GT points (M = K*n: the only shape emd_module.py:36-39 admits), their object-centred counterpart
+    (dataset.py:165 stores both; here canonical = view_to_obj_points(view_center)), the dataset's camera values, and a GT
+    silhouette rendered from a second primitive set."""
+    M = K * n
+    params, gt_view = synth_inputs(B, K, M, 1234, dev)
+    g = torch.Generator().manual_seed(77)
+    dists = (1.0 + 0.5 * torch.rand(B, generator=g)).to(dev)          # rendering_metadata.txt: distance ratio (dataset.py:145-165)
+    elevs = (20.0 + 20.0 * torch.rand(B, generator=g)).to(dev)        # degrees
+    azims = (360.0 * torch.rand(B, generator=g)).to(dev)
+    angles = torch.zeros(B, device=dev)                               # AUGMENT_3D['rotate'] = False (config.py:47)
+    kinds = vpn_amd.kinds_tensor([vpn_amd.SPHERE] * K, dev)           # config.py:33-34: all spheres
+    with torch.no_grad():
+        gt_canon = vpn_amd.view_to_obj_points(gt_view, dists, elevs, azims, angles).contiguous()
+        p2, _ = synth_inputs(B, K, 8, 4321, dev)
+        cam1 = torch.tensor([[1.0, 0.0, 0.0]], device=dev).expand(B, 3).contiguous()       # train.py:172-174
+        a2, _ = vpn_amd.RasterFunction.apply(p2, kinds, cam1, H, H, vpn_amd.config.RASTER_SIGMA, vpn_amd.config.RASTER_GAMMA,
+                                             vpn_amd.config.RASTER_Z_FAR)
+    gt_sil = (a2 > 0.5).float().reshape(B, 1, H, H)
+    return params, kinds, gt_view, gt_canon, gt_sil, dists, elevs, azims, angles
+
+
+C5_WEIGHTS = (1.0, 0.0, 1.0, 0.1, 1.0)      # L_VIEW_CD, L_CAN_CD, L_SIL, L_VP_DIV, L_EMD: config.py:13-17 with the render ON
+# (config.py:15 has L_SIL = 0.0, for which train.py:167 returns before rendering; BASELINE config C5 names 256x256, so the
+# silhouette term is evaluated here with weight 1; L_CAN_CD = 0 is the reference's value: that Chamfer is computed and weighted 0)
+
+
+def train_step_block(vpn_amd, _lib, dev, B, K, n, H, steps, warmup, windows, form, with_oracle):
+    """The step train.py:243-262 runs: sampler -> view-centred Chamfer + object-centred Chamfer through view_to_obj_points
+    + silhouette loss + VP-diversity loss + EMD (eps 0.005, 50 rounds) -> weighted total -> backward to d/d(v,q,t).
+    form 'modules': the drop-in module surface called the way train.py calls it (one autograd node per reference call);
+    form 'fused': one autograd node, no ATen kernel inside the step (TrainStepLossFunction)."""
+    params, kinds, gt_view, gt_canon, gt_sil, dists, elevs, azims, angles = c5_inputs(vpn_amd, B, K, n, H, dev)
+    params.requires_grad_(True)
+    w = C5_WEIGHTS
+    ones, zeros = torch.ones(B, device=dev), torch.zeros(B, device=dev)
+    cd, sil_f, div_f, emd_f = (vpn_amd.ChamferDistanceLoss(), vpn_amd.SilhouetteLoss(), vpn_amd.VPDiverseLoss(vp_num=K),
+                               vpn_amd.EarthMoverDistanceLoss())
+    one = torch.ones((), device=dev)
+    seed_buf = torch.full((1,), 1234, dtype=torch.int64, device=dev)
+
+    def step_modules(_i=0):
+        params.grad = None
+        volumes, rotates, translates = vpn_amd.split_primitives(params)
+        pred = vpn_amd.Sampling.sample_primitives(params, kinds, n, seed=1234)                      # train.py:243
+        view_cd = cd(pred, gt_view) * w[0]                                                           # :160
+        obj_cd = cd(vpn_amd.view_to_obj_points(pred, dists, elevs, azims, angles), gt_canon) * w[1]  # :158-161
+        sil = sil_f(vpn_amd.PrimitivePack(params, kinds), gt_sil, ones, zeros, zeros) * w[2]         # :169-176
+        div = div_f(translates, gt_view) * w[3]                                                      # :185
+        dist, _ = emd_f(pred, gt_view, 0.005, 50)                                                    # :193
+        emd = torch.sqrt(dist).mean() * w[4]                                                         # :195
+        total = view_cd + obj_cd + sil + div + emd                                                   # :260
+        total.backward()
+        return torch.stack([view_cd, obj_cd, sil, div, emd, total]).detach()
+
+    def step_fused(_i=0):
+        params.grad = None
+        out = vpn_amd.TrainStepLossFunction.apply(params, kinds, gt_view, gt_canon, gt_sil, dists, elevs, azims, angles, n,
+                                                  seed_buf, 0, H, H, w, 0.005, 50, True)
+        out[5].backward(one)
+        return out
+
+    compute = step_modules if form == 'modules' else step_fused
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for i in range(3):
+            compute(i)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    res = {'form': form}
+    try:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            g_out = compute(0)
+        run = lambda i=0: graph.replay()
+        res['launch'] = 'hip-graph replay'
+    except Exception as e:        # noqa: BLE001 -- e.g. a cooperative launch that cannot be captured
+        torch.cuda.synchronize()
+        res['launch'] = 'eager (graph capture failed: %s: %s)' % (type(e).__name__, str(e)[:200])
+        run = compute
+        g_out = None
+    for _ in range(warmup):
+        run()
+    torch.cuda.synchronize()
+    ev = event_windows(run, steps, windows)
+    ksteps = 10
+    with _lib.KernelProfile() as kp:
+        for i in range(ksteps):
+            out = compute(i)
+    kern = kp.summary()
+    ms = ev['median']
+    res.update({'workload': 'train.py:243-262 step: B=%d, K=%d spheres, n=%d pts/prim (N=M=%d), %dx%d, weights (view_cd, can_cd, sil, '
+                            'vp_div, emd) = %s, EMD eps=0.005 iters=50' % (B, K, n, K * n, H, H, (w,)),
+                'ms_per_step': round(ms, 5), 'images_per_s': round(B / ms * 1e3, 1), 'timing': ev,
+                'losses': dict(zip(('view_cd', 'obj_cd', 'sil', 'vp_div', 'emd', 'total'), [float(x) for x in out.cpu()])),
+                'finite_grad': bool(torch.isfinite(params.grad).all()),
+                'kernel_us': {k: {'calls_per_step': round(v[0] / ksteps, 2), 'avg_us': round(v[1] * 1e3, 2)} for k, v in kern.items()},
+                'kernel_us_sum_per_step': round(sum(v[0] * v[1] for v in kern.values()) / ksteps * 1e3, 1)})
+    return res, (params, kinds, gt_view, gt_canon, gt_sil, dists, elevs, azims, angles)
+
+
 def free_port():
     import socket
     with socket.socket() as sk:
@@ -208,7 +311,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
-    ap.add_argument('--workload', choices=['c3', 'c2'], default='c3')
+    ap.add_argument('--workload', choices=['c3', 'c2', 'c5'], default='c3')
     ap.add_argument('--batch', type=int, default=None, help='samples per GPU (default 64 for c3, 32 for c2)')
     ap.add_argument('--global-batch', type=int, default=None,
                     help='fixed GLOBAL batch split evenly over the ranks (C4: 256): strong scaling')
@@ -223,6 +326,7 @@ def main():
                     help='the one gradient exchange per step when N>1 (north_star: RCCL all-reduce)')
     ap.add_argument('--windows', type=int, default=5, help='hipEvent windows of --steps replays each (median reported)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--c5-form', choices=['modules', 'fused', 'both'], default='both')
     ap.add_argument('--no-c2', action='store_true', help='skip the C2 raster-only measurement of the default run')
     ap.add_argument('--no-extras', action='store_true', help='skip C2, EMD and the CPU baseline (profiling runs)')
     ap.add_argument('--no-graph', action='store_true', help='launch every step eagerly instead of replaying a HIP graph')
@@ -280,6 +384,20 @@ def main():
                    'roofline': dict(dom.get('hbm', {}), kernel=domk, executed_work=dom.get('executed_work')),
                    'c2': res}
             print(json.dumps(out), flush=True)
+        if multi:
+            dist.destroy_process_group()
+        return
+
+    if args.workload == 'c5':
+        forms = [args.c5_form] if args.c5_form != 'both' else ['modules', 'fused']
+        res = {f: train_step_block(vpn_amd, _lib, dev, args.batch or 64, args.prims or 64, args.points if args.points != 256 else 32,
+                                   args.size or 256, args.steps, args.warmup, args.windows, f, False)[0] for f in forms}
+        if rank == 0:
+            best = min(res.values(), key=lambda r: r['ms_per_step'])
+            print(json.dumps({'metric': 'train.py step (5 losses) images/sec (BASELINE config C5, one GPU)', 'value': best['images_per_s'],
+                              'unit': 'images/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
+                              'ms_per_step': best['ms_per_step'], 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+                              'dtype': 'f32', 'data': 'synthetic', 'config': {'workload': best['workload']}, 'c5': res}), flush=True)
         if multi:
             dist.destroy_process_group()
         return

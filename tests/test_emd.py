@@ -129,9 +129,11 @@ def test_emd_equals_oracle(emd, B, n, eps, iters):
 
 @pytest.mark.gpu
 def test_emd_both_kernels_agree(emd):
-    """n <= 2048 runs the replicated-state kernel with the grid-pruned Bid scan, VPN_EMD_NOGRID=1 the same rounds with the
-    full scan (what 2048 < n <= 4096 uses), VPN_EMD_STREAMING=1 the streaming kernel (state in memory, two barriers) that
-    larger clouds use.  All three must equal the oracle bit for bit -- and therefore each other -- for every group size."""
+    """n <= 2048 runs the pruned auction with static bidder ownership and the granule exchange (round 4), VPN_EMD_GRID1=1
+    round 3's pruned kernel (two box scans per bid, atomic max + counter barrier in memory), VPN_EMD_NOGRID=1 the same
+    rounds with the full scan (what 2048 < n <= 4096 uses), VPN_EMD_STREAMING=1 the streaming kernel (state in memory, two
+    barriers) that larger clouds use.  All four must equal the oracle bit for bit -- and therefore each other -- for every
+    group size."""
     import os
     from vpn_amd.ops import EmdFunction
     x1, x2 = _clouds(5, 700, 21)
@@ -142,15 +144,15 @@ def test_emd_both_kernels_agree(emd):
     cases = [(x1, x2, 0.005, 40), (y1, y2, 0.005, 40), (y2, y1, 0.01, 25), (x1[:, :64], x2[:, :64], 0.005, 30)]
     refs = [O.emd_auction(a, b, e, it) for a, b, e, it in cases]
     try:
-        for streaming, nogrid in (('0', '0'), ('0', '1'), ('1', '0')):       # pruned / replicated-state / streaming kernel
-            os.environ['VPN_EMD_STREAMING'], os.environ['VPN_EMD_NOGRID'] = streaming, nogrid
+        for streaming, nogrid, grid1 in (('0', '0', '0'), ('0', '0', '1'), ('0', '1', '0'), ('1', '0', '0')):
+            os.environ['VPN_EMD_STREAMING'], os.environ['VPN_EMD_NOGRID'], os.environ['VPN_EMD_GRID1'] = streaming, nogrid, grid1
             for (a, b, e, it), (rd, ra) in zip(cases, refs):
-                for G in (None, 1, 2, 8):
+                for G in (None, 1, 2, 4, 8, 16):
                     dist, assign = EmdFunction.apply(a.to(DEV), b.to(DEV), e, it, G)
-                    assert torch.equal(assign.cpu(), ra) and torch.equal(dist.cpu(), rd), (streaming, nogrid, G, a.shape)
+                    assert torch.equal(assign.cpu(), ra) and torch.equal(dist.cpu(), rd), (streaming, nogrid, grid1, G, a.shape)
     finally:
-        os.environ.pop('VPN_EMD_STREAMING', None)
-        os.environ.pop('VPN_EMD_NOGRID', None)
+        for k in ('VPN_EMD_STREAMING', 'VPN_EMD_NOGRID', 'VPN_EMD_GRID1'):
+            os.environ.pop(k, None)
 
 
 @pytest.mark.gpu

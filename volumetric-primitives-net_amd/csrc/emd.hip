@@ -681,6 +681,325 @@ __global__ __launch_bounds__(EMD_THREADS) void emd_auction_grid_kernel(const flo
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Round 4: the pruned auction again, rebuilt around what a late round IS -- ~100 bidders per sample, i.e. a chain of
+// latencies (emd_auction_grid_kernel above: ~19 us per round, of which ~6 are five dependent L2 round trips of the
+// atomic-max / counter / read-back exchange and the rest two box scans per bidder at ~1.5-2 us each).
+//   * TARGET IDS ARE SORTED POSITIONS.  The counting sort is made deterministic (rank inside a cell = rank of the
+//     original index), so every workgroup of a sample holds the same order; owner table, per-target maxima, prices and
+//     the bids all speak sorted positions, the original index only breaks ties and is restored in the output.
+//   * STATIC OWNERSHIP: point i always bids from workgroup i mod G, so its coordinates and the BOX IT SCANNED LAST TIME
+//     live in that workgroup's LDS.  Prices only rise, hence a bidder's second-best value only falls and the radius
+//     R = 3 - second that bounds the targets that matter only grows: the box of the last bid is a subset of what this
+//     bid needs -- it is scanned FIRST, and almost always it is also enough (one box scan per bid instead of two).
+//   * A box is scanned row by row of cells, L = 64 / rows lanes per row, straight from the cell table: no flattened
+//     per-wave list in LDS (28 KB), no prefix sum over rows, no LDS round trip before the first target is evaluated.
+//   * EXCHANGE BY TAGGED GRANULES (the hand-off form MI355X_MICROARCH.md prices at ~1 us: one naturally aligned 8-byte
+//     {tag | target | increment} written by ONE sc1 store, polled with sc1 loads): every workgroup knows the round's
+//     bidder list, so it knows which entries to wait for; no counter, no barrier, no atomics in memory.  GetMax
+//     (emd_cuda.cu:181-194) is an LDS 64-bit atomic max per target on every workgroup's own copy.
+//   * 16-bit state: 32 n + 18 n / G bytes of LDS (75 KB at n = 2048, G >= 4): two workgroups per CU, G = 8 at B = 64.
+// Same arithmetic, same tie rules: bit-equal to the oracle and to the other three kernels for every group size.
+constexpr unsigned EMD_BOX_NONE = 0xffffffffu;
+
+__device__ inline int emd_wave_scan_incl(int v) {          // inclusive prefix sum over the 64 lanes, on the VALU
+#define EMD_SSTEP(ctrl, rmask) v += __builtin_amdgcn_update_dpp(0, v, ctrl, rmask, 0xf, false)
+    EMD_SSTEP(0x111, 0xf); EMD_SSTEP(0x112, 0xf); EMD_SSTEP(0x114, 0xf); EMD_SSTEP(0x118, 0xf);
+    EMD_SSTEP(0x142, 0xa); EMD_SSTEP(0x143, 0xc);
+#undef EMD_SSTEP
+    return v;
+}
+
+struct EmdTables {
+    const float *tx, *ty, *tz, *tp;
+    const unsigned short* orig;
+    const int* cell_start;
+};
+
+// floor(a / d) for 0 <= a < 64, 1 <= d <= 64 (d wave-uniform): one multiply and a shift
+__device__ inline int emd_div64(int a, int d) { return (a * ((65536 + d - 1) / d)) >> 16; }
+
+// all targets of the cells [c0, c1] (inclusive) -> the wave's merged result; idx is a SORTED position
+__device__ inline Bid3 emd_scan_rows(const int c0[3], const int c1[3], float x1, float y1, float z1, const EmdTables& T) {
+    const int lane = threadIdx.x & 63;
+    const int ny = c1[1] - c0[1] + 1, nz = c1[2] - c0[2] + 1, nrows = ny * nz;      // <= 64
+    const int L = 64 / nrows;                                    // lanes per (y, z) row of cells
+    const int row = emd_div64(lane, L), sub = lane - row * L;
+    int k = 0, e = 0;
+    if (row < nrows) {
+        const int rz = emd_div64(row, ny), ry = row - rz * ny;
+        const int base = ((c0[2] + rz) * EG + c0[1] + ry) * EG;
+        k = T.cell_start[base + c0[0]] + sub;
+        e = T.cell_start[base + c1[0] + 1];
+    }
+    Bid3 r{-1e9f, -1e9f, -1};                                    // :116
+    for (; k < e; k += L) {
+        const float dx = T.tx[k] - x1, dy = T.ty[k] - y1, dz = T.tz[k] - z1;                            // :139-141
+        const float d = (3.0f - emd_sqrt(((dx * dx) + (dy * dy)) + (dz * dz))) - T.tp[k];              // :143
+        bool take = d > r.best;                                                                     // :144-151
+        if (__builtin_amdgcn_ballot_w64(d == r.best && r.idx >= 0))    // equal values: the lower ORIGINAL index wins (rare)
+            take = take || (d == r.best && r.idx >= 0 && T.orig[k] < T.orig[r.idx]);
+        r.idx = take ? k : r.idx;
+        r.better = __builtin_amdgcn_fmed3f(r.best, d, r.better);
+        r.best = fmaxf(r.best, d);
+    }
+    // merge of the 64 lanes (disjoint target sets): largest value, lowest ORIGINAL index among its holders, second
+    // largest counting duplicates
+    Bid3 o;
+    o.best = emd_wave_max(r.best);
+    const int key = (r.idx >= 0 && r.best == o.best) ? (((int)T.orig[r.idx] << 12) | r.idx) : 0x7fffffff;
+    const int kmin = emd_wave_min_i(key);
+    o.idx = kmin == 0x7fffffff ? -1 : (kmin & 0xfff);
+    o.better = emd_wave_max((r.idx >= 0 && r.idx == o.idx) ? r.better : r.best);
+    return o;
+}
+
+__device__ inline unsigned emd_box_pack(const int c0[3], const int c1[3]) {
+    return (unsigned)(c0[0] | (c0[1] << 3) | (c0[2] << 6) | (c1[0] << 9) | (c1[1] << 12) | (c1[2] << 15));
+}
+
+__global__ __launch_bounds__(EMD_THREADS, 8) void emd_auction_grid2_kernel(const float* __restrict__ xyz1,
+                                                                        const float* __restrict__ xyz2, int B, int n,
+                                                                        int npad, int G, int lgG, float eps, int iters,
+                                                                        float* __restrict__ dist, int32_t* assignment,
+                                                                        float* wsf, unsigned* counters) {
+    extern __shared__ __attribute__((aligned(16))) float emd_lds[];
+    const int nown = npad >> lgG;                                // points this workgroup bids for (local index i >> lgG)
+    float* tx = emd_lds; float* ty = tx + npad; float* tz = ty + npad; float* tp = tz + npad;      // SORTED by cell, then index
+    unsigned long long* top_l = reinterpret_cast<unsigned long long*>(tp + npad);                  // per target: (increment, ~bidder) max
+    float* ox = reinterpret_cast<float*>(top_l + npad); float* oy = ox + nown; float* oz = oy + nown;   // own bidders
+    unsigned* box = reinterpret_cast<unsigned*>(oz + nown);                                        // the cells each own bidder scanned last
+    unsigned short* orig = reinterpret_cast<unsigned short*>(box + nown);                          // sorted position -> target
+    short* assign_l = reinterpret_cast<short*>(orig + npad);                                       // point -> sorted position | -1
+    short* inv_l = assign_l + npad;                                                                // sorted position -> point | -1
+    unsigned short* ulist = reinterpret_cast<unsigned short*>(inv_l + npad);                       // unassigned points, ascending
+    unsigned short* ownu = ulist + npad;                                                           // list positions of the own ones
+    __shared__ int cell_start[ENC + 8];
+    __shared__ float red[EMD_WAVES][6];
+    __shared__ EmdGrid grid;
+    __shared__ unsigned wtot[EMD_WAVES];
+    __shared__ int gave_up;
+    if (threadIdx.x == 0) gave_up = 0;
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int b = (q / G) * 8 + xcd, g = q % G;
+    if (b >= B) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* p1 = xyz1 + (size_t)b * n * 3;
+    const float* p2 = xyz2 + (size_t)b * n * 3;
+    // workspace of the sample: two buffers (round parity) of n 8-byte bid granules
+    unsigned long long* bids = reinterpret_cast<unsigned long long*>(wsf + (size_t)b * EMD_WS_PLANES * n);
+    unsigned* counter = counters + 2 * b;
+    unsigned passed = 0;
+    int* cursor = reinterpret_cast<int*>(top_l);                 // init only: per-cell counters (top_l is zeroed afterwards)
+
+    // ---- the grid: bounding box of the targets, counting sort by cell, rank inside a cell by original index
+    {
+        float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+        for (int j = tid; j < n; j += EMD_THREADS)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { const float c = p2[(size_t)j * 3 + a]; lo[a] = fminf(lo[a], c); hi[a] = fmaxf(hi[a], c); }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], o, 64)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o, 64)); }
+            if (lane == 0) { red[wave][a] = lo[a]; red[wave][3 + a] = hi[a]; }
+        }
+        for (int c = tid; c < ENC; c += EMD_THREADS) cursor[c] = 0;
+        __syncthreads();
+        if (tid < 3) {
+            float l = red[0][tid], h = red[0][3 + tid];
+            for (int w = 1; w < EMD_WAVES; ++w) { l = fminf(l, red[w][tid]); h = fmaxf(h, red[w][3 + tid]); }
+            grid.mn[tid] = l;
+            grid.sc[tid] = h > l ? (float)EG / (h - l) : 0.0f;      // a flat (or non-finite) extent: one layer of cells
+        }
+        __syncthreads();
+        for (int j = tid; j < n; j += EMD_THREADS) {
+            const int c = (emd_cell1(p2[(size_t)j * 3 + 2], grid.mn[2], grid.sc[2]) * EG + emd_cell1(p2[(size_t)j * 3 + 1], grid.mn[1], grid.sc[1])) * EG
+                          + emd_cell1(p2[(size_t)j * 3], grid.mn[0], grid.sc[0]);
+            atomicAdd(&cursor[c], 1);
+        }
+        __syncthreads();
+        int cnt = 0, incl = 0;
+        if (tid < ENC) { cnt = cursor[tid]; incl = cnt; }
+        incl = emd_wave_scan_incl(incl);
+        if (lane == 63) wtot[wave] = (unsigned)incl;
+        __syncthreads();
+        if (tid < ENC) {
+            int before = 0;
+            for (int w = 0; w < wave; ++w) before += (int)wtot[w];
+            cell_start[tid] = before + incl - cnt;
+            cursor[tid] = before + incl - cnt;
+        }
+        if (tid == 0) cell_start[ENC] = n;
+        __syncthreads();
+        for (int j = tid; j < n; j += EMD_THREADS) {              // members of every cell, in whatever order the atomics give
+            const int c = (emd_cell1(p2[(size_t)j * 3 + 2], grid.mn[2], grid.sc[2]) * EG + emd_cell1(p2[(size_t)j * 3 + 1], grid.mn[1], grid.sc[1])) * EG
+                          + emd_cell1(p2[(size_t)j * 3], grid.mn[0], grid.sc[0]);
+            ulist[atomicAdd(&cursor[c], 1)] = (unsigned short)j;
+        }
+        __syncthreads();
+        for (int j = tid; j < n; j += EMD_THREADS) {              // ... then by index: the same order in every workgroup
+            const float x = p2[(size_t)j * 3], y = p2[(size_t)j * 3 + 1], z = p2[(size_t)j * 3 + 2];
+            const int c = (emd_cell1(z, grid.mn[2], grid.sc[2]) * EG + emd_cell1(y, grid.mn[1], grid.sc[1])) * EG + emd_cell1(x, grid.mn[0], grid.sc[0]);
+            const int s = cell_start[c], e = cell_start[c + 1];
+            int rank = 0;
+            for (int k = s; k < e; ++k) rank += (int)ulist[k] < j;
+            const int pos = s + rank;
+            tx[pos] = x; ty[pos] = y; tz[pos] = z; tp[pos] = 0.0f; orig[pos] = (unsigned short)j;
+        }
+        for (int j = n + tid; j < npad; j += EMD_THREADS) { tx[j] = 0.0f; ty[j] = 0.0f; tz[j] = 0.0f; tp[j] = __builtin_inff(); orig[j] = 0xffff; }
+        for (int l = tid; l < nown; l += EMD_THREADS) {
+            const int i = min((l << lgG) + g, n - 1);
+            ox[l] = p1[(size_t)i * 3]; oy[l] = p1[(size_t)i * 3 + 1]; oz[l] = p1[(size_t)i * 3 + 2];
+            box[l] = EMD_BOX_NONE;
+        }
+        __syncthreads();                                         // cursor (aliases top_l) and the unsorted member lists are done with
+        for (int j = tid; j < npad; j += EMD_THREADS) { assign_l[j] = -1; inv_l[j] = -1; top_l[j] = 0ull; }
+    }
+    for (int j = g * EMD_THREADS + tid; j < 2 * n; j += G * EMD_THREADS) emd_st(bids + j, 0ull);
+    bool ok = emd_group_sync(counter, passed, G, &gave_up);       // the launch's only counter barrier: granule tags start at 0
+    const EmdTables T{tx, ty, tz, tp, orig, cell_start};
+
+    for (int it = 0; ok && it < iters; ++it) {
+        const bool last = it == iters - 1;
+        unsigned long long* bid_w = bids + (size_t)(it & 1) * n;
+        const unsigned tag = (unsigned)(it % 65535) + 1u;        // never 0, differs from the tag two rounds ago
+        // ---- unassigned points in ascending order (every copy builds the same list) and the own ones among them:
+        //      thread t looks at points t and t + 1024 (same residue mod G); four 8-bit counters in one DPP scan
+        const bool mine = (tid & (G - 1)) == g;
+        const int c0 = (tid < n && assign_l[tid] == -1) ? 1 : 0;
+        const int c1 = (tid + EMD_THREADS < n && assign_l[tid + EMD_THREADS] == -1) ? 1 : 0;
+        const int pk = c0 | (c1 << 8) | ((mine ? c0 : 0) << 16) | ((mine ? c1 : 0) << 24);
+        const int sc = emd_wave_scan_incl(pk);
+        if (lane == 63) wtot[wave] = (unsigned)sc;
+        __syncthreads();
+        unsigned befA = 0, totA = 0, befB = 0, totB = 0;         // 16-bit fields: (c0 | own c0 << 16), (c1 | own c1 << 16)
+#pragma unroll
+        for (int w = 0; w < EMD_WAVES; ++w) {
+            const unsigned t = wtot[w], a = t & 0x00ff00ffu, bb = (t >> 8) & 0x00ff00ffu;
+            totA += a; totB += bb;
+            befA += w < wave ? a : 0u; befB += w < wave ? bb : 0u;
+        }
+        const int U = (int)((totA & 0xffffu) + (totB & 0xffffu));
+        const int Uown = (int)((totA >> 16) + (totB >> 16));
+        if (U == 0) break;                                       // every copy agrees
+        {
+            const unsigned ex = (unsigned)(sc - pk);             // exclusive prefix inside the wave
+            const int u0 = (int)((befA & 0xffffu) + (ex & 0xffu));
+            const int u1 = (int)((totA & 0xffffu) + (befB & 0xffffu) + ((ex >> 8) & 0xffu));
+            if (c0) ulist[u0] = (unsigned short)tid;
+            if (c1) ulist[u1] = (unsigned short)(tid + EMD_THREADS);
+            if (mine) {
+                if (c0) ownu[(befA >> 16) + ((ex >> 16) & 0xffu)] = (unsigned short)u0;
+                if (c1) ownu[(totA >> 16) + (befB >> 16) + ((ex >> 24) & 0xffu)] = (unsigned short)u1;
+            }
+        }
+        __syncthreads();
+
+        // ---- Bid (:95-179), pruned: wave w takes own bidders w, w + 16, ...
+        for (int kb = wave; kb < Uown; kb += EMD_WAVES) {
+            const int u = ownu[kb], i = ulist[u], l = i >> lgG;
+            const float x1 = ox[l], y1 = oy[l], z1 = oz[l];
+            const float xyz[3] = {x1, y1, z1};
+            const unsigned bx = box[l];
+            int a0[3], a1[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const int c = emd_cell1(xyz[a], grid.mn[a], grid.sc[a]);
+                a0[a] = bx == EMD_BOX_NONE ? max(c - 1, 0) : (int)((bx >> (3 * a)) & 7u);
+                a1[a] = bx == EMD_BOX_NONE ? min(c + 1, EG - 1) : (int)((bx >> (9 + 3 * a)) & 7u);
+                a0[a] = __builtin_amdgcn_readfirstlane(a0[a]); a1[a] = __builtin_amdgcn_readfirstlane(a1[a]);
+            }
+            Bid3 r = emd_scan_rows(a0, a1, x1, y1, z1, T);
+            // every target outside [x - R, x + R]^3 is strictly below the runner-up found so far
+            const bool two = r.idx >= 0 && r.better > -1e8f;
+            const float R = two ? (3.0f - r.better) + 1.0e-5f : __builtin_inff();
+            int b0[3], b1[3];
+            bool inside = true;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                b0[a] = emd_cell1(xyz[a] - R, grid.mn[a], grid.sc[a]);
+                b1[a] = emd_cell1(xyz[a] + R, grid.mn[a], grid.sc[a]);
+                if (!(R < 1e30f)) { b0[a] = 0; b1[a] = EG - 1; }                // also a NaN radius: everything
+                b0[a] = __builtin_amdgcn_readfirstlane(b0[a]); b1[a] = __builtin_amdgcn_readfirstlane(b1[a]);
+                inside = inside && b0[a] >= a0[a] && b1[a] <= a1[a];
+            }
+            if (!inside) {
+#pragma unroll
+                for (int a = 0; a < 3; ++a) { a0[a] = min(b0[a], a0[a]); a1[a] = max(b1[a], a1[a]); }
+                r = emd_scan_rows(a0, a1, x1, y1, z1, T);
+            }
+            if (lane == 0) {
+                box[l] = emd_box_pack(a0, a1);
+                const float v = (r.best - r.better) + eps;                                  // :175-176
+                const unsigned t = (unsigned)min(max(r.idx, 0), n - 1);
+                emd_st(bid_w + u, ((unsigned long long)((tag << 16) | t) << 32) | (unsigned)__float_as_int(v));
+            }
+        }
+
+        // ---- gather the round's granules (one lane per bidder), GetMax (:181-194) on this copy
+        int gi[2], gt[2]; unsigned long long gk[2]; float gv[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int u = tid + h * EMD_THREADS;
+            gi[h] = -1; gt[h] = 0; gk[h] = 0ull; gv[h] = 0.0f;
+            if (u < U) {
+                unsigned long long e = emd_ld(bid_w + u);
+                unsigned spins = 0;
+                while ((unsigned)(e >> 48) != tag) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > EMD_SPIN_LIMIT ||
+                        ((spins & 255u) == 0 && __hip_atomic_load(counter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                        __hip_atomic_store(counter + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // tell the others
+                        gave_up = 1;
+                        break;
+                    }
+                    e = emd_ld(bid_w + u);
+                }
+                gi[h] = ulist[u];
+                gt[h] = min((int)((e >> 32) & 0xffffu), n - 1);
+                gv[h] = __int_as_float((int)(unsigned)e);
+                gk[h] = ((e & 0xffffffffull) << 32) | (unsigned)(0x7fffffff - gi[h]);       // v >= 0: its bits order like the value
+                if (!last) atomicMax(&top_l[gt[h]], gk[h]);
+            }
+        }
+        __syncthreads();
+        if (gave_up) { ok = false; break; }
+        // ---- Assign (:196-215) of ALL bidders on this workgroup's copy
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (gi[h] < 0) continue;
+            const int i = gi[h], t = gt[h];
+            if (last) { assign_l[i] = (short)t; continue; }
+            if (top_l[t] != gk[h]) continue;
+            const int prev = inv_l[t];
+            if (prev != -1) assign_l[prev] = -1;
+            inv_l[t] = (short)i;
+            assign_l[i] = (short)t;
+            tp[t] = tp[t] + gv[h];                              // :211
+            top_l[t] = 0ull;                                    // :212 (losers read either their winner's key or 0: both != theirs)
+        }
+        __syncthreads();
+    }
+
+    if (!ok) {                                                  // a partner never delivered: no result for this sample
+        for (int l = tid; l < nown; l += EMD_THREADS) {
+            const int i = (l << lgG) + g;
+            if (i < n) { dist[(size_t)b * n + i] = __builtin_nanf(""); assignment[(size_t)b * n + i] = -1; }
+        }
+        return;
+    }
+    for (int l = tid; l < nown; l += EMD_THREADS) {               // CalcDist :217-226 + the assignment itself, own points
+        const int i = (l << lgG) + g;
+        if (i >= n) continue;
+        const int t = assign_l[i];
+        if (t < 0 || t >= n) { assignment[(size_t)b * n + i] = -1; dist[(size_t)b * n + i] = __builtin_nanf(""); continue; }
+        assignment[(size_t)b * n + i] = (int)orig[t];
+        const float dx = ox[l] - tx[t], dy = oy[l] - ty[t], dz = oz[l] - tz[t];
+        dist[(size_t)b * n + i] = ((dx * dx) + (dy * dy)) + (dz * dz);
+    }
+}
+
 // NmDistanceGradKernel :284-300: grad_xyz1 = (2 g) (x1 - x2[assignment]); xyz2 gets no gradient
 __global__ __launch_bounds__(256) void emd_bwd_kernel(const float* __restrict__ xyz1, const float* __restrict__ xyz2,
                                                       const float* __restrict__ grad_dist,
@@ -754,6 +1073,48 @@ extern "C" int vpn_emd_fwd(const float* xyz1, const float* xyz2, int B, int n, f
     unsigned* counters = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + emd_state_bytes(B, n));
     if (hipMemsetAsync(counters, 0, (size_t)2 * B * sizeof(unsigned), s) != hipSuccess) return (int)hipGetLastError();
     float* wsf = (float*)workspace;
+    if (n <= EMD_GRID_MAX && n >= 64 && !emd_force_streaming() && !emd_env_flag("VPN_EMD_NOGRID") && !emd_env_flag("VPN_EMD_GRID1")) {
+        // the training call (n = SAMPLE_NUM * VP_NUM = 2048): pruned scan, static ownership, granule exchange
+        const int npad = (n + 63) / 64 * 64;
+        const void* kern = reinterpret_cast<const void*>(emd_auction_grid2_kernel);
+        auto lds_of = [&](int G) { return (size_t)npad * 32 + (size_t)(npad / G) * 18; };
+        static size_t raised = 0;
+        if (lds_of(1) > raised) {
+            const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(1));
+            if (e != hipSuccess) return (int)e;
+            raised = lds_of(1);
+        }
+        // largest G (power of two, <= 16, <= max_group) whose whole grid is resident: workgroups per CU from the
+        // occupancy query of THIS kernel with THAT group size's LDS, times the CU count of the current device
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+        const int padded = (B + 7) / 8 * 8;
+        const int cap = max_group > 0 && max_group < EMD_MAX_GROUP ? max_group : EMD_MAX_GROUP;
+        int G = 1, lgG = 0;
+        for (int cand = EMD_MAX_GROUP, lg = 4; cand > 1; cand >>= 1, --lg) {
+            if (cand > cap || cand * EMD_WAVES * 4 > n || npad % cand != 0) continue;
+            int per_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, EMD_THREADS, lds_of(cand)) != hipSuccess || per_cu <= 0) continue;
+            if ((long long)padded * cand <= (long long)cus * per_cu) { G = cand; lgG = lg; break; }
+        }
+        const unsigned lds = (unsigned)lds_of(G);
+        const bool coop = G > 1 && !emd_env_flag("VPN_EMD_PLAIN_LAUNCH");
+        if (coop) {
+            void* args[] = {(void*)&xyz1, (void*)&xyz2, (void*)&B, (void*)&n, (void*)&npad, (void*)&G, (void*)&lgG, (void*)&eps, (void*)&iters,
+                            (void*)&dist, (void*)&assignment, (void*)&wsf, (void*)&counters};
+            vpn::prof_begin("emd_auction_grid2_kernel", s);
+            const hipError_t e = hipLaunchCooperativeKernel(kern, dim3(padded * G), dim3(EMD_THREADS), args, lds, s);
+            vpn::prof_end(s);
+            if (e == hipSuccess) return 0;
+            (void)hipGetLastError();
+            if (e != hipErrorCooperativeLaunchTooLarge && e != hipErrorNotSupported && e != hipErrorInvalidConfiguration) return (int)e;
+            G = 1; lgG = 0;
+        }
+        VPN_LAUNCH(emd_auction_grid2_kernel, dim3(padded * G), dim3(EMD_THREADS), (unsigned)lds_of(G), s, xyz1, xyz2, B, n, npad, G, lgG, eps,
+                   iters, dist, assignment, wsf, counters);
+        VPN_LAUNCH_CHECK();
+        return 0;
+    }
     if (n <= EMD_TILE && !emd_force_streaming()) {
         // one-tile problem (every training call): replicated state, one group barrier per round
         int npad = (n + 64 * EMD_UNROLL - 1) / (64 * EMD_UNROLL) * (64 * EMD_UNROLL);
