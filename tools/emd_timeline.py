@@ -1,0 +1,41 @@
+"""Per-round timeline of the auction kernel (library built with VPN_EXTRA_FLAGS=-DEMD_TRACE):
+    python tools/emd_timeline.py [uniform|step]
+for sample 0: per round the bidders, the team size, rows / targets evaluated, and where the round's time went (list build,
+bids, waiting for the other workgroups' granules, assign), slowest workgroup of the sample."""
+import ctypes, os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import vpn_amd, bench
+from vpn_amd import _lib
+dev = torch.device('cuda')
+mode = sys.argv[1] if len(sys.argv) > 1 else 'step'
+B, n = int(os.environ.get('B', 64)), 2048
+if mode == 'uniform':
+    g = torch.Generator().manual_seed(1)
+    x1 = torch.rand(B, n, 3, generator=g).to(dev); x2 = torch.rand(B, n, 3, generator=g).to(dev)
+else:
+    params, x2 = bench.synth_inputs(B, 64, n, 1234, dev)
+    x1 = vpn_amd.Sampling.sample_primitives(params, vpn_amd.kinds_tensor([0] * 64, dev), 32, seed=1234)
+L = _lib.lib()
+ws = torch.zeros(L.vpn_emd_workspace(B, n) // 4, dtype=torch.int32, device=dev)
+dist = torch.empty(B, n, device=dev); asg = torch.empty(B, n, dtype=torch.int32, device=dev)
+for _ in range(3):
+    _lib.call('vpn_emd_fwd', _lib.ptr(x1.contiguous()), _lib.ptr(x2.contiguous()), B, n, 0.005, 50, _lib.ptr(dist), _lib.ptr(asg), _lib.ptr(ws), int(os.environ.get('G', 0)), _lib.stream())
+torch.cuda.synchronize()
+w = ws.cpu().numpy().view('uint32')
+for b in (0, B // 2):
+    tr = w[b * 10 * n + 4 * n: b * 10 * n + 4 * n + 16 * 64 * 8].reshape(16, 64, 8).astype('int64')
+    G = int((tr[:, 0, 0] != 0).sum())
+    t_launch = tr[:G, 63, 7].min()
+    print('sample %d: G = %d; first round starts %.1f us after the kernel began; last round ends at %.1f us' % (b, G, (tr[:G, 0, 0].min() - t_launch) / 100.0, (tr[:G, :50, 4].max() - t_launch) / 100.0))
+    print(' it     U  Uown(max)  T  rows/bid evals/bid | list  bid(max) bid(min)  wait(min)  assign | round us')
+    for it in range(50):
+        r = tr[:G, it]
+        if r[0, 0] == 0: break
+        U = r[0, 5] & 0xffff; uown = (r[:, 5] >> 16)
+        T = 1
+        while T < int(os.environ.get('VPN_EMD_TMAX', 16)) and 2 * T * int(uown.max()) <= int(os.environ.get('VPN_EMD_TNUM', 512)): T *= 2
+        us = lambda a: a / 100.0
+        print(' %2d  %4d  %4d      %2d  %7.1f %8.1f | %4.1f  %6.1f  %6.1f   %6.1f   %5.1f | %6.1f' % (
+            it, U, uown.max(), T, r[:, 7].sum() / max(1, uown.sum()), r[:, 6].sum() / max(1, uown.sum()),
+            us((r[:, 1] - r[:, 0]).max()), us((r[:, 2] - r[:, 1]).max()), us((r[:, 2] - r[:, 1]).min()), us((r[:, 3] - r[:, 2]).min()),
+            us((r[:, 4] - r[:, 3]).max()), us(r[:, 4].max() - r[:, 0].min())))

@@ -682,25 +682,43 @@ __global__ __launch_bounds__(EMD_THREADS) void emd_auction_grid_kernel(const flo
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Round 4: the pruned auction again, rebuilt around what a late round IS -- ~100 bidders per sample, i.e. a chain of
-// latencies (emd_auction_grid_kernel above: ~19 us per round, of which ~6 are five dependent L2 round trips of the
-// atomic-max / counter / read-back exchange and the rest two box scans per bidder at ~1.5-2 us each).
-//   * TARGET IDS ARE SORTED POSITIONS.  The counting sort is made deterministic (rank inside a cell = rank of the
-//     original index), so every workgroup of a sample holds the same order; owner table, per-target maxima, prices and
-//     the bids all speak sorted positions, the original index only breaks ties and is restored in the output.
-//   * STATIC OWNERSHIP: point i always bids from workgroup i mod G, so its coordinates and the BOX IT SCANNED LAST TIME
-//     live in that workgroup's LDS.  Prices only rise, hence a bidder's second-best value only falls and the radius
-//     R = 3 - second that bounds the targets that matter only grows: the box of the last bid is a subset of what this
-//     bid needs -- it is scanned FIRST, and almost always it is also enough (one box scan per bid instead of two).
-//   * A box is scanned row by row of cells, L = 64 / rows lanes per row, straight from the cell table: no flattened
-//     per-wave list in LDS (28 KB), no prefix sum over rows, no LDS round trip before the first target is evaluated.
+// Round 4: the pruned auction again, rebuilt around two measurements.  (i) A late round of an easy auction (uniform
+// clouds) is ~100 bidders per sample: a chain of latencies -- in emd_auction_grid_kernel ~19 us per round, ~6 of them five
+// dependent L2 round trips of the atomic-max / counter / read-back exchange.  (ii) The auction the training step really
+// runs (points on K small primitives against a cloud that fills the cube, train.py:193 early in training) keeps 500-1500
+// bidders per round and their radius grows to 2-3 cells: there that kernel is bound by VALU issue -- ~1000 wave-instructions
+// per bidder, of which ~80 targets (the ones inside the radius) out of ~300 scanned (the cell box) matter.
+//   * TARGET IDS ARE SORTED POSITIONS.  The counting sort is deterministic (rank inside a cell = rank of the original
+//     index): every workgroup of a sample holds the same order; owner table, per-target maxima, prices and bids speak
+//     sorted positions, the original index only breaks ties and is restored in the output.
+//   * STATIC OWNERSHIP: point i always bids from workgroup i mod G, so its coordinates and its MEMORY -- the two targets
+//     that were best and second best in its last bid -- live in that workgroup's LDS.  Any two distinct targets bound the
+//     second-best value from below (min of their two current values), hence the radius R = 3 - that bound holds every
+//     target that can matter NOW: one scan per bid, with a radius that is exact unless a remembered target was repriced.
+//   * TEAMS: T lanes per bidder, T = the power of two that spreads the round's own bidders over the workgroup's 1024
+//     lanes (T = 64 in a late easy round, 2-4 in the crowded ones: 16-32 bidders per wave instead of one).  A team walks
+//     the (y, z) rows of a 16^3 grid inside the disc of radius R around the bidder and, per row, the cells of the chord:
+//     the scanned set is the sphere at cell resolution, not its bounding box of cells.
 //   * EXCHANGE BY TAGGED GRANULES (the hand-off form MI355X_MICROARCH.md prices at ~1 us: one naturally aligned 8-byte
 //     {tag | target | increment} written by ONE sc1 store, polled with sc1 loads): every workgroup knows the round's
 //     bidder list, so it knows which entries to wait for; no counter, no barrier, no atomics in memory.  GetMax
 //     (emd_cuda.cu:181-194) is an LDS 64-bit atomic max per target on every workgroup's own copy.
-//   * 16-bit state: 32 n + 18 n / G bytes of LDS (75 KB at n = 2048, G >= 4): two workgroups per CU, G = 8 at B = 64.
+//   * 16-bit state: 32 n + 18 n / G bytes of LDS + the cell table: two workgroups per CU, G = 8 at B = 64.
 // Same arithmetic, same tie rules: bit-equal to the oracle and to the other three kernels for every group size.
-constexpr unsigned EMD_BOX_NONE = 0xffffffffu;
+#ifndef EMD_EG
+#define EMD_EG 8
+#endif
+#ifndef EMD_EGX
+#define EMD_EGX 32
+#endif
+constexpr int EG3 = EMD_EG, EGX3 = EMD_EGX, ENC3 = EG3 * EG3 * EGX3;     // cells along y and z; at most EGX3 along x (the contiguous axis)
+constexpr unsigned EMD_MEM_NONE = 0xffffffffu;
+
+struct EmdGrid3 { float mn[3], sc[3], cw[3], mg; int egx; };     // origin, cells per unit, cell width; geometric margin; cells along x
+__device__ inline int emd_cell3(float x, float mn, float sc, int cells = EG3) {
+    const int c = (int)((x - mn) * sc);                          // monotone in x (truncation toward zero included)
+    return min(max(c, 0), cells - 1);
+}
 
 __device__ inline int emd_wave_scan_incl(int v) {          // inclusive prefix sum over the 64 lanes, on the VALU
 #define EMD_SSTEP(ctrl, rmask) v += __builtin_amdgcn_update_dpp(0, v, ctrl, rmask, 0xf, false)
@@ -710,73 +728,153 @@ __device__ inline int emd_wave_scan_incl(int v) {          // inclusive prefix s
     return v;
 }
 
-struct EmdTables {
-    const float *tx, *ty, *tz, *tp;
+// a lane's (team's) running result: the two largest values (counting duplicates) and the sorted positions that hold them
+struct Top2 { float b, s; int i, j; };
+
+__device__ inline float emd_value(const float4 t, float x1, float y1, float z1) {
+    const float dx = t.x - x1, dy = t.y - y1, dz = t.z - z1;                                          // :139-141
+    return (3.0f - emd_sqrt(((dx * dx) + (dy * dy)) + (dz * dz))) - t.w;                               // :143
+}
+// c ? a : b as ONE v_cndmask on the compare's lane mask: left to itself the compiler turns the three dependent selects of
+// top2_put into nested exec-mask branches (a dozen scalar instructions per target in a loop bound by instruction issue)
+__device__ inline int emd_sel(bool c, int a, int b) {
+    int r;
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(c);
+    __asm__("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+    return r;
+}
+__device__ inline void top2_put(Top2& r, int k, float d) {                                            // :144-151
+    const bool gb = d > r.b, gs = d > r.s;
+    r.j = emd_sel(gb, r.i, emd_sel(gs, k, r.j));
+    r.s = __builtin_amdgcn_fmed3f(r.b, d, r.s);
+    r.i = emd_sel(gb, k, r.i);
+    r.b = fmaxf(r.b, d);
+}
+// fold the result over a DISJOINT target set (o) into a
+__device__ inline void top2_merge(Top2& a, const Top2& o) {
+    const bool gb = a.b > o.b;
+    const float lb = fminf(a.b, o.b), ws = gb ? a.s : o.s;
+    const int li = gb ? o.i : a.i, wj = gb ? a.j : o.j;
+    a.i = gb ? a.i : o.i;
+    a.b = fmaxf(a.b, o.b);
+    a.j = ws >= lb ? wj : li;
+    a.s = fmaxf(ws, lb);
+}
+template <int CTRL>
+__device__ inline void top2_step_dpp(Top2& r) {
+    Top2 o;
+    o.b = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(r.b), CTRL, 0xf, 0xf, false));
+    o.s = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(r.s), CTRL, 0xf, 0xf, false));
+    o.i = __builtin_amdgcn_update_dpp(0, r.i, CTRL, 0xf, 0xf, false);
+    o.j = __builtin_amdgcn_update_dpp(0, r.j, CTRL, 0xf, 0xf, false);
+    top2_merge(r, o);
+}
+__device__ inline void top2_step_xor(Top2& r, int m) {
+    Top2 o;
+    o.b = __shfl_xor(r.b, m, 64); o.s = __shfl_xor(r.s, m, 64); o.i = __shfl_xor(r.i, m, 64); o.j = __shfl_xor(r.j, m, 64);
+    top2_merge(r, o);
+}
+// the T lanes of a team (aligned, T a power of two) -> the team's result in every one of them.  Every step folds two
+// disjoint halves whose lanes all hold their half's result: quad permutes, then the mirrors of 8 and 16 lanes, then
+// the cross-row exchanges.
+__device__ inline void top2_team(Top2& r, int T) {
+    if (T >= 2) top2_step_dpp<0xB1>(r);        // quad_perm [1,0,3,2]
+    if (T >= 4) top2_step_dpp<0x4E>(r);        // quad_perm [2,3,0,1]
+    if (T >= 8) top2_step_dpp<0x141>(r);       // row_half_mirror
+    if (T >= 16) top2_step_dpp<0x140>(r);      // row_mirror
+    if (T >= 32) top2_step_xor(r, 16);
+    if (T >= 64) top2_step_xor(r, 32);
+}
+__device__ inline int emd_team_min(int v, int T) {
+#define EMD_MSTEP(ctrl) v = min(v, __builtin_amdgcn_update_dpp(v, v, ctrl, 0xf, 0xf, false))
+    if (T >= 2) EMD_MSTEP(0xB1);
+    if (T >= 4) EMD_MSTEP(0x4E);
+    if (T >= 8) EMD_MSTEP(0x141);
+    if (T >= 16) EMD_MSTEP(0x140);
+#undef EMD_MSTEP
+    if (T >= 32) v = min(v, __shfl_xor(v, 16, 64));
+    if (T >= 64) v = min(v, __shfl_xor(v, 32, 64));
+    return v;
+}
+
+struct EmdTables3 {
+    const float4* t4;                 // targets (x, y, z, price), sorted by cell then index
     const unsigned short* orig;
-    const int* cell_start;
+    const unsigned short* cell_start;
+    const EmdGrid3* grid;
+#ifdef EMD_TRACE
+    unsigned *tr_evals, *tr_rows;
+#endif
 };
 
-// floor(a / d) for 0 <= a < 64, 1 <= d <= 64 (d wave-uniform): one multiply and a shift
-__device__ inline int emd_div64(int a, int d) { return (a * ((65536 + d - 1) / d)) >> 16; }
-
-// all targets of the cells [c0, c1] (inclusive) -> the wave's merged result; idx is a SORTED position
-__device__ inline Bid3 emd_scan_rows(const int c0[3], const int c1[3], float x1, float y1, float z1, const EmdTables& T) {
-    const int lane = threadIdx.x & 63;
-    const int ny = c1[1] - c0[1] + 1, nz = c1[2] - c0[2] + 1, nrows = ny * nz;      // <= 64
-    const int L = 64 / nrows;                                    // lanes per (y, z) row of cells
-    const int row = emd_div64(lane, L), sub = lane - row * L;
-    int k = 0, e = 0;
-    if (row < nrows) {
-        const int rz = emd_div64(row, ny), ry = row - rz * ny;
-        const int base = ((c0[2] + rz) * EG + c0[1] + ry) * EG;
-        k = T.cell_start[base + c0[0]] + sub;
-        e = T.cell_start[base + c1[0] + 1];
+// Every target within R of (x1, y1, z1) -- and whatever else shares its cells -- is handed to f(k) exactly once over
+// the T lanes of the team (tl = this lane's number in it): the (y, z) rows of cells inside the disc of radius R around
+// the bidder are dealt to the lanes (row r of the disc's bounding square to lane r mod T; L lanes share a row when the
+// team has more lanes than the square has rows), per row the cells of the chord -- the cells along x are fine (up to 32)
+// because trimming a contiguous run costs nothing.  The row bounds come from the same monotone cell function the sort
+// used, a row's distance from the cell boundaries minus a margin that covers their rounding: a target left out is farther
+// than R.  (Measured against the alternative -- all lanes of a team walk every row together, striding over its targets --
+// on 16^3 and 32 x 8 x 8 grids: this form on 32 x 8 x 8 is the fastest on crowded and on sparse auctions.)
+template <typename F>
+__device__ inline void emd_walk(float x1, float y1, float z1, float R, int tl, int T, const EmdTables3& Tb, F&& f) {
+    const EmdGrid3& g = *Tb.grid;
+    const int cy0 = emd_cell3(y1 - R, g.mn[1], g.sc[1]), cy1 = emd_cell3(y1 + R, g.mn[1], g.sc[1]);
+    const int cz0 = emd_cell3(z1 - R, g.mn[2], g.sc[2]), cz1 = emd_cell3(z1 + R, g.mn[2], g.sc[2]);
+    const int ny = cy1 - cy0 + 1, nrows = ny * (cz1 - cz0 + 1);
+    const float inv_ny = 1.0f / (float)ny;
+    int L = 1, lg = 0;
+    while (2 * L * nrows <= T) { L *= 2; ++lg; }
+    const int RS = T >> lg, sub = tl & (L - 1);
+    const float R2 = R * R;
+    for (int r = tl >> lg; r < nrows; r += RS) {
+        const int rz = (int)(((float)r + 0.5f) * inv_ny), ry = r - rz * ny;
+        const int cy = cy0 + ry, cz = cz0 + rz;
+        // distance of the row from the bidder in y and z: below its lower edge or above its upper one (cells 0 and EG3 - 1
+        // also hold what the clamp folded into them: their outer edges are the cloud's own bounds), else inside: 0
+        const float ylo = g.mn[1] + (float)cy * g.cw[1], zlo = g.mn[2] + (float)cz * g.cw[2];
+        const float dy = fmaxf(fmaxf(ylo - y1, y1 - (ylo + g.cw[1])) - g.mg, 0.0f);
+        const float dz = fmaxf(fmaxf(zlo - z1, z1 - (zlo + g.cw[2])) - g.mg, 0.0f);
+        const float h2 = (R2 - dy * dy) - dz * dz;
+        if (!(h2 >= 0.0f)) continue;
+        const float h = __builtin_amdgcn_sqrtf(h2) * 1.000001f + g.mg;
+        const int cx0 = emd_cell3(x1 - h, g.mn[0], g.sc[0], g.egx), cx1 = emd_cell3(x1 + h, g.mn[0], g.sc[0], g.egx);
+        const int base = (cz * EG3 + cy) * g.egx;
+        int k = (int)Tb.cell_start[base + cx0] + sub;
+        const int e = (int)Tb.cell_start[base + cx1 + 1];
+#ifdef EMD_TRACE
+        if (Tb.tr_rows) { atomicAdd(Tb.tr_rows, 1u); if (e > k) atomicAdd(Tb.tr_evals, (unsigned)((e - k + L - 1) / L)); }
+#endif
+        for (; k < e; k += L) f(k);
     }
-    Bid3 r{-1e9f, -1e9f, -1};                                    // :116
-    for (; k < e; k += L) {
-        const float dx = T.tx[k] - x1, dy = T.ty[k] - y1, dz = T.tz[k] - z1;                            // :139-141
-        const float d = (3.0f - emd_sqrt(((dx * dx) + (dy * dy)) + (dz * dz))) - T.tp[k];              // :143
-        bool take = d > r.best;                                                                     // :144-151
-        if (__builtin_amdgcn_ballot_w64(d == r.best && r.idx >= 0))    // equal values: the lower ORIGINAL index wins (rare)
-            take = take || (d == r.best && r.idx >= 0 && T.orig[k] < T.orig[r.idx]);
-        r.idx = take ? k : r.idx;
-        r.better = __builtin_amdgcn_fmed3f(r.best, d, r.better);
-        r.best = fmaxf(r.best, d);
-    }
-    // merge of the 64 lanes (disjoint target sets): largest value, lowest ORIGINAL index among its holders, second
-    // largest counting duplicates
-    Bid3 o;
-    o.best = emd_wave_max(r.best);
-    const int key = (r.idx >= 0 && r.best == o.best) ? (((int)T.orig[r.idx] << 12) | r.idx) : 0x7fffffff;
-    const int kmin = emd_wave_min_i(key);
-    o.idx = kmin == 0x7fffffff ? -1 : (kmin & 0xfff);
-    o.better = emd_wave_max((r.idx >= 0 && r.idx == o.idx) ? r.better : r.best);
-    return o;
 }
 
-__device__ inline unsigned emd_box_pack(const int c0[3], const int c1[3]) {
-    return (unsigned)(c0[0] | (c0[1] << 3) | (c0[2] << 6) | (c1[0] << 9) | (c1[1] << 12) | (c1[2] << 15));
-}
+// -DEMD_TRACE (tools/emd_timeline.py): per workgroup and round, 100-MHz timestamps of the round's phases and the work
+// counters, written behind the bid granules in the sample's workspace (8 words per (workgroup, round), 64 rounds)
+#ifdef EMD_TRACE
+#define EMD_TR(slot) do { if (tid == 0 && it < 64) trace[(g * 64 + it) * 8 + (slot)] = (unsigned)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define EMD_TR(slot) do {} while (0)
+#endif
 
-__global__ __launch_bounds__(EMD_THREADS, 8) void emd_auction_grid2_kernel(const float* __restrict__ xyz1,
-                                                                        const float* __restrict__ xyz2, int B, int n,
-                                                                        int npad, int G, int lgG, float eps, int iters,
-                                                                        float* __restrict__ dist, int32_t* assignment,
-                                                                        float* wsf, unsigned* counters) {
+__global__ __launch_bounds__(EMD_THREADS, 8) void emd_auction_team_kernel(const float* __restrict__ xyz1,
+                                                                          const float* __restrict__ xyz2, int B, int n,
+                                                                          int npad, int G, int lgG, float eps, int iters,
+                                                                          float* __restrict__ dist, int32_t* assignment,
+                                                                          float* wsf, unsigned* counters, int tnum, int tmax) {
     extern __shared__ __attribute__((aligned(16))) float emd_lds[];
     const int nown = npad >> lgG;                                // points this workgroup bids for (local index i >> lgG)
-    float* tx = emd_lds; float* ty = tx + npad; float* tz = ty + npad; float* tp = tz + npad;      // SORTED by cell, then index
-    unsigned long long* top_l = reinterpret_cast<unsigned long long*>(tp + npad);                  // per target: (increment, ~bidder) max
+    float4* t4 = reinterpret_cast<float4*>(emd_lds);                                               // SORTED by cell, then index
+    unsigned long long* top_l = reinterpret_cast<unsigned long long*>(t4 + npad);                  // per target: (increment, ~bidder) max
     float* ox = reinterpret_cast<float*>(top_l + npad); float* oy = ox + nown; float* oz = oy + nown;   // own bidders
-    unsigned* box = reinterpret_cast<unsigned*>(oz + nown);                                        // the cells each own bidder scanned last
-    unsigned short* orig = reinterpret_cast<unsigned short*>(box + nown);                          // sorted position -> target
+    unsigned* mem = reinterpret_cast<unsigned*>(oz + nown);                                        // best | second << 16 of each own bidder's last bid
+    unsigned short* orig = reinterpret_cast<unsigned short*>(mem + nown);                          // sorted position -> target
     short* assign_l = reinterpret_cast<short*>(orig + npad);                                       // point -> sorted position | -1
     short* inv_l = assign_l + npad;                                                                // sorted position -> point | -1
     unsigned short* ulist = reinterpret_cast<unsigned short*>(inv_l + npad);                       // unassigned points, ascending
     unsigned short* ownu = ulist + npad;                                                           // list positions of the own ones
-    __shared__ int cell_start[ENC + 8];
+    __shared__ unsigned short cell_start[ENC3 + 8];
     __shared__ float red[EMD_WAVES][6];
-    __shared__ EmdGrid grid;
+    __shared__ EmdGrid3 grid;
     __shared__ unsigned wtot[EMD_WAVES];
     __shared__ int gave_up;
     if (threadIdx.x == 0) gave_up = 0;
@@ -790,7 +888,15 @@ __global__ __launch_bounds__(EMD_THREADS, 8) void emd_auction_grid2_kernel(const
     unsigned long long* bids = reinterpret_cast<unsigned long long*>(wsf + (size_t)b * EMD_WS_PLANES * n);
     unsigned* counter = counters + 2 * b;
     unsigned passed = 0;
-    int* cursor = reinterpret_cast<int*>(top_l);                 // init only: per-cell counters (top_l is zeroed afterwards)
+#ifdef EMD_TRACE
+    unsigned* trace = reinterpret_cast<unsigned*>(wsf + (size_t)b * EMD_WS_PLANES * n + 4 * (size_t)n);
+    __shared__ unsigned tr_evals, tr_rows;
+    { const int it = 0; if (tid == 0) trace[(g * 64 + 63) * 8 + 7] = (unsigned)__builtin_amdgcn_s_memrealtime(); (void)it; }
+#endif
+    int* cursor = reinterpret_cast<int*>(top_l);                 // init only: per-cell counters (4096 ints = top_l's 16 KB at n = 2048)
+    // the grid is egx x 8 x 8 cells, x fastest: 32 along x when the counters have room, fewer for small clouds
+    // (the host sends n < 128 to the other kernels: at least four)
+    const int egx = min(ENC3, 2 * npad) / (EG3 * EG3), ncell = egx * EG3 * EG3;
 
     // ---- the grid: bounding box of the targets, counting sort by cell, rank inside a cell by original index
     {
@@ -804,66 +910,96 @@ __global__ __launch_bounds__(EMD_THREADS, 8) void emd_auction_grid2_kernel(const
             for (int o = 32; o > 0; o >>= 1) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], o, 64)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o, 64)); }
             if (lane == 0) { red[wave][a] = lo[a]; red[wave][3 + a] = hi[a]; }
         }
-        for (int c = tid; c < ENC; c += EMD_THREADS) cursor[c] = 0;
+        for (int c = tid; c < ncell; c += EMD_THREADS) cursor[c] = 0;
         __syncthreads();
-        if (tid < 3) {
-            float l = red[0][tid], h = red[0][3 + tid];
-            for (int w = 1; w < EMD_WAVES; ++w) { l = fminf(l, red[w][tid]); h = fmaxf(h, red[w][3 + tid]); }
-            grid.mn[tid] = l;
-            grid.sc[tid] = h > l ? (float)EG / (h - l) : 0.0f;      // a flat (or non-finite) extent: one layer of cells
+        if (tid == 0) {
+            float big = 0.0f;
+            for (int a = 0; a < 3; ++a) {
+                float l = red[0][a], h = red[0][3 + a];
+                for (int w = 1; w < EMD_WAVES; ++w) { l = fminf(l, red[w][a]); h = fmaxf(h, red[w][3 + a]); }
+                const float cells = a == 0 ? (float)egx : (float)EG3;
+                grid.mn[a] = l;
+                grid.sc[a] = h > l ? cells / (h - l) : 0.0f;      // a flat (or non-finite) extent: one layer of cells
+                grid.cw[a] = h > l ? (h - l) / cells : 0.0f;
+                big = fmaxf(big, fmaxf(fabsf(l), fabsf(h)));
+            }
+            grid.mg = 4.0e-6f * big + 1.0e-30f;                  // rounding of (x - mn) * sc and of mn + c * cw, with room
+            grid.egx = egx;
         }
         __syncthreads();
-        for (int j = tid; j < n; j += EMD_THREADS) {
-            const int c = (emd_cell1(p2[(size_t)j * 3 + 2], grid.mn[2], grid.sc[2]) * EG + emd_cell1(p2[(size_t)j * 3 + 1], grid.mn[1], grid.sc[1])) * EG
-                          + emd_cell1(p2[(size_t)j * 3], grid.mn[0], grid.sc[0]);
-            atomicAdd(&cursor[c], 1);
-        }
+        auto cell_of = [&](float x, float y, float z) {
+            return (emd_cell3(z, grid.mn[2], grid.sc[2]) * EG3 + emd_cell3(y, grid.mn[1], grid.sc[1])) * egx
+                   + emd_cell3(x, grid.mn[0], grid.sc[0], egx);
+        };
+        for (int j = tid; j < n; j += EMD_THREADS) atomicAdd(&cursor[cell_of(p2[(size_t)j * 3], p2[(size_t)j * 3 + 1], p2[(size_t)j * 3 + 2])], 1);
         __syncthreads();
-        int cnt = 0, incl = 0;
-        if (tid < ENC) { cnt = cursor[tid]; incl = cnt; }
-        incl = emd_wave_scan_incl(incl);
+        // exclusive scan of the cell counts: CPT cells per thread, waves, workgroup
+        constexpr int CPT = ENC3 / EMD_THREADS;
+        static_assert(ENC3 == CPT * EMD_THREADS && CPT >= 1, "whole cells per thread");
+        int c4[CPT], sum4 = 0;
+#pragma unroll
+        for (int e = 0; e < CPT; ++e) {
+            const int c = tid * CPT + e;
+            c4[e] = c < ncell ? cursor[c] : 0;
+            sum4 += c4[e];
+        }
+        const int incl = emd_wave_scan_incl(sum4);
         if (lane == 63) wtot[wave] = (unsigned)incl;
         __syncthreads();
-        if (tid < ENC) {
+        {
             int before = 0;
             for (int w = 0; w < wave; ++w) before += (int)wtot[w];
-            cell_start[tid] = before + incl - cnt;
-            cursor[tid] = before + incl - cnt;
+            int run = before + incl - sum4;
+#pragma unroll
+            for (int e = 0; e < CPT; ++e) { cell_start[tid * CPT + e] = (unsigned short)run; run += c4[e]; }   // cells >= ncell: n
         }
-        if (tid == 0) cell_start[ENC] = n;
+        if (tid == 0) cell_start[ENC3] = (unsigned short)n;
         __syncthreads();
-        for (int j = tid; j < n; j += EMD_THREADS) {              // members of every cell, in whatever order the atomics give
-            const int c = (emd_cell1(p2[(size_t)j * 3 + 2], grid.mn[2], grid.sc[2]) * EG + emd_cell1(p2[(size_t)j * 3 + 1], grid.mn[1], grid.sc[1])) * EG
-                          + emd_cell1(p2[(size_t)j * 3], grid.mn[0], grid.sc[0]);
-            ulist[atomicAdd(&cursor[c], 1)] = (unsigned short)j;
-        }
+        for (int c = tid; c < ncell; c += EMD_THREADS) cursor[c] = cell_start[c];
+        __syncthreads();
+        for (int j = tid; j < n; j += EMD_THREADS)               // members of every cell, in whatever order the atomics give
+            ulist[atomicAdd(&cursor[cell_of(p2[(size_t)j * 3], p2[(size_t)j * 3 + 1], p2[(size_t)j * 3 + 2])], 1)] = (unsigned short)j;
         __syncthreads();
         for (int j = tid; j < n; j += EMD_THREADS) {              // ... then by index: the same order in every workgroup
             const float x = p2[(size_t)j * 3], y = p2[(size_t)j * 3 + 1], z = p2[(size_t)j * 3 + 2];
-            const int c = (emd_cell1(z, grid.mn[2], grid.sc[2]) * EG + emd_cell1(y, grid.mn[1], grid.sc[1])) * EG + emd_cell1(x, grid.mn[0], grid.sc[0]);
+            const int c = cell_of(x, y, z);
             const int s = cell_start[c], e = cell_start[c + 1];
             int rank = 0;
             for (int k = s; k < e; ++k) rank += (int)ulist[k] < j;
-            const int pos = s + rank;
-            tx[pos] = x; ty[pos] = y; tz[pos] = z; tp[pos] = 0.0f; orig[pos] = (unsigned short)j;
+            t4[s + rank] = make_float4(x, y, z, 0.0f);
+            orig[s + rank] = (unsigned short)j;
         }
-        for (int j = n + tid; j < npad; j += EMD_THREADS) { tx[j] = 0.0f; ty[j] = 0.0f; tz[j] = 0.0f; tp[j] = __builtin_inff(); orig[j] = 0xffff; }
+        for (int j = n + tid; j < npad; j += EMD_THREADS) { t4[j] = make_float4(0.0f, 0.0f, 0.0f, __builtin_inff()); orig[j] = 0xffff; }
         for (int l = tid; l < nown; l += EMD_THREADS) {
             const int i = min((l << lgG) + g, n - 1);
             ox[l] = p1[(size_t)i * 3]; oy[l] = p1[(size_t)i * 3 + 1]; oz[l] = p1[(size_t)i * 3 + 2];
-            box[l] = EMD_BOX_NONE;
+            mem[l] = EMD_MEM_NONE;
         }
         __syncthreads();                                         // cursor (aliases top_l) and the unsorted member lists are done with
         for (int j = tid; j < npad; j += EMD_THREADS) { assign_l[j] = -1; inv_l[j] = -1; top_l[j] = 0ull; }
     }
     for (int j = g * EMD_THREADS + tid; j < 2 * n; j += G * EMD_THREADS) emd_st(bids + j, 0ull);
     bool ok = emd_group_sync(counter, passed, G, &gave_up);       // the launch's only counter barrier: granule tags start at 0
-    const EmdTables T{tx, ty, tz, tp, orig, cell_start};
+#ifdef EMD_TRACE
+    const EmdTables3 Tb{t4, orig, cell_start, &grid, &tr_evals, &tr_rows};
+#else
+    const EmdTables3 Tb{t4, orig, cell_start, &grid};
+#endif
+    // first bid of a point (no memory yet): radius that holds ~6 targets of a cloud that fills its box; doubled until two are found
+    const float r_first = 1.5f * cbrtf(fmaxf(grid.cw[0] * (float)egx, 1e-30f) * fmaxf(grid.cw[1] * EG3, 1e-30f) * fmaxf(grid.cw[2] * EG3, 1e-30f)
+                                       * (6.0f / (4.0f * 3.14159265f)) / (float)n);
+    const float r_first_floor = 0.03f * fmaxf(fmaxf(grid.cw[0] * (float)egx, grid.cw[1] * EG3), grid.cw[2] * EG3);
+    const float r0 = fmaxf(r_first, r_first_floor) > 0.0f ? fmaxf(r_first, r_first_floor) : 1.0f;
+    const float slack = 1.0e-5f + 4.0f * grid.mg;
 
     for (int it = 0; ok && it < iters; ++it) {
         const bool last = it == iters - 1;
         unsigned long long* bid_w = bids + (size_t)(it & 1) * n;
         const unsigned tag = (unsigned)(it % 65535) + 1u;        // never 0, differs from the tag two rounds ago
+        EMD_TR(0);
+#ifdef EMD_TRACE
+        if (tid == 0) { tr_evals = 0; tr_rows = 0; }
+#endif
         // ---- unassigned points in ascending order (every copy builds the same list) and the own ones among them:
         //      thread t looks at points t and t + 1024 (same residue mod G); four 8-bit counters in one DPP scan
         const bool mine = (tid & (G - 1)) == g;
@@ -873,12 +1009,20 @@ __global__ __launch_bounds__(EMD_THREADS, 8) void emd_auction_grid2_kernel(const
         const int sc = emd_wave_scan_incl(pk);
         if (lane == 63) wtot[wave] = (unsigned)sc;
         __syncthreads();
-        unsigned befA = 0, totA = 0, befB = 0, totB = 0;         // 16-bit fields: (c0 | own c0 << 16), (c1 | own c1 << 16)
-#pragma unroll
-        for (int w = 0; w < EMD_WAVES; ++w) {
-            const unsigned t = wtot[w], a = t & 0x00ff00ffu, bb = (t >> 8) & 0x00ff00ffu;
-            totA += a; totB += bb;
-            befA += w < wave ? a : 0u; befB += w < wave ? bb : 0u;
+        // the 16 wave totals -> this wave's offsets: lanes 0..15 scan them on the VALU (a 16-step loop over LDS words in
+        // every lane was ~130 instructions of every wave of every round).  16-bit fields: (c0 | own c0 << 16), (c1 | own c1 << 16)
+        unsigned befA, totA, befB, totB;
+        {
+            const unsigned t = wtot[lane & (EMD_WAVES - 1)];
+            int a = (int)(t & 0x00ff00ffu), bb = (int)((t >> 8) & 0x00ff00ffu);
+            const int a0 = a, b0 = bb;
+#define EMD_RSTEP(v, ctrl) v += __builtin_amdgcn_update_dpp(0, v, ctrl, 0xf, 0xf, false)
+            EMD_RSTEP(a, 0x111); EMD_RSTEP(a, 0x112); EMD_RSTEP(a, 0x114); EMD_RSTEP(a, 0x118);      // row_shr 1, 2, 4, 8: inclusive
+            EMD_RSTEP(bb, 0x111); EMD_RSTEP(bb, 0x112); EMD_RSTEP(bb, 0x114); EMD_RSTEP(bb, 0x118);
+#undef EMD_RSTEP
+            static_assert(EMD_WAVES == 16, "one DPP row holds the wave totals");
+            totA = (unsigned)__builtin_amdgcn_readlane(a, 15); totB = (unsigned)__builtin_amdgcn_readlane(bb, 15);
+            befA = (unsigned)__builtin_amdgcn_readlane(a - a0, wave); befB = (unsigned)__builtin_amdgcn_readlane(bb - b0, wave);
         }
         const int U = (int)((totA & 0xffffu) + (totB & 0xffffu));
         const int Uown = (int)((totA >> 16) + (totB >> 16));
@@ -896,47 +1040,75 @@ __global__ __launch_bounds__(EMD_THREADS, 8) void emd_auction_grid2_kernel(const
         }
         __syncthreads();
 
-        // ---- Bid (:95-179), pruned: wave w takes own bidders w, w + 16, ...
-        for (int kb = wave; kb < Uown; kb += EMD_WAVES) {
-            const int u = ownu[kb], i = ulist[u], l = i >> lgG;
-            const float x1 = ox[l], y1 = oy[l], z1 = oz[l];
-            const float xyz[3] = {x1, y1, z1};
-            const unsigned bx = box[l];
-            int a0[3], a1[3];
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const int c = emd_cell1(xyz[a], grid.mn[a], grid.sc[a]);
-                a0[a] = bx == EMD_BOX_NONE ? max(c - 1, 0) : (int)((bx >> (3 * a)) & 7u);
-                a1[a] = bx == EMD_BOX_NONE ? min(c + 1, EG - 1) : (int)((bx >> (9 + 3 * a)) & 7u);
-                a0[a] = __builtin_amdgcn_readfirstlane(a0[a]); a1[a] = __builtin_amdgcn_readfirstlane(a1[a]);
+        EMD_TR(1);
+        // ---- Bid (:95-179), pruned: teams of T lanes, one own bidder each
+        // T lanes per bidder: the own bidders spread over ~tnum lanes, not over all 1024 -- a team's lanes repeat the row
+        // set-up, and the rounds are bound by instruction issue (two workgroups share a CU), not by idle lanes
+        int T = 1, lgT = 0;
+        while (T < tmax && 2 * T * Uown <= tnum) { T *= 2; ++lgT; }
+        const int per_pass = EMD_THREADS >> lgT, tl = tid & (T - 1);
+        for (int k0 = 0; k0 < Uown; k0 += per_pass) {
+            const int kb = k0 + (tid >> lgT);
+            const bool have = kb < Uown;
+            int u = 0, l = 0;
+            float x1 = 0.0f, y1 = 0.0f, z1 = 0.0f, R = -1.0f;
+            unsigned m = EMD_MEM_NONE;
+            if (have) {
+                u = ownu[kb]; l = (int)ulist[u] >> lgG;
+                x1 = ox[l]; y1 = oy[l]; z1 = oz[l]; m = mem[l];
             }
-            Bid3 r = emd_scan_rows(a0, a1, x1, y1, z1, T);
-            // every target outside [x - R, x + R]^3 is strictly below the runner-up found so far
-            const bool two = r.idx >= 0 && r.better > -1e8f;
-            const float R = two ? (3.0f - r.better) + 1.0e-5f : __builtin_inff();
-            int b0[3], b1[3];
-            bool inside = true;
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                b0[a] = emd_cell1(xyz[a] - R, grid.mn[a], grid.sc[a]);
-                b1[a] = emd_cell1(xyz[a] + R, grid.mn[a], grid.sc[a]);
-                if (!(R < 1e30f)) { b0[a] = 0; b1[a] = EG - 1; }                // also a NaN radius: everything
-                b0[a] = __builtin_amdgcn_readfirstlane(b0[a]); b1[a] = __builtin_amdgcn_readfirstlane(b1[a]);
-                inside = inside && b0[a] >= a0[a] && b1[a] <= a1[a];
+            Top2 r{-1e9f, -1e9f, -1, -1};                        // :116
+            if (have && m != EMD_MEM_NONE) {
+                // any two distinct targets bound the second-best value from below: the best two of the last bid, repriced
+                const float v1 = emd_value(t4[m & 0xffffu], x1, y1, z1), v2 = emd_value(t4[m >> 16], x1, y1, z1);
+                R = (3.0f - fminf(v1, v2)) + slack;
+                if (!(R < 1e30f)) R = __builtin_inff();
+                emd_walk(x1, y1, z1, R, tl, T, Tb, [&](int k) { top2_put(r, k, emd_value(t4[k], x1, y1, z1)); });
             }
-            if (!inside) {
-#pragma unroll
-                for (int a = 0; a < 3; ++a) { a0[a] = min(b0[a], a0[a]); a1[a] = max(b1[a], a1[a]); }
-                r = emd_scan_rows(a0, a1, x1, y1, z1, T);
+            top2_team(r, T);
+            // first bid of a point (no memory yet): grow a ball until it holds the two best
+            float Rt = (have && m == EMD_MEM_NONE) ? r0 : -1.0f;
+            while (__builtin_amdgcn_ballot_w64(Rt > 0.0f)) {
+                Top2 w{-1e9f, -1e9f, -1, -1};
+                if (Rt > 0.0f) emd_walk(x1, y1, z1, Rt, tl, T, Tb, [&](int k) { top2_put(w, k, emd_value(t4[k], x1, y1, z1)); });
+                top2_team(w, T);                                 // teams that are done fold empty results: theirs stays as it is
+                if (Rt > 0.0f) {
+                    r = w;
+                    // every target outside the ball of radius 3 - second is strictly below the runner-up found so far
+                    const float need = (r.j >= 0 && r.s > -1e8f) ? (3.0f - r.s) + slack : __builtin_inff();
+                    if (need <= Rt || !(Rt < 1e30f)) Rt = -1.0f;                  // the ball already held them (or was everything)
+                    else Rt = (need < 1e30f) ? need : ((Rt < 64.0f * r0) ? Rt * 2.0f : __builtin_inff());
+                }
             }
-            if (lane == 0) {
-                box[l] = emd_box_pack(a0, a1);
-                const float v = (r.best - r.better) + eps;                                  // :175-176
-                const unsigned t = (unsigned)min(max(r.idx, 0), n - 1);
+            // equal values at the top (lattices, duplicated targets): the lowest ORIGINAL index wins (:144-151 scans in
+            // index order) -- the walk's order is not the index order, so the holders of the maximum are collected again
+            const bool tie = have && r.i >= 0 && r.s == r.b;
+            if (__builtin_amdgcn_ballot_w64(tie)) {
+                int key = 0x7fffffff;
+                if (tie) {
+                    const float Rw = (3.0f - r.b) + slack;
+                    emd_walk(x1, y1, z1, (Rw < 1e30f) ? Rw : __builtin_inff(), tl, T, Tb, [&](int k) {
+                        if (emd_value(t4[k], x1, y1, z1) == r.b) key = min(key, ((int)orig[k] << 12) | k);
+                    });
+                }
+                key = emd_team_min(key, T);
+                if (tie && key != 0x7fffffff) {
+                    const int ki = key & 0xfff;
+                    if (ki != r.i) { r.j = r.i; r.i = ki; }      // the displaced one holds the same value: still a valid memory
+                }
+            }
+            if (have && tl == 0) {
+                mem[l] = (r.i >= 0 && r.j >= 0 && r.i != r.j) ? ((unsigned)r.i | ((unsigned)r.j << 16)) : EMD_MEM_NONE;
+                const float v = (r.b - r.s) + eps;                                          // :175-176
+                const unsigned t = (unsigned)min(max(r.i, 0), n - 1);
                 emd_st(bid_w + u, ((unsigned long long)((tag << 16) | t) << 32) | (unsigned)__float_as_int(v));
             }
         }
 
+        EMD_TR(2);
+#ifdef EMD_TRACE
+        if (tid == 0 && it < 64) { trace[(g * 64 + it) * 8 + 5] = (unsigned)U | ((unsigned)Uown << 16); }
+#endif
         // ---- gather the round's granules (one lane per bidder), GetMax (:181-194) on this copy
         int gi[2], gt[2]; unsigned long long gk[2]; float gv[2];
 #pragma unroll
@@ -964,6 +1136,7 @@ __global__ __launch_bounds__(EMD_THREADS, 8) void emd_auction_grid2_kernel(const
             }
         }
         __syncthreads();
+        EMD_TR(3);
         if (gave_up) { ok = false; break; }
         // ---- Assign (:196-215) of ALL bidders on this workgroup's copy
 #pragma unroll
@@ -976,10 +1149,14 @@ __global__ __launch_bounds__(EMD_THREADS, 8) void emd_auction_grid2_kernel(const
             if (prev != -1) assign_l[prev] = -1;
             inv_l[t] = (short)i;
             assign_l[i] = (short)t;
-            tp[t] = tp[t] + gv[h];                              // :211
+            t4[t].w = t4[t].w + gv[h];                          // :211
             top_l[t] = 0ull;                                    // :212 (losers read either their winner's key or 0: both != theirs)
         }
         __syncthreads();
+        EMD_TR(4);
+#ifdef EMD_TRACE
+        if (tid == 0 && it < 64) { trace[(g * 64 + it) * 8 + 6] = tr_evals; trace[(g * 64 + it) * 8 + 7] = tr_rows; }
+#endif
     }
 
     if (!ok) {                                                  // a partner never delivered: no result for this sample
@@ -995,7 +1172,8 @@ __global__ __launch_bounds__(EMD_THREADS, 8) void emd_auction_grid2_kernel(const
         const int t = assign_l[i];
         if (t < 0 || t >= n) { assignment[(size_t)b * n + i] = -1; dist[(size_t)b * n + i] = __builtin_nanf(""); continue; }
         assignment[(size_t)b * n + i] = (int)orig[t];
-        const float dx = ox[l] - tx[t], dy = oy[l] - ty[t], dz = oz[l] - tz[t];
+        const float4 y = t4[t];
+        const float dx = ox[l] - y.x, dy = oy[l] - y.y, dz = oz[l] - y.z;
         dist[(size_t)b * n + i] = ((dx * dx) + (dy * dy)) + (dz * dz);
     }
 }
@@ -1073,10 +1251,10 @@ extern "C" int vpn_emd_fwd(const float* xyz1, const float* xyz2, int B, int n, f
     unsigned* counters = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + emd_state_bytes(B, n));
     if (hipMemsetAsync(counters, 0, (size_t)2 * B * sizeof(unsigned), s) != hipSuccess) return (int)hipGetLastError();
     float* wsf = (float*)workspace;
-    if (n <= EMD_GRID_MAX && n >= 64 && !emd_force_streaming() && !emd_env_flag("VPN_EMD_NOGRID") && !emd_env_flag("VPN_EMD_GRID1")) {
+    if (n <= EMD_GRID_MAX && n >= 128 && !emd_force_streaming() && !emd_env_flag("VPN_EMD_NOGRID") && !emd_env_flag("VPN_EMD_GRID1")) {
         // the training call (n = SAMPLE_NUM * VP_NUM = 2048): pruned scan, static ownership, granule exchange
         const int npad = (n + 63) / 64 * 64;
-        const void* kern = reinterpret_cast<const void*>(emd_auction_grid2_kernel);
+        const void* kern = reinterpret_cast<const void*>(emd_auction_team_kernel);
         auto lds_of = [&](int G) { return (size_t)npad * 32 + (size_t)(npad / G) * 18; };
         static size_t raised = 0;
         if (lds_of(1) > raised) {
@@ -1099,10 +1277,14 @@ extern "C" int vpn_emd_fwd(const float* xyz1, const float* xyz2, int B, int n, f
         }
         const unsigned lds = (unsigned)lds_of(G);
         const bool coop = G > 1 && !emd_env_flag("VPN_EMD_PLAIN_LAUNCH");
+        int tnum = 1024, tmax = 16;                              // lanes the own bidders of a round are spread over; largest team
+        if (const char* e = getenv("VPN_EMD_TNUM")) tnum = atoi(e) > 0 ? atoi(e) : tnum;
+        if (const char* e = getenv("VPN_EMD_TMAX")) tmax = atoi(e) > 0 ? atoi(e) : tmax;
+        if (tmax > 64) tmax = 64;
         if (coop) {
             void* args[] = {(void*)&xyz1, (void*)&xyz2, (void*)&B, (void*)&n, (void*)&npad, (void*)&G, (void*)&lgG, (void*)&eps, (void*)&iters,
-                            (void*)&dist, (void*)&assignment, (void*)&wsf, (void*)&counters};
-            vpn::prof_begin("emd_auction_grid2_kernel", s);
+                            (void*)&dist, (void*)&assignment, (void*)&wsf, (void*)&counters, (void*)&tnum, (void*)&tmax};
+            vpn::prof_begin("emd_auction_team_kernel", s);
             const hipError_t e = hipLaunchCooperativeKernel(kern, dim3(padded * G), dim3(EMD_THREADS), args, lds, s);
             vpn::prof_end(s);
             if (e == hipSuccess) return 0;
@@ -1110,8 +1292,8 @@ extern "C" int vpn_emd_fwd(const float* xyz1, const float* xyz2, int B, int n, f
             if (e != hipErrorCooperativeLaunchTooLarge && e != hipErrorNotSupported && e != hipErrorInvalidConfiguration) return (int)e;
             G = 1; lgG = 0;
         }
-        VPN_LAUNCH(emd_auction_grid2_kernel, dim3(padded * G), dim3(EMD_THREADS), (unsigned)lds_of(G), s, xyz1, xyz2, B, n, npad, G, lgG, eps,
-                   iters, dist, assignment, wsf, counters);
+        VPN_LAUNCH(emd_auction_team_kernel, dim3(padded * G), dim3(EMD_THREADS), (unsigned)lds_of(G), s, xyz1, xyz2, B, n, npad, G, lgG, eps,
+                   iters, dist, assignment, wsf, counters, tnum, tmax);
         VPN_LAUNCH_CHECK();
         return 0;
     }
