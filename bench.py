@@ -276,11 +276,33 @@ def train_step_block(vpn_amd, _lib, dev, B, K, n, H, steps, warmup, windows, for
     res.update({'workload': 'train.py:243-262 step: B=%d, K=%d spheres, n=%d pts/prim (N=M=%d), %dx%d, weights (view_cd, can_cd, sil, '
                             'vp_div, emd) = %s, EMD eps=0.005 iters=50' % (B, K, n, K * n, H, H, (w,)),
                 'ms_per_step': round(ms, 5), 'images_per_s': round(B / ms * 1e3, 1), 'timing': ev,
-                'losses': dict(zip(('view_cd', 'obj_cd', 'sil', 'vp_div', 'emd', 'total'), [float(x) for x in out.cpu()])),
+                'losses': dict(zip(('view_cd', 'obj_cd', 'sil', 'vp_div', 'emd', 'total'), [float(x) for x in out])),
                 'finite_grad': bool(torch.isfinite(params.grad).all()),
                 'kernel_us': {k: {'calls_per_step': round(v[0] / ksteps, 2), 'avg_us': round(v[1] * 1e3, 2)} for k, v in kern.items()},
                 'kernel_us_sum_per_step': round(sum(v[0] * v[1] for v in kern.values()) / ksteps * 1e3, 1)})
+    if with_oracle:
+        res['parity_vs_oracle'] = c5_parity(vpn_amd, params.detach(), kinds, gt_view, gt_canon, gt_sil, dists, elevs, azims, angles, K, n, H, w)
     return res, (params, kinds, gt_view, gt_canon, gt_sil, dists, elevs, azims, angles)
+
+
+def c5_parity(vpn_amd, params, kinds, gt_view, gt_canon, gt_sil, dists, elevs, azims, angles, K, n, H, w, S=2):
+    """The fused step node on S images against the CPU oracle (oracle.vpn_oracle.train_step: every term restated from the
+    reference, the auction included), loss terms and gradient; host seed = the Philox key the oracle replays."""
+    from oracle import vpn_oracle as O
+    t0 = time.perf_counter()
+    ref, gref = O.train_step(params[:S].cpu(), gt_view[:S].cpu(), gt_canon[:S].cpu(), gt_sil[:S].cpu(), dists[:S].cpu(), elevs[:S].cpu(),
+                             azims[:S].cpu(), angles[:S].cpu(), [0] * K, n, H, H, w, 4242)
+    cpu_s = time.perf_counter() - t0
+    pg = params[:S].clone().requires_grad_(True)
+    out = vpn_amd.TrainStepLossFunction.apply(pg, kinds, gt_view[:S].contiguous(), gt_canon[:S].contiguous(), gt_sil[:S].contiguous(),
+                                              dists[:S].contiguous(), elevs[:S].contiguous(), azims[:S].contiguous(), angles[:S].contiguous(),
+                                              n, 4242, 0, H, H, w)
+    out[5].backward()
+    got = torch.stack([o.detach() for o in out]).cpu()
+    names = ('view_cd', 'obj_cd', 'sil', 'vp_div', 'emd', 'total')
+    rel = {k: float('%.3g' % (abs(float(a) - float(b)) / max(abs(float(b)), 1e-12))) for k, a, b in zip(names, got, ref) if float(b) != 0.0}
+    return {'images': S, 'loss_rel': rel, 'grad_rel': float('%.3g' % float((pg.grad.cpu() - gref).abs().max() / gref.abs().max())),
+            'cpu_port_images_per_s': round(S / cpu_s, 3), 'tolerance': 1e-4}
 
 
 def free_port():
@@ -327,6 +349,7 @@ def main():
     ap.add_argument('--windows', type=int, default=5, help='hipEvent windows of --steps replays each (median reported)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--c5-form', choices=['modules', 'fused', 'both'], default='both')
+    ap.add_argument('--no-c5', action='store_true', help='skip the C5 train-step measurement of the default run')
     ap.add_argument('--no-c2', action='store_true', help='skip the C2 raster-only measurement of the default run')
     ap.add_argument('--no-extras', action='store_true', help='skip C2, EMD and the CPU baseline (profiling runs)')
     ap.add_argument('--no-graph', action='store_true', help='launch every step eagerly instead of replaying a HIP graph')
@@ -391,7 +414,8 @@ def main():
     if args.workload == 'c5':
         forms = [args.c5_form] if args.c5_form != 'both' else ['modules', 'fused']
         res = {f: train_step_block(vpn_amd, _lib, dev, args.batch or 64, args.prims or 64, args.points if args.points != 256 else 32,
-                                   args.size or 256, args.steps, args.warmup, args.windows, f, False)[0] for f in forms}
+                                   args.size or 256, args.steps, args.warmup, args.windows, f, f == 'fused' and not args.no_cpu_baseline)[0]
+               for f in forms}
         if rank == 0:
             best = min(res.values(), key=lambda r: r['ms_per_step'])
             print(json.dumps({'metric': 'train.py step (5 losses) images/sec (BASELINE config C5, one GPU)', 'value': best['images_per_s'],
@@ -717,6 +741,15 @@ def main():
                                          guarded(variant, [vpn_amd.CUBOID] * (K // 2) + [vpn_amd.SPHERE] * (K - K // 2))}
         if world == 1 and not args.no_extras:      # row f1, outside the metric: the auction EMD loss of the same step
             out['emd'] = guarded(emd_extra, B, M, dev, vpn_amd, cpu is not None and 'error' not in cpu)
+        if world == 1 and not args.no_extras and not args.no_c5:
+            # BASELINE config C5, one GPU: the step train.py really runs (all five losses, train.py:243-262), as one fused
+            # autograd node and as the module composition a train.py user writes; then the reference's default shape
+            # (config.py:8-9,34,49: K = 16, n = 128, B = 8, 128 x 128)
+            out['c5'] = {
+                'fused': guarded(lambda: train_step_block(vpn_amd, _lib, dev, 64, 64, 32, 256, 50, 10, 3, 'fused', cpu is not None)[0]),
+                'modules': guarded(lambda: train_step_block(vpn_amd, _lib, dev, 64, 64, 32, 256, 30, 5, 3, 'modules', False)[0]),
+                'reference_default_shape_fused': guarded(lambda: train_step_block(vpn_amd, _lib, dev, 8, 16, 128, 128, 50, 10, 3, 'fused', False)[0]),
+            }
         print(json.dumps(out), flush=True)
     if multi:
         dist.destroy_process_group()

@@ -34,10 +34,11 @@
 extern "C" {
 #endif
 
-/* 4 (round 3): raster records are 16 float4 per primitive (vpn_raster_records_size grew), tile_order is a buffer of
+/* 5 (round 4): vpn_vpdiv_fwd, vpn_camera_matrix, vpn_trainstep_finalize, vpn_trainstep_bwd (the reference's whole training
+ * step in one autograd node).  4 (round 3): raster records are 16 float4 per primitive (vpn_raster_records_size grew), tile_order is a buffer of
  * 48-byte tile entries (vpn_raster_order_size, K <= 64).  3: vpn_raster_total_fwd_fin, vpn_hotpath_chamfer_fwd, the mesh
  * entry points. */
-#define VPN_ABI_VERSION 4
+#define VPN_ABI_VERSION 5
 
 /* primitive kinds (reference: train.py:106-116 cuboids first, then spheres, cones are stubs) */
 #define VPN_SPHERE 0
@@ -348,6 +349,49 @@ int vpn_head_pack_bwd(const float* volumes, const float* rotates, const float* t
                       int B, int K, int is_sigmoid, float clamp_min, float clamp_max, float restrict0,
                       float restrict1, float restrict2, float* grad_volumes, float* grad_rotates,
                       float* grad_translates, void* stream);
+
+/* ---- the reference's whole training step (train.py:243-262) around the hot path: BASELINE config C5
+ *   total = L_VIEW_CD * ChamferDistanceLoss(pred, view_center)            (train.py:160)   [vpn_hotpath_*]
+ *         + L_CAN_CD  * ChamferDistanceLoss(view_to_obj(pred), canonical) (train.py:158-161)
+ *         + L_SIL     * SilhouetteLoss(primitives, silhouettes)           (train.py:176)   [vpn_raster_total_fwd_fin]
+ *         + L_VP_DIV  * VPDiverseLoss(translates, view_center)            (train.py:185, vp_diverse.py:12-18)
+ *         + L_EMD     * sqrt(EMD dist).mean()                             (train.py:193-195) [vpn_emd_fwd]
+ * vpn_vpdiv_fwd: the nearest neighbours of VPDiverseLoss -- centres = params[b,k,7:10] (the reference cats the K
+ *   translations), both directions: dist1/idx1 [B,K] (centre -> nearest ground-truth point), dist2/idx2 [B,M]; same
+ *   arithmetic and tie rule as vpn_chamfer_fwd (chamfer_distance.py:14-23).
+ * vpn_camera_matrix: mat [B,9] row-major with view_to_obj_points(p) = mat p (to_object != 0; transform.py:21-47) or
+ *   obj_to_view_points(p) = mat p (to_object == 0; :50-73), the scale by dist included.
+ * vpn_trainstep_finalize: out [6] = (L_VIEW_CD*view_cd, L_CAN_CD*obj_cd, L_SIL*sil, L_VP_DIV*vp_div, L_EMD*emd, their sum)
+ *   from hot_losses [4] as vpn_raster_total_fwd_fin leaves them (w_cd = L_VIEW_CD, w_sil = L_SIL, w_dep = 0), the
+ *   auction's dist [B,N], the object-centred cloud's nearest-neighbour distances cn_dist1 [B,N] / cn_dist2 [B,Mc] and
+ *   the VP-diversity distances dv_dist1 [B,K] / dv_dist2 [B,M]; any of the three groups may be NULL (term = 0).
+ *   Fixed summation order.
+ * vpn_trainstep_bwd: grad_params [B,K,10] = (*grad_total) * d total / d params in ONE launch: vpn_hotpath_bwd (w1 =
+ *   cd_w1 * L_VIEW_CD / B, w2 = cd_w2 * L_VIEW_CD / B; records / workspace NULL when the silhouette term is off) plus
+ *   - the EMD term through the assignment (emd_cuda.cu:284-300 and the sqrt / mean of train.py:195): emd_coef = L_EMD / (B N);
+ *   - the VP-diversity term, straight into the translations: dv_c1 = L_VP_DIV * 0.5 / (K B), dv_c2 = L_VP_DIV * 1.0 / (M B);
+ *   - the object-centred Chamfer term through cn_mat [B,9] (cn_points = the transformed cloud, cn_gt [B,cn_M,3],
+ *     its four nearest-neighbour arrays): cn_c1 = L_CAN_CD * cd_w1 / (N B), cn_c2 = L_CAN_CD * cd_w2 / (cn_M B).
+ *   A group whose first pointer is NULL is skipped (the reference's default L_CAN_CD = 0 multiplies that gradient by 0). */
+int vpn_vpdiv_fwd(const float* params, const float* gt_points, int B, int K, int M, float* dist1, int32_t* idx1,
+                  float* dist2, int32_t* idx2, void* stream);
+int vpn_camera_matrix(const float* dists, const float* elevs, const float* azims, const float* angles, int B,
+                      int to_object, float* mat, void* stream);
+int vpn_trainstep_finalize(const float* hot_losses, const float* emd_dist, const float* cn_dist1, const float* cn_dist2,
+                           const float* dv_dist1, const float* dv_dist2, int B, int N, int M, int Mc, int K,
+                           float w_view, float w_can, float w_sil, float w_div, float w_emd, float cd_w1, float cd_w2,
+                           float* out, void* stream);
+int vpn_trainstep_bwd(const float* params, const int32_t* kinds, uint64_t seed, const uint64_t* seed_dev,
+                      uint64_t sample_base, int B, int K, int n, const float* points, const float* gt_points, int M,
+                      const float* dist1, const int32_t* idx1, const float* dist2, const int32_t* idx2,
+                      float w1, float w2, const float* cam, int H, int W, const void* records,
+                      const void* workspace, const float* grad_total,
+                      const float* emd_dist, const int32_t* emd_assign, float emd_coef,
+                      const float* dv_dist1, const int32_t* dv_idx1, const float* dv_dist2, const int32_t* dv_idx2,
+                      float dv_c1, float dv_c2,
+                      const float* cn_points, const float* cn_gt, const float* cn_mat, const float* cn_dist1,
+                      const int32_t* cn_idx1, const float* cn_dist2, const int32_t* cn_idx2, float cn_c1, float cn_c2,
+                      int cn_M, float* grad_params, void* stream);
 
 /* ---- Earth Mover's Distance, auction approximation (row f1)
  * Replaces emd.forward / emd.backward of the reference's CUDA extension (modules/loss/emd/emd_cuda.cu:228-282,

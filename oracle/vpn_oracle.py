@@ -626,3 +626,35 @@ def head_post_process(volumes, rotates, translates, is_sigmoid=True, clamp_min=0
     K = volumes.shape[1] // 3
     v = v.reshape(B, K, 3) / torch.tensor(list(volume_restrict), dtype=v.dtype)
     return torch.cat([v, q.reshape(B, K, 4), t.reshape(B, K, 3)], dim=2)
+
+
+def train_step(params, gt_view, gt_canon, gt_sil, dists, elevs, azims, angles, kinds, n, H, W, weights, seed,
+               eps=0.005, iters=50, sigma=0.05, gamma=0.1, z_far=2.0):
+    """One training iteration's loss of the reference (train.py:243-262) and its gradient w.r.t. the packed primitive
+    parameters, fp32 on the CPU: sampler (Philox replay of the kernel's draws) -> view-centred Chamfer (train.py:160) +
+    object-centred Chamfer through view_to_obj_points (:158-161) + L1 silhouette loss with the view-centred camera
+    (:169-176, silhouette.py:13-23) + VP-diversity (:185, vp_diverse.py:15-17) + sqrt(EMD dist).mean() (:193-195; the
+    assignment is a constant of the graph, as in emdFunction, emd_module.py:58-70).  weights = (L_VIEW_CD, L_CAN_CD, L_SIL,
+    L_VP_DIV, L_EMD).  Returns ([6] = the five weighted terms and their sum, d total / d params)."""
+    B, K = params.shape[0], params.shape[1]
+    w = [float(x) for x in weights]
+    p = params.detach().clone().requires_grad_(True)
+    u = philox_uniforms(seed, 0, B, K, n)
+    pred = sample_primitives(p, kinds, u)
+    zero = torch.zeros(())
+    view_cd = chamfer_loss(pred, gt_view) * w[0]
+    obj_cd = chamfer_loss(view_to_obj_points(pred, dists, elevs, azims, angles), gt_canon) * w[1]
+    sil = zero
+    if w[2]:
+        cam = torch.tensor([[1.0, 0.0, 0.0]]).expand(B, 3)                        # train.py:172-174
+        alpha, _ = raster(p, kinds, cam, H, W, sigma, gamma, z_far)
+        sil = (alpha - gt_sil.reshape(B, H, W)).abs().mean() * w[2]
+    div = chamfer_loss(p[:, :, 7:10], gt_view, w1=0.5, w2=1.0) * w[3] if w[3] else zero
+    emd = zero
+    if w[4]:
+        _, assign = emd_auction(pred.detach(), gt_view, eps, iters)
+        picked = torch.gather(gt_view, 1, assign.long()[..., None].expand(-1, -1, 3))
+        emd = torch.sqrt(((pred - picked) ** 2).sum(-1)).mean() * w[4]
+    total = view_cd + obj_cd + sil + div + emd
+    total.backward()
+    return torch.stack([view_cd, obj_cd, sil, div, emd, total]).detach(), p.grad

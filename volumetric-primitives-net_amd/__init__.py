@@ -6,7 +6,7 @@ ABI of include/vpn_hip.h; there is no CPU fallback."""
 from . import config
 from .ops import (SPHERE, CUBOID, SampleFunction, TransformFunction, ChamferFunction, EmdFunction, HeadPackFunction, MeshFunction,
                   CameraTransformFunction, RasterFunction,
-                  RasterLossFunction, RasterTotalFunction, HotPathLossFunction, chamfer_nn, kinds_tensor)
+                  RasterLossFunction, RasterTotalFunction, HotPathLossFunction, TrainStepLossFunction, chamfer_nn, kinds_tensor)
 from .primitives import PrimitivePack, pack_primitives, kinds_from_counts
 from .modules import (Sampling, ChamferDistanceLoss, EarthMoverDistanceLoss, SilhouetteLoss, VPDiverseLoss, VertexRenderer,
                       transform_points, rotate_points, translate_points, view_to_obj_points,

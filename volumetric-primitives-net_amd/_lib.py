@@ -9,7 +9,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libvpn_hip.so')
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _c_f = ctypes.c_void_p      # device pointers travel as void*
 _i, _f, _u64, _sz = ctypes.c_int, ctypes.c_float, ctypes.c_uint64, ctypes.c_size_t
@@ -62,6 +62,12 @@ SIGNATURES = {
     'vpn_mesh_sample_bwd': (_i, [_c_f, _c_f, _c_f, _c_f, _i, _i, _i, _i, _c_f, _c_f]),
     'vpn_head_pack_fwd': (_i, [_c_f, _c_f, _c_f, _i, _i, _i, _f, _f, _f, _f, _f, _c_f, _c_f]),
     'vpn_head_pack_bwd': (_i, [_c_f, _c_f, _c_f, _c_f, _i, _i, _i, _f, _f, _f, _f, _f, _c_f, _c_f, _c_f, _c_f]),
+    'vpn_vpdiv_fwd': (_i, [_c_f, _c_f, _i, _i, _i, _c_f, _c_f, _c_f, _c_f, _c_f]),
+    'vpn_camera_matrix': (_i, [_c_f, _c_f, _c_f, _c_f, _i, _i, _c_f, _c_f]),
+    'vpn_trainstep_finalize': (_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _c_f, _c_f]),
+    'vpn_trainstep_bwd': (_i, [_c_f, _c_f, _u64, _c_f, _u64, _i, _i, _i, _c_f, _c_f, _i, _c_f, _c_f, _c_f, _c_f, _f, _f, _c_f, _i, _i,
+                               _c_f, _c_f, _c_f, _c_f, _c_f, _f, _c_f, _c_f, _c_f, _c_f, _f, _f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f,
+                               _f, _f, _i, _c_f, _c_f]),
     'vpn_emd_workspace': (_sz, [_i, _i]),
     'vpn_emd_fwd': (_i, [_c_f, _c_f, _i, _i, _f, _i, _c_f, _c_f, _c_f, _i, _c_f]),
     'vpn_emd_bwd': (_i, [_c_f, _c_f, _c_f, _c_f, _i, _i, _c_f, _c_f]),

@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libvpn_hip.so')
-SOURCES = ['vpn_api.hip', 'sampler.hip', 'chamfer.hip', 'raster.hip', 'emd.hip', 'head.hip', 'mesh.hip']
+SOURCES = ['vpn_api.hip', 'sampler.hip', 'chamfer.hip', 'raster.hip', 'emd.hip', 'head.hip', 'mesh.hip', 'trainstep.hip']
 COMMON = ['-O3', '--offload-arch=gfx950', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function']
 COMMON += os.environ.get('VPN_EXTRA_FLAGS', '').split()      # experiments only (e.g. -DVPN_CHAMFER_DEBUG)
 RASTER_EXTRA = os.environ.get('VPN_RASTER_FLAGS', '').split()  # experiments only: extra flags for raster.hip alone
@@ -23,6 +23,7 @@ PER_FILE = {
     'chamfer.hip': ['-ffp-contract=off', '-mllvm', '-amdgpu-mfma-vgpr-form'],
     # bit-equal to the oracle's auction: same rounding rules as the Chamfer scan
     'emd.hip': ['-ffp-contract=off', '-fno-slp-vectorize'],     # packed fp32 is half rate: keep the scan scalar
+    'trainstep.hip': ['-ffp-contract=off'],                     # the VP-diversity neighbours follow the Chamfer arithmetic
     # the raster is compared with a 1e-4 tolerance: 1-ulp v_rcp/v_sqrt instead of the IEEE sequences
     # -fgpu-flush-denormals-to-zero: no denormal-safe scaling around v_rcp / v_sqrt / v_exp
     # -fno-slp-vectorize: packed fp32 is half rate here and the packing costs v_mov shuffles and 25 VGPRs

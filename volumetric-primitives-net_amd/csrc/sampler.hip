@@ -318,12 +318,28 @@ __global__ __launch_bounds__(SAMP_BLOCK) void sample_bwd_kernel(
 #ifndef SCB_BLOCK
 #define SCB_BLOCK 128
 #endif
+// The other loss terms of the reference's training step (train.py:243-262) that reach the sampled points or the
+// primitive centres; every coefficient is multiplied by the upstream gradient of the total in the kernel.
+struct StepExtras {
+    // EMD (train.py:193-195): w_emd * mean_{b,i} sqrt(dist_i), dist_i = |p_i - gt[assign_i]|^2 from vpn_emd_fwd(points, gt)
+    const float* emd_dist = nullptr; const int32_t* emd_assign = nullptr; float emd_coef = 0.f;   // w_emd / (B N)
+    // VP-diversity (vp_diverse.py:15-17): Chamfer(centres [B,K,3] = the translations, gt; w1 = 0.5, w2 = 1.0)
+    const float* dv_dist1 = nullptr; const int32_t* dv_idx1 = nullptr;                            // [B,K]
+    const float* dv_dist2 = nullptr; const int32_t* dv_idx2 = nullptr;                            // [B,M]
+    float dv_c1 = 0.f, dv_c2 = 0.f;                                                               // w_div * 0.5 / (K B), w_div * 1.0 / (M B)
+    // object-centred Chamfer (train.py:158-161) of canon = cn_mat_b p against cn_gt [B,Mc,3]
+    const float* cn_points = nullptr; const float* cn_gt = nullptr; const float* cn_mat = nullptr;   // [B,N,3], [B,Mc,3], [B,9]
+    const float* cn_dist1 = nullptr; const int32_t* cn_idx1 = nullptr; const float* cn_dist2 = nullptr; const int32_t* cn_idx2 = nullptr;
+    float cn_c1 = 0.f, cn_c2 = 0.f; int cn_M = 0;                                                 // w_can * cd_w1 / (N B), w_can * cd_w2 / (Mc B)
+};
+
+template <bool EXTRAS>
 __global__ __launch_bounds__(SCB_BLOCK) void sample_chamfer_bwd_kernel(
     const float* __restrict__ params, const int32_t* __restrict__ kinds, const float* __restrict__ u,
     uint64_t seed, const uint64_t* __restrict__ seed_dev, uint64_t sample_base, int K, int n,
     const float* __restrict__ points, const float* __restrict__ gt, int M, const float* __restrict__ dist1, const int32_t* __restrict__ idx1,
     const float* __restrict__ dist2, const int32_t* __restrict__ idx2, const float* __restrict__ grad_loss_b,
-    float w1, float w2, float* __restrict__ grad_params, const RasterFinish rf) {
+    float w1, float w2, float* __restrict__ grad_params, const RasterFinish rf, const StepExtras ex) {
     __shared__ PrimLds P;
     __shared__ float red[SCB_BLOCK / 64][12];
     __shared__ float fin[SCB_BLOCK / 64][12];
@@ -390,11 +406,40 @@ __global__ __launch_bounds__(SCB_BLOCK) void sample_chamfer_bwd_kernel(
             acc[9 + r] += g[r];
         }
     };
+    // object-centred Chamfer: canon = S p with S = cn_mat_b (3x3, the camera rotations times dist); a gradient g of a
+    // canonical point is S^T g for the view-centred point it came from
+    float S[9];
+    if (EXTRAS && ex.cn_points) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) S[i] = ex.cn_mat[b * 9 + i];
+    }
+    auto add_canon = [&](int pl, float gx, float gy, float gz) {
+        add(pl, S[0] * gx + S[3] * gy + S[6] * gz, S[1] * gx + S[4] * gy + S[7] * gz, S[2] * gx + S[5] * gy + S[8] * gz);
+    };
     for (int pl = threadIdx.x; pl < n; pl += SCB_BLOCK) {              // own nearest neighbour
         const int i = k * n + pl, j = idx1[(size_t)b * N + i];
         const float coef = ca / dist1[(size_t)b * N + i];
         const F3 a = ld3(A + i * 3), g = ld3(G2 + j * 3);
-        add(pl, coef * (a.x - g.x), coef * (a.y - g.y), coef * (a.z - g.z));
+        float gx = coef * (a.x - g.x), gy = coef * (a.y - g.y), gz = coef * (a.z - g.z);
+        if (EXTRAS && ex.emd_dist) {
+            // d mean sqrt(dist) / d p = (p - y) / sqrt(dist) / (B N)  (sqrt and mean of train.py:195 through NmDistanceGradKernel,
+            // emd_cuda.cu:284-300: 2 g (p - y) with g = 1 / (2 sqrt(dist)));  dist = 0 gives NaN like the reference's chain
+            const int t = ex.emd_assign[(size_t)b * N + i];
+            if (t >= 0 && t < M) {
+                const F3 y = ld3(G2 + t * 3);
+                const float ce = (gl * ex.emd_coef) / sqrtf(ex.emd_dist[(size_t)b * N + i]);
+                gx += ce * (a.x - y.x); gy += ce * (a.y - y.y); gz += ce * (a.z - y.z);
+            } else {
+                gx = gy = gz = __builtin_nanf("");                  // the auction left the point unassigned: say so
+            }
+        }
+        add(pl, gx, gy, gz);
+        if (EXTRAS && ex.cn_points) {
+            const int jc = ex.cn_idx1[(size_t)b * N + i];
+            const float cc = (gl * ex.cn_c1) / ex.cn_dist1[(size_t)b * N + i];
+            const F3 ac = ld3(ex.cn_points + ((size_t)b * N + i) * 3), gc = ld3(ex.cn_gt + ((size_t)b * ex.cn_M + jc) * 3);
+            add_canon(pl, cc * (ac.x - gc.x), cc * (ac.y - gc.y), cc * (ac.z - gc.z));
+        }
     }
     // being a GT point's nearest neighbour: about M/K of the M entries concern this primitive, spread so that almost
     // every pass over 256 entries has a lane with a match — handled in place, the heavy body (dependent loads,
@@ -429,6 +474,36 @@ __global__ __launch_bounds__(SCB_BLOCK) void sample_chamfer_bwd_kernel(
         const float coef = cb / dist2[(size_t)b * M + e];
         const F3 a = ld3(A + i * 3), g = ld3(G2 + e * 3);
         add(i - k * n, coef * (a.x - g.x), coef * (a.y - g.y), coef * (a.z - g.z));
+    }
+    if (EXTRAS && ex.cn_points) {
+        // the object-centred cloud's scatter term: ground-truth points whose nearest canonical point is one of this
+        // primitive's (their number is small: handled where they are found)
+        const float cbc = gl * ex.cn_c2;
+        for (int e = threadIdx.x; e < ex.cn_M; e += SCB_BLOCK) {
+            const int i = ex.cn_idx2[(size_t)b * ex.cn_M + e];
+            if (i < k * n || i >= (k + 1) * n) continue;
+            const float cc = cbc / ex.cn_dist2[(size_t)b * ex.cn_M + e];
+            const F3 ac = ld3(ex.cn_points + ((size_t)b * N + i) * 3), gc = ld3(ex.cn_gt + ((size_t)b * ex.cn_M + e) * 3);
+            add_canon(i - k * n, cc * (ac.x - gc.x), cc * (ac.y - gc.y), cc * (ac.z - gc.z));
+        }
+    }
+    if (EXTRAS && ex.dv_dist1) {
+        // VP-diversity: the centre of primitive k IS t_k, so its gradient goes straight into sum g (acc[9..11])
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        const float c2 = gl * ex.dv_c2;
+        for (int e = threadIdx.x; e < M; e += SCB_BLOCK) {
+            if (ex.dv_idx2[(size_t)b * M + e] != k) continue;
+            const float cc = c2 / ex.dv_dist2[(size_t)b * M + e];
+            const F3 g = ld3(G2 + e * 3);
+            sx += cc * (tx - g.x); sy += cc * (ty - g.y); sz += cc * (tz - g.z);
+        }
+        if (threadIdx.x == 0) {
+            const int j = ex.dv_idx1[b * K + k];
+            const float cc = (gl * ex.dv_c1) / ex.dv_dist1[b * K + k];
+            const F3 g = ld3(G2 + j * 3);
+            sx += cc * (tx - g.x); sy += cc * (ty - g.y); sz += cc * (tz - g.z);
+        }
+        acc[9] += sx; acc[10] += sy; acc[11] += sz;
     }
     {   // 12 sums per wave with ONE transposing butterfly (17 cross-lane moves) instead of 12 x 6
         float v16[16];
@@ -721,6 +796,17 @@ __global__ __launch_bounds__(TR_BLOCK) void camera_transform_kernel(
     }
 }
 
+// the per-sample 3x3 of the fused camera transforms, scale included: out = mat p  (backward of the object-centred Chamfer)
+__global__ __launch_bounds__(64) void camera_matrix_kernel(const float* __restrict__ dists, const float* __restrict__ elevs,
+                                                          const float* __restrict__ azims, const float* __restrict__ angles,
+                                                          int B, int to_object, float* __restrict__ mat) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    const Mat3 M = camera_matrix(elevs[b], azims[b], angles ? angles[b] : 0.0f, to_object);
+    const float d = dists[b];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) mat[b * 9 + i * 3 + j] = to_object ? M.m[i][j] * d : M.m[i][j] / d;
+}
+
 // records of all (image, primitive) pairs: one lane each (also zeroes the arrival counter of the loss finalisation)
 __global__ __launch_bounds__(256) void raster_prep_kernel(const float* __restrict__ params,
                                                           const int32_t* __restrict__ kinds,
@@ -862,6 +948,14 @@ static int camera_launch(const float* points, const float* dists, const float* e
     return 0;
 }
 
+extern "C" int vpn_camera_matrix(const float* dists, const float* elevs, const float* azims, const float* angles, int B,
+                                 int to_object, float* mat, void* stream) {
+    if (!dists || !elevs || !azims || !mat || (to_object && !angles) || B <= 0) return VPN_E_BADARG;
+    VPN_LAUNCH(camera_matrix_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, dists, elevs, azims, angles, B, to_object, mat);
+    VPN_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int vpn_camera_transform_fwd(const float* points, const float* dists, const float* elevs,
                                         const float* azims, const float* angles, int B, int N, int to_object,
                                         float* out, void* stream) {
@@ -878,7 +972,7 @@ static int launch_scb(const float* params, const int32_t* kinds, const float* u,
                       const uint64_t* seed_dev, uint64_t sample_base, int B, int K, int n, const float* points,
                       const float* gt_points, int M, const float* dist1, const int32_t* idx1,
                       const float* dist2, const int32_t* idx2, const float* grad_loss_b, float w1,
-                      float w2, float* grad_params, const RasterFinish& rf, void* stream) {
+                      float w2, float* grad_params, const RasterFinish& rf, void* stream, const StepExtras* ex = nullptr) {
     if (!params || !kinds || !points || !gt_points || !dist1 || !idx1 || !dist2 || !idx2 || !grad_params)
         return VPN_E_BADARG;
     if (!grad_loss_b && !rf.scale) return VPN_E_BADARG;
@@ -887,8 +981,12 @@ static int launch_scb(const float* params, const int32_t* kinds, const float* u,
     constexpr int BLK = SCB_BLOCK;
     const size_t lds = (size_t)((M + BLK - 1) / BLK) * 64 * (BLK / 64) * sizeof(int2);  // = 8 B per GT point
     if (lds > 60 * 1024) return VPN_E_TOOBIG;                           // 7680 GT points; beyond: vpn_chamfer_bwd + vpn_sample_bwd
-    VPN_LAUNCH(sample_chamfer_bwd_kernel, dim3(K, B), dim3(BLK), lds, (hipStream_t)stream, params, kinds, u, seed,
-               seed_dev, sample_base, K, n, points, gt_points, M, dist1, idx1, dist2, idx2, grad_loss_b, w1, w2, grad_params, rf);
+    if (ex)
+        VPN_LAUNCH_AS("sample_chamfer_bwd_kernel<step>", sample_chamfer_bwd_kernel<true>, dim3(K, B), dim3(BLK), lds, (hipStream_t)stream, params, kinds, u, seed,
+                      seed_dev, sample_base, K, n, points, gt_points, M, dist1, idx1, dist2, idx2, grad_loss_b, w1, w2, grad_params, rf, *ex);
+    else
+        VPN_LAUNCH_AS("sample_chamfer_bwd_kernel", sample_chamfer_bwd_kernel<false>, dim3(K, B), dim3(BLK), lds, (hipStream_t)stream, params, kinds, u, seed,
+                      seed_dev, sample_base, K, n, points, gt_points, M, dist1, idx1, dist2, idx2, grad_loss_b, w1, w2, grad_params, rf, StepExtras{});
     VPN_LAUNCH_CHECK();
     return 0;
 }
@@ -920,6 +1018,42 @@ extern "C" int vpn_hotpath_bwd(const float* params, const int32_t* kinds, const 
     rf.scale = grad_total;
     return launch_scb(params, kinds, u, seed, seed_dev, sample_base, B, K, n, points, gt_points, M, dist1, idx1, dist2, idx2,
                       grad_loss_b, w1, w2, grad_params, rf, stream);
+}
+
+// Backward of the WHOLE training step of the reference (train.py:243-264) in one launch: vpn_hotpath_bwd plus the EMD
+// term, the VP-diversity term and (when its weight is not zero) the object-centred Chamfer term; see include/vpn_hip.h
+extern "C" int vpn_trainstep_bwd(const float* params, const int32_t* kinds, uint64_t seed, const uint64_t* seed_dev,
+                                 uint64_t sample_base, int B, int K, int n, const float* points, const float* gt_points, int M,
+                                 const float* dist1, const int32_t* idx1, const float* dist2, const int32_t* idx2,
+                                 float w1, float w2, const float* cam, int H, int W, const void* records,
+                                 const void* workspace, const float* grad_total,
+                                 const float* emd_dist, const int32_t* emd_assign, float emd_coef,
+                                 const float* dv_dist1, const int32_t* dv_idx1, const float* dv_dist2, const int32_t* dv_idx2,
+                                 float dv_c1, float dv_c2,
+                                 const float* cn_points, const float* cn_gt, const float* cn_mat, const float* cn_dist1,
+                                 const int32_t* cn_idx1, const float* cn_dist2, const int32_t* cn_idx2, float cn_c1, float cn_c2,
+                                 int cn_M, float* grad_params, void* stream) {
+    if (!grad_total) return VPN_E_BADARG;
+    if (emd_dist && (!emd_assign || K * n != M)) return VPN_E_BADARG;              // emd_module.py:36: equal sizes
+    if (dv_dist1 && (!dv_idx1 || !dv_dist2 || !dv_idx2)) return VPN_E_BADARG;
+    if (cn_points && (!cn_gt || !cn_mat || !cn_dist1 || !cn_idx1 || !cn_dist2 || !cn_idx2 || cn_M <= 0)) return VPN_E_BADARG;
+    RasterFinish rf;
+    rf.scale = grad_total;
+    if (records && workspace) {                                                   // the silhouette term's partials exist
+        if (!cam || H <= 0 || W <= 0) return VPN_E_BADARG;
+        rf.rec = (const float4*)records;
+        rf.ntile = ((W + R_TW - 1) / R_TW) * ((H + R_TH - 1) / R_TH);
+        rf.words = (K + 63) / 64;
+        rf.masks = reinterpret_cast<const unsigned long long*>(reinterpret_cast<const char*>(records) + (size_t)B * K * R_REC * sizeof(float4));
+        rf.partial = (const float*)workspace;
+    }
+    StepExtras ex;
+    ex.emd_dist = emd_dist; ex.emd_assign = emd_assign; ex.emd_coef = emd_coef;
+    ex.dv_dist1 = dv_dist1; ex.dv_idx1 = dv_idx1; ex.dv_dist2 = dv_dist2; ex.dv_idx2 = dv_idx2; ex.dv_c1 = dv_c1; ex.dv_c2 = dv_c2;
+    ex.cn_points = cn_points; ex.cn_gt = cn_gt; ex.cn_mat = cn_mat; ex.cn_dist1 = cn_dist1; ex.cn_idx1 = cn_idx1;
+    ex.cn_dist2 = cn_dist2; ex.cn_idx2 = cn_idx2; ex.cn_c1 = cn_c1; ex.cn_c2 = cn_c2; ex.cn_M = cn_M;
+    return launch_scb(params, kinds, nullptr, seed, seed_dev, sample_base, B, K, n, points, gt_points, M, dist1, idx1, dist2, idx2,
+                      nullptr, w1, w2, grad_params, rf, stream, &ex);
 }
 
 static int mesh_check(const void* params, const void* kinds, const void* offsets, const void* ts, const void* tc,

@@ -725,3 +725,167 @@ class HotPathLossFunction(Function):
         _lib.call('vpn_raster_total_bwd', _lib.ptr(params), _lib.ptr(cam), B, K, H, W, _lib.ptr(rec), _lib.ptr(rws),
                   _lib.ptr(grad_total), _lib.ptr(grad_params), 1, s)
         return (grad_params,) + (None,) * 20
+
+
+_CAMS = {}
+
+
+def _view_camera(B, dev):
+    """cam [B,3] = (dist 1, elev 0, azim 0): the view-centred camera of train.py:172-174, cached per (B, device)."""
+    key = (B, str(dev))
+    if key not in _CAMS:
+        _CAMS[key] = torch.tensor([[1.0, 0.0, 0.0]], dtype=torch.float32, device=dev).expand(B, 3).contiguous()
+    return _CAMS[key]
+
+
+class TrainStepLossFunction(Function):
+    """The loss of one training iteration of the reference (train.py:243-262) as ONE autograd node, BASELINE config C5:
+
+        total = L_VIEW_CD * ChamferDistanceLoss(pred, view_center_points)                          train.py:160
+              + L_CAN_CD  * ChamferDistanceLoss(view_to_obj_points(pred, ...), canonical_points)   train.py:158-161
+              + L_SIL     * SilhouetteLoss(primitives, silhouettes; dist 1, elev 0, azim 0)        train.py:169-176
+              + L_VP_DIV  * VPDiverseLoss(translates, view_center_points)                          train.py:185
+              + L_EMD     * sqrt(EarthMoverDistanceLoss(pred, view_center_points, eps, iters)[0]).mean()   train.py:193-195
+
+    with pred = sample_predict_points (train.py:105-120) of params [B,K,10].  Forward: the hot path's three launches
+    (sampler + raster records + Chamfer features, Chamfer scan + tile rider, raster with the loss finalisation), the
+    auction, the object-centred cloud (camera transform, its Chamfer scan), the VP-diversity neighbours, one reduction;
+    backward: ONE launch (vpn_trainstep_bwd).  No ATen kernel runs in either.  `weights` = (L_VIEW_CD, L_CAN_CD, L_SIL,
+    L_VP_DIV, L_EMD) of config.py:13-17; a zero weight skips that term's backward (the reference multiplies it by 0), and
+    L_SIL = 0 skips the render like train.py:167.  Returns six scalars (the five weighted terms, then the total); only the
+    total is differentiable: backward through `out[5]` (the terms are marked non-differentiable)."""
+
+    @staticmethod
+    def forward(ctx, params, kinds, gt_view, gt_canon, gt_sil, dists, elevs, azims, angles, n, seed, sample_base, H, W,
+                weights, eps=0.005, iters=50, advance_seed=False, cd_w1=1.0, cd_w2=1.0, sil_mse=False):
+        from . import config
+        params, gt_view = _f32c(params), _f32c(gt_view)
+        B, K, _ = params.shape
+        M = gt_view.shape[1]
+        N = K * n
+        dev = params.device
+        kinds = kinds_tensor(kinds, dev)
+        w_view, w_can, w_sil, w_div, w_emd = (float(x) for x in weights)
+        cd_w1, cd_w2, sil_mse = float(cd_w1), float(cd_w2), int(bool(sil_mse))
+        L = _lib.lib()
+        s = _lib.stream()
+        seed_host, seed_dev = _seed_args(seed)
+        if advance_seed and seed_dev is None:
+            raise ValueError('advance_seed needs a device seed (a CUDA int64 tensor of one element)')
+        if w_emd and N != M:
+            raise ValueError('the EMD term needs as many predicted as ground-truth points (emd_module.py:36): %d vs %d' % (N, M))
+        if not L.vpn_hotpath_fused_features(B, K, n, M):
+            raise ValueError('TrainStepLossFunction needs a shape the fused sampler / Chamfer path takes (K <= 64, large clouds)')
+        f32 = dict(dtype=torch.float32, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        render = w_sil != 0.0 and gt_sil is not None
+        cam = _view_camera(B, dev)
+        gt_sil = _f32c(gt_sil).reshape(B, H, W) if render else None
+        sigma, gamma, z_far = config.RASTER_SIGMA, config.RASTER_GAMMA, config.RASTER_Z_FAR
+        # the render's buffers exist (tiny) even when the silhouette term is off: the sampler launch writes the records
+        Hr, Wr = (H, W) if render else (16, 16)
+        rec = torch.empty((L.vpn_raster_records_size(B, K, Hr, Wr) // 4,), **f32)
+        lws = torch.empty((L.vpn_raster_loss_workspace(B, Hr, Wr) // 4,), **f32)
+        rws = torch.empty((L.vpn_raster_bwd_workspace(B, K, Hr, Wr) // 4,), **f32)
+        hot = torch.empty((4,), **f32)
+        points = torch.empty((B, N, 3), **f32)
+        cws = torch.empty((L.vpn_chamfer_workspace(B, N, M) // 4,), **f32)
+        d1, d2 = torch.empty((B, N), **f32), torch.empty((B, M), **f32)
+        i1, i2 = torch.empty((B, N), **i32), torch.empty((B, M), **i32)
+        # ---- hot path: sampler (+ records + features) -> view-centred Chamfer (+ tile rider) -> raster + finalisation
+        _lib.call('vpn_hotpath_sample_fwd', _lib.ptr(params), _lib.ptr(kinds), None, seed_host, seed_dev, int(sample_base), B, K, n,
+                  _lib.ptr(points), _lib.ptr(cam), Hr, Wr, float(sigma), _lib.ptr(rec), _lib.ptr(lws), _lib.ptr(gt_view), M,
+                  _lib.ptr(cws), cws.numel() * 4, s)
+        ntile = ((Wr + 15) // 16) * ((Hr + 15) // 16)
+        use_order = render and TILE_ORDER and K <= 64 and ntile <= 16384 and K * 84 + (K + 2) * 4 + ntile <= 24576
+        order = None
+        if use_order:
+            order = torch.empty((L.vpn_raster_order_size(B, Hr, Wr) // 8,), dtype=torch.int64, device=dev)
+            _lib.call('vpn_hotpath_chamfer_fwd', _lib.ptr(points), _lib.ptr(gt_view), B, N, M, _lib.ptr(d1), _lib.ptr(i1), _lib.ptr(d2),
+                      _lib.ptr(i2), _lib.ptr(cws), cws.numel() * 4, 7, _lib.ptr(rec), K, Hr, Wr, _lib.ptr(order), s)
+        else:
+            _lib.call('vpn_chamfer_fwd_ws', _lib.ptr(points), _lib.ptr(gt_view), B, N, M, _lib.ptr(d1), _lib.ptr(i1), _lib.ptr(d2),
+                      _lib.ptr(i2), _lib.ptr(cws), cws.numel() * 4, 7, s)
+        if render:
+            _lib.call('vpn_raster_total_fwd_fin', _lib.ptr(params), _lib.ptr(kinds), _lib.ptr(cam), B, K, H, W, float(sigma), float(gamma),
+                      float(z_far), _lib.ptr(gt_sil), None, sil_mse, w_sil, 0.0, _lib.ptr(rec), _lib.ptr(lws), _lib.ptr(rws), 1,
+                      _lib.ptr(cws), cws.numel() * 4, N, M, cd_w1, cd_w2, w_view, _lib.ptr(hot), None,
+                      seed_dev if advance_seed else None, _lib.ptr(order), s)
+        else:
+            # train.py:167: no render; the Chamfer term alone (H = W = 0: no image losses)
+            _lib.call('vpn_loss_finalize', _lib.ptr(lws), B, 0, 0, _lib.ptr(d1), _lib.ptr(d2), N, M, cd_w1, cd_w2, w_view, 0.0, 0.0,
+                      _lib.ptr(hot), None, s)
+            if advance_seed:
+                raise ValueError('advance_seed rides in the raster launch: it needs the silhouette term (L_SIL != 0)')
+        # ---- EMD auction on the same clouds (train.py:193)
+        emd_dist = emd_assign = None
+        if w_emd:
+            emd_dist = torch.empty((B, N), **f32)
+            emd_assign = torch.empty((B, N), **i32)
+            ews = torch.empty((max(1, L.vpn_emd_workspace(B, N) // 4),), **f32)
+            _lib.call('vpn_emd_fwd', _lib.ptr(points), _lib.ptr(gt_view), B, N, float(eps), int(iters), _lib.ptr(emd_dist),
+                      _lib.ptr(emd_assign), _lib.ptr(ews), 1 if CONCURRENT_BRANCHES else int(os.environ.get('VPN_EMD_GROUP', '0')), s)
+        # ---- object-centred Chamfer (train.py:158-161): computed even at weight 0, like the reference
+        cn = None
+        if gt_canon is not None:
+            gt_canon = _f32c(gt_canon)
+            Mc = gt_canon.shape[1]
+            cam4 = [_f32c(c.reshape(-1)) for c in (dists, elevs, azims, angles)]
+            canon = torch.empty_like(points)
+            _lib.call('vpn_camera_transform_fwd', _lib.ptr(points), _lib.ptr(cam4[0]), _lib.ptr(cam4[1]), _lib.ptr(cam4[2]),
+                      _lib.ptr(cam4[3]), B, N, 1, _lib.ptr(canon), s)
+            cd1, cd2 = torch.empty((B, N), **f32), torch.empty((B, Mc), **f32)
+            ci1, ci2 = torch.empty((B, N), **i32), torch.empty((B, Mc), **i32)
+            ccws = torch.empty((L.vpn_chamfer_workspace(B, N, Mc) // 4,), **f32)
+            _lib.call('vpn_chamfer_fwd_ws', _lib.ptr(canon), _lib.ptr(gt_canon), B, N, Mc, _lib.ptr(cd1), _lib.ptr(ci1), _lib.ptr(cd2),
+                      _lib.ptr(ci2), _lib.ptr(ccws), ccws.numel() * 4, 0, s)
+            mat = None
+            if w_can:
+                mat = torch.empty((B, 9), **f32)
+                _lib.call('vpn_camera_matrix', _lib.ptr(cam4[0]), _lib.ptr(cam4[1]), _lib.ptr(cam4[2]), _lib.ptr(cam4[3]), B, 1,
+                          _lib.ptr(mat), s)
+            cn = (canon, gt_canon, mat, cd1, ci1, cd2, ci2, Mc)
+        # ---- VP-diversity (train.py:185)
+        dv = None
+        if w_div:
+            dv = (torch.empty((B, K), **f32), torch.empty((B, K), **i32), torch.empty((B, M), **f32), torch.empty((B, M), **i32))
+            _lib.call('vpn_vpdiv_fwd', _lib.ptr(params), _lib.ptr(gt_view), B, K, M, _lib.ptr(dv[0]), _lib.ptr(dv[1]), _lib.ptr(dv[2]),
+                      _lib.ptr(dv[3]), s)
+        out = torch.empty((6,), **f32)
+        _lib.call('vpn_trainstep_finalize', _lib.ptr(hot), _lib.ptr(emd_dist), _lib.ptr(cn[3]) if cn else None,
+                  _lib.ptr(cn[5]) if cn else None, _lib.ptr(dv[0]) if dv else None, _lib.ptr(dv[2]) if dv else None, B, N, M,
+                  cn[7] if cn else 0, K, w_view, w_can, w_sil if render else 0.0, w_div, w_emd, cd_w1, cd_w2, _lib.ptr(out), s)
+        ctx.meta = (B, K, n, M, H, W, seed_host, int(sample_base), cd_w1, cd_w2, w_view, w_can, w_div, w_emd, render,
+                    seed_dev is not None, cn[7] if cn else 0)
+        # the sampler's launch keeps the seed it used at loss_ws + 8: backward reads it from there
+        ctx.tensors = dict(params=params, kinds=kinds, cam=cam, gt_view=gt_view, points=points, d1=d1, i1=i1, d2=d2, i2=i2, rec=rec,
+                           rws=rws, lws=lws, emd_dist=emd_dist, emd_assign=emd_assign, dv=dv, cn=cn if (cn and w_can) else None)
+        terms = out.unbind(0)
+        ctx.mark_non_differentiable(*terms[:5])
+        ctx.set_materialize_grads(False)       # no zero-filled gradients for the five reported terms
+        return terms
+
+    @staticmethod
+    def backward(ctx, _g0, _g1, _g2, _g3, _g4, grad_total):
+        t = ctx.tensors
+        if grad_total is None:
+            return (None,) * 21
+        (B, K, n, M, H, W, seed_host, base, cd_w1, cd_w2, w_view, w_can, w_div, w_emd, render, has_seed_dev, Mc) = ctx.meta
+        N = K * n
+        p = _lib.ptr
+        g = _f32c(grad_total).reshape(1)
+        grad_params = torch.empty_like(t['params'])
+        seed_dev = ctypes.c_void_p(t['lws'].data_ptr() + 8) if has_seed_dev else None
+        dv, cn = t['dv'], t['cn']
+        _lib.call('vpn_trainstep_bwd', p(t['params']), p(t['kinds']), 0 if has_seed_dev else seed_host, seed_dev, base, B, K, n,
+                  p(t['points']), p(t['gt_view']), M, p(t['d1']), p(t['i1']), p(t['d2']), p(t['i2']),
+                  cd_w1 * w_view / B, cd_w2 * w_view / B, p(t['cam']), H, W, p(t['rec']) if render else None,
+                  p(t['rws']) if render else None, p(g),
+                  p(t['emd_dist']) if w_emd else None, p(t['emd_assign']) if w_emd else None, w_emd / (B * N),
+                  p(dv[0]) if dv else None, p(dv[1]) if dv else None, p(dv[2]) if dv else None, p(dv[3]) if dv else None,
+                  w_div * 0.5 / (K * B), w_div * 1.0 / (M * B),
+                  p(cn[0]) if cn else None, p(cn[1]) if cn else None, p(cn[2]) if cn else None, p(cn[3]) if cn else None,
+                  p(cn[4]) if cn else None, p(cn[5]) if cn else None, p(cn[6]) if cn else None,
+                  (w_can * cd_w1 / (N * B)) if cn else 0.0, (w_can * cd_w2 / (Mc * B)) if cn else 0.0, Mc if cn else 0,
+                  p(grad_params), _lib.stream())
+        return (grad_params,) + (None,) * 20
