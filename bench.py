@@ -558,6 +558,38 @@ def main():
         dts = float(tmax)
     steady = {'prelude_steps': 200, 'steps': 200, 'ms_per_step': round(dts / 200 * 1e3, 4), 'value': round(Bg * 200 / dts, 1),
               'unit': 'images/s', 'note': 'same step and brackets as `value`, after the clocks have settled'}
+    # ---- N>1: what the process group really is and what the exchange costs, so that a SCALE record can be checked without
+    # trusting the `parallelism` string: the group's own backend / world size, the RCCL version, every rank's device name,
+    # and per-step device time of the compute part and of the collective (hipEvent pairs on the launch stream around each
+    # of them; median over the steps, maximum over the ranks)
+    dist_info = None
+    if multi:
+        comp_ev, coll_ev = [], []
+        for i in range(max(5, min(args.steps, 50))):
+            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            e0.record()
+            if use_graph:
+                graph.replay()
+            else:
+                g_loss = compute(i)
+                reducer.pack(params.grad, g_loss)
+            e1.record()
+            comm()
+            e2.record()
+            comp_ev.append((e0, e1)); coll_ev.append((e1, e2))
+        torch.cuda.synchronize()
+        med = lambda evs: statistics.median(a.elapsed_time(b) for a, b in evs) * 1e3
+        tt = torch.tensor([med(comp_ev), med(coll_ev)], device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        names = [None] * world
+        dist.all_gather_object(names, '%s (rank %d, local device %d)' % (torch.cuda.get_device_name(dev), rank, local_rank))
+        try:
+            ver = '.'.join(str(x) for x in torch.cuda.nccl.version())
+        except Exception as e:                  # noqa: BLE001 -- reported in place of the version
+            ver = 'unavailable: %s' % type(e).__name__
+        dist_info = {'backend': dist.get_backend(), 'world_size': dist.get_world_size(), 'rccl_version': ver,
+                     'device_names': names, 'compute_us': round(float(tt[0]), 2), 'collective_us': round(float(tt[1]), 2),
+                     'collective': args.collective, 'rehearsal': bool(args.rehearse)}
     seed_after = int(seed_buf.item())
 
     # ---- device time per C-ABI entry point and per KERNEL (HIP events on the launch stream, recorded by the
@@ -694,6 +726,8 @@ def main():
             'roofline': roofline, 'raster_roofline': raster_roof, 'kernel_us': kernel_us, 'entry_us': entry_us,
         }
         assert 0.0 < roofline['frac'] <= 1.0, 'roofline.frac must be a fraction: %r' % (roofline,)
+        if dist_info is not None:
+            out['dist'] = dist_info
         if step_hbm is not None:
             out['step_hbm'] = step_hbm
             roofline['step_hbm_frac'] = step_hbm['frac']

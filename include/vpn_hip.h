@@ -373,14 +373,16 @@ int vpn_head_pack_bwd(const float* volumes, const float* rotates, const float* t
  *   - the object-centred Chamfer term through cn_mat [B,9] (cn_points = the transformed cloud, cn_gt [B,cn_M,3],
  *     its four nearest-neighbour arrays): cn_c1 = L_CAN_CD * cd_w1 / (N B), cn_c2 = L_CAN_CD * cd_w2 / (cn_M B).
  *   A group whose first pointer is NULL is skipped (the reference's default L_CAN_CD = 0 multiplies that gradient by 0). */
+size_t vpn_vpdiv_workspace(int B, int K);          /* scratch of vpn_vpdiv_fwd (8-byte aligned) */
 int vpn_vpdiv_fwd(const float* params, const float* gt_points, int B, int K, int M, float* dist1, int32_t* idx1,
-                  float* dist2, int32_t* idx2, void* stream);
+                  float* dist2, int32_t* idx2, void* workspace, void* stream);
 int vpn_camera_matrix(const float* dists, const float* elevs, const float* azims, const float* angles, int B,
                       int to_object, float* mat, void* stream);
+size_t vpn_trainstep_workspace(int B);             /* scratch of vpn_trainstep_finalize (per-sample sums) */
 int vpn_trainstep_finalize(const float* hot_losses, const float* emd_dist, const float* cn_dist1, const float* cn_dist2,
                            const float* dv_dist1, const float* dv_dist2, int B, int N, int M, int Mc, int K,
                            float w_view, float w_can, float w_sil, float w_div, float w_emd, float cd_w1, float cd_w2,
-                           float* out, void* stream);
+                           void* workspace, float* out, void* stream);
 int vpn_trainstep_bwd(const float* params, const int32_t* kinds, uint64_t seed, const uint64_t* seed_dev,
                       uint64_t sample_base, int B, int K, int n, const float* points, const float* gt_points, int M,
                       const float* dist1, const int32_t* idx1, const float* dist2, const int32_t* idx2,

@@ -63,3 +63,31 @@ def hit_box(eye, d, v, q, t):
     lo = torch.minimum(s1, s2).max(-1)[0]
     hi = torch.maximum(s1, s2).min(-1)[0]
     return hi - lo, lo
+
+
+def uv_sphere_386(radius=1.0):
+    """The topology of the reference's 386.obj (train_sphere.py:53): a UV sphere of 16 rings x 24 segments plus the two
+    poles = 386 vertices, 2 x 24 cap triangles + 15 x 24 x 2 = 768 faces; a closed surface."""
+    import math
+    rings, seg = 16, 24
+    vs = [[0.0, radius, 0.0]]
+    for r in range(rings):
+        th = math.pi * (r + 1) / (rings + 1)
+        for s_ in range(seg):
+            ph = 2.0 * math.pi * s_ / seg
+            vs.append([radius * math.sin(th) * math.cos(ph), radius * math.cos(th), radius * math.sin(th) * math.sin(ph)])
+    vs.append([0.0, -radius, 0.0])
+    south = len(vs) - 1
+    fs = []
+    for s_ in range(seg):
+        fs.append([0, 1 + (s_ + 1) % seg, 1 + s_])
+        base = 1 + (rings - 1) * seg
+        fs.append([south, base + s_, base + (s_ + 1) % seg])
+    for r in range(rings - 1):
+        for s_ in range(seg):
+            a, b = 1 + r * seg + s_, 1 + r * seg + (s_ + 1) % seg
+            c, d = a + seg, b + seg
+            fs += [[a, b, c], [b, d, c]]
+    v, f = torch.tensor(vs, dtype=torch.float32), torch.tensor(fs, dtype=torch.int64)
+    assert v.shape == (386, 3) and f.shape == (768, 3)
+    return v, f

@@ -55,3 +55,16 @@ def test_under_a_launcher_no_respawn():
     src = open(os.path.join(ROOT, 'bench.py')).read()
     assert "'WORLD_SIZE' not in os.environ and args.gpus > 1" in src
     assert 'os.exec' not in src
+
+
+def test_multi_rank_line_is_self_checking():
+    """the N>1 line carries `dist` = what the process group itself reports (backend, world size,
+    RCCL version, every rank's device) and hipEvent-timed compute / collective microseconds.  The code path needs a GPU to
+    run (tests/test_dist_gpu.py rehearses it); here: the record is built from the group's own queries, not from arguments."""
+    src = open(os.path.join(ROOT, 'bench.py')).read()
+    blk = src[src.index('dist_info = {'):src.index('dist_info = {') + 600]
+    for key in ("'backend': dist.get_backend()", "'world_size': dist.get_world_size()", "'rccl_version'", "'device_names'",
+                "'compute_us'", "'collective_us'"):
+        assert key in blk, key
+    assert "out['dist'] = dist_info" in src
+    assert 'dist.all_gather_object(names' in src and 'torch.cuda.nccl.version()' in src

@@ -10,6 +10,7 @@ import pytest
 import torch
 
 from conftest import rel_err
+from geom_util import uv_sphere_386
 from oracle import vpn_oracle as O
 
 DEV = 'cuda'
@@ -131,7 +132,8 @@ def test_mesh_raster_vs_oracle(vpn, B, P, F, H, W, sigma, camrow):
     from vpn_amd.ops import MeshRasterFunction, faces_i32
     gen = torch.Generator().manual_seed(P + F)
     if P == 386:
-        v, f = icosphere(2, 0.3)                                       # 162 vertices, 320 faces: a closed surface
+        v, f = uv_sphere_386(0.3)                                      # 386 vertices, 768 faces: the topology of 386.obj
+        assert v.shape[0] == P and f.shape[0] == F
         v, f = v[None].repeat(B, 1, 1) + 0.02 * torch.randn(B, v.shape[0], 3, generator=gen), f
     else:
         vf = [_random_mesh(gen, P, F) for _ in range(B)]
@@ -150,7 +152,9 @@ def test_mesh_raster_vs_oracle(vpn, B, P, F, H, W, sigma, camrow):
     assert float((a.detach().cpu() - ref[torch.float64][0]).abs().max()) <= 2e-5          # alpha is in [0,1]
     e_cpu = rel_err(ref[torch.float32][1], ref[torch.float64][1])
     e_gpu = rel_err(vg.grad.cpu(), ref[torch.float64][1])
-    assert e_gpu <= max(1e-4, 2 * e_cpu), (e_gpu, e_cpu)
+    # 1e-4 against the fp64 truth; the fp32 oracle's own distance from it may only widen the bound when it is itself
+    # beyond 5e-5 (its rounding noise then eats half the budget), and never past 3e-4
+    assert e_gpu <= (1e-4 if e_cpu <= 5e-5 else min(2 * e_cpu, 3e-4)), (e_gpu, e_cpu)
     # linear in the upstream gradient, finite
     vg2 = v.to(DEV).requires_grad_(True)
     a2 = MeshRasterFunction.apply(vg2, faces_i32(f, torch.device(DEV)), cam.to(DEV), H, W, sigma)
@@ -318,4 +322,84 @@ def test_mesh_lists_of_mixed_topology_and_a_large_mesh(vpn):
     a = O.mesh_raster(vc, faces.cpu(), torch.tensor([[1.0, 0.0, 0.0]]), 64, 64, vpn.config.MESH_RASTER_SIGMA)
     a.abs().mean().backward()
     assert abs(float(loss.detach()) - float(a.detach().mean())) / float(a.detach().mean()) <= 1e-4
-    assert rel_err(big.vertices.grad.cpu(), vc.grad[0]) <= 2e-4
+    assert rel_err(big.vertices.grad.cpu(), vc.grad[0]) <= 1e-4
+
+
+@pytest.mark.gpu
+def test_module_path_does_not_synchronise_with_the_host(vpn, tmp_path):
+    """no host sync inside ops.  Both call patterns of the reference under torch's sync debug mode ('error': any
+    device-to-host wait raises): (a) train.py:122-149,176 -- B lists of K Meshing-made meshes, composed, handed to
+    SilhouetteLoss; (b) train_sphere.py:50-128 -- B spheres loaded from an OBJ file with 386.obj's topology, moved to the
+    device, deformed in place, sampled, rendered.  The first step may fill the host-side registries (kinds, face
+    fingerprints); the second step, on FRESH meshes as every training step makes them, must not wait once."""
+    dev = torch.device(DEV)
+    gen = torch.Generator().manual_seed(2)
+    B, K, H = 4, 3, 64
+    gt = (torch.rand(B, 1, H, H, generator=gen) > 0.5).float().to(dev)
+    dists, elevs, azims = torch.ones(B, device=dev), torch.zeros(B, device=dev), torch.zeros(B, device=dev)
+    loss_fn = vpn.SilhouetteLoss()
+
+    def step_a():
+        v = [((torch.rand(B, 3, generator=gen) + 0.1) / 8).to(dev).requires_grad_(True) for _ in range(K)]
+        q = [torch.rand(B, 4, generator=gen).to(dev) for _ in range(K)]
+        t = [(0.3 * (torch.rand(B, 3, generator=gen) * 2 - 1)).to(dev) for _ in range(K)]
+        return v, q, t
+
+    def run_a(v, q, t):
+        per_sample = [[] for _ in range(B)]
+        for k in range(K):                                              # train.py:122-140
+            meshes = (vpn.Meshing.cuboid_meshing if k == 0 else vpn.Meshing.sphere_meshing)(v[k], q[k], t[k])
+            for b in range(B):
+                per_sample[b].append(meshes[b])
+        composed = [vpn.Meshing.compose_meshes(m) for m in per_sample]  # train.py:143-149
+        loss = loss_fn(composed, gt, dists, elevs, azims)                # train.py:176
+        loss.backward()
+        return loss
+
+    obj = tmp_path / 'sphere386.obj'
+    sv, sf = uv_sphere_386(0.3)
+    obj.write_text(''.join('v %f %f %f\n' % tuple(p) for p in sv.tolist()) + ''.join('f %d %d %d\n' % tuple(i + 1 for i in f) for f in sf.tolist()))
+
+    def load_b():
+        return [vpn.TriangleMesh.from_obj(str(obj)).cuda() for _ in range(B)], (0.01 * torch.randn(B, 386, 3, generator=gen)).to(dev).requires_grad_(True)
+
+    def run_b(meshes, offset):
+        for b in range(B):
+            meshes[b].vertices += offset[b]                             # train_sphere.py:62-68
+        pts = torch.stack([m.sample(256)[0] for m in meshes])           # train_sphere.py:76
+        loss = loss_fn(meshes, gt, dists, elevs, azims) + pts.square().mean()
+        loss.backward()
+        return loss
+
+    run_a(*step_a())                                                    # warm-up: registries, templates, allocator
+    run_b(*load_b())
+    args_a, args_b = step_a(), load_b()                                 # host-to-device copies happen outside the strict region
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode('error')
+    try:
+        la = run_a(*args_a)
+        lb = run_b(*args_b)
+    finally:
+        torch.cuda.set_sync_debug_mode('default')
+    assert bool(torch.isfinite(la)) and bool(torch.isfinite(lb))
+
+
+@pytest.mark.gpu
+def test_face_cache_is_keyed_by_content_not_by_address(vpn):
+    """the int32 face copy used to be cached under (data_ptr, version, numel); a freed int64 face tensor's
+    address is handed to the next one of the same size, which then rendered with the PREVIOUS topology."""
+    from vpn_amd.ops import faces_i32
+    dev = torch.device(DEV)
+    v, f = uv_sphere_386(0.3)
+    vd = v.to(dev)
+    cam = (torch.ones(1), torch.zeros(1), torch.zeros(1))
+    f1 = f.to(dev)
+    ptr = f1.data_ptr()
+    _, a1, _ = vpn.VertexRenderer.render(vpn.TriangleMesh(vd, f1), *cam, image_size=(64, 64))
+    a1 = a1.clone()
+    del f1
+    f2 = f[: f.shape[0] // 2].repeat(2, 1).to(dev)                      # same shape, half the sphere twice
+    same_address = f2.data_ptr() == ptr                                 # what the caching allocator normally does
+    _, a2, _ = vpn.VertexRenderer.render(vpn.TriangleMesh(vd, f2), *cam, image_size=(64, 64))
+    assert torch.equal(faces_i32(f2, dev).cpu().long(), f2.cpu()), 'stale face copy (same address: %s)' % same_address
+    assert float((a1 - a2).abs().max()) > 0.5                           # half the sphere is missing

@@ -62,9 +62,11 @@ SIGNATURES = {
     'vpn_mesh_sample_bwd': (_i, [_c_f, _c_f, _c_f, _c_f, _i, _i, _i, _i, _c_f, _c_f]),
     'vpn_head_pack_fwd': (_i, [_c_f, _c_f, _c_f, _i, _i, _i, _f, _f, _f, _f, _f, _c_f, _c_f]),
     'vpn_head_pack_bwd': (_i, [_c_f, _c_f, _c_f, _c_f, _i, _i, _i, _f, _f, _f, _f, _f, _c_f, _c_f, _c_f, _c_f]),
-    'vpn_vpdiv_fwd': (_i, [_c_f, _c_f, _i, _i, _i, _c_f, _c_f, _c_f, _c_f, _c_f]),
+    'vpn_vpdiv_workspace': (_sz, [_i, _i]),
+    'vpn_vpdiv_fwd': (_i, [_c_f, _c_f, _i, _i, _i, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f]),
+    'vpn_trainstep_workspace': (_sz, [_i]),
     'vpn_camera_matrix': (_i, [_c_f, _c_f, _c_f, _c_f, _i, _i, _c_f, _c_f]),
-    'vpn_trainstep_finalize': (_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _c_f, _c_f]),
+    'vpn_trainstep_finalize': (_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _c_f, _c_f, _c_f]),
     'vpn_trainstep_bwd': (_i, [_c_f, _c_f, _u64, _c_f, _u64, _i, _i, _i, _c_f, _c_f, _i, _c_f, _c_f, _c_f, _c_f, _f, _f, _c_f, _i, _i,
                                _c_f, _c_f, _c_f, _c_f, _c_f, _f, _c_f, _c_f, _c_f, _c_f, _f, _f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f,
                                _f, _f, _i, _c_f, _c_f]),

@@ -195,7 +195,6 @@ struct Tile {
     int b, tile, c0, r0;
     int colq[2], rowq[2];       // this lane's column in quadrant column 0 / 1, row in quadrant row 0 / 1
     float pxq[2], pyq[2];
-    bool valid;
     __device__ int col(int s) const { return colq[s & 1]; }
     __device__ int row(int s) const { return rowq[s >> 1]; }
     __device__ float px(int s) const { return pxq[s & 1]; }
@@ -226,7 +225,6 @@ __device__ inline Tile make_tile(int H, int W, int tiles_x, int tiles_y, int B, 
         const int t = min(tile_of_entry, tiles_x * tiles_y - 1);
         ty = t / tiles_x; tx = t - ty * tiles_x;
     }
-    T.valid = true;
     T.tile = ty * tiles_x + tx;
     T.c0 = tx * R_TW; T.r0 = ty * R_TH;
 #pragma unroll
@@ -505,6 +503,18 @@ __device__ inline unsigned long long tile_forward(const Tile& T, const float4* _
 // exactly those.  No atomics: bitwise reproducible.  `staged`: srec already holds the records of mask word 0 = m0
 // (one-pass kernel with K <= 64); mrow: the tile's mask words (stored by an earlier launch, or by this wave's lane 0 in
 // its forward half: stage_word takes lane 0's value), or null to repeat the test.
+// -DR_DEBUG_LIN (tools/raster_linearity_check.py): for ONE chosen (image, primitive, tile) every lane's twelve sums before
+// the wave reduction and, per lane and pixel slot, the backward's intermediates -- to find the operation in which doubling
+// the incoming gradient is not exact
+#ifdef R_DEBUG_LIN
+struct RasterDebugLin { int b, k, tile; float* buf; };
+__device__ RasterDebugLin g_dbg_lin = {-1, -1, -1, nullptr};
+extern "C" int vpn_debug_raster_lin(int b, int k, int tile, float* buf) {
+    RasterDebugLin h{b, k, tile, buf};
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_lin), &h, sizeof(h));
+}
+#endif
+
 __device__ inline void tile_backward(const Tile& T, const float4* __restrict__ rec_b, const unsigned long long* __restrict__ mrow,
                                      int words, int K, int ntile, int H, int W, float4* srec, bool staged,
                                      unsigned long long m0, float inv_sigma,
@@ -541,6 +551,13 @@ __device__ inline void tile_backward(const Tile& T, const float4* __restrict__ r
                     const float gm2 = -gx * inv_sigma;
                     float go[3], gd[3];
                     prim_backward<KIND>(q0, q, gz, gm2, go, gd);
+#ifdef R_DEBUG_LIN
+                    if (g_dbg_lin.buf && T.b == g_dbg_lin.b && k == g_dbg_lin.k && T.tile == g_dbg_lin.tile) {
+                        float* o = g_dbg_lin.buf + 64 * 16 + (lane * R_PPL + s) * 16;
+                        o[0] = gw; o[1] = gz; o[2] = ga; o[3] = gx; o[4] = gm2; o[5] = go[0]; o[6] = go[1]; o[7] = go[2];
+                        o[8] = gd[0]; o[9] = gd[1]; o[10] = gd[2]; o[11] = q.wgt; o[12] = q.E; o[13] = q.a; o[14] = gAtot[s]; o[15] = gZbar[s];
+                    }
+#endif
                     v[0] += go[0]; v[1] += go[1]; v[2] += go[2];
                     v[3] += T.px(s) * gd[0]; v[4] += T.px(s) * gd[1]; v[5] += T.px(s) * gd[2];
                     v[6] += T.py(s) * gd[0]; v[7] += T.py(s) * gd[1]; v[8] += T.py(s) * gd[2];
@@ -549,6 +566,10 @@ __device__ inline void tile_backward(const Tile& T, const float4* __restrict__ r
             };
             if (__builtin_amdgcn_readfirstlane(__float_as_int(q0.w)) == VPN_SPHERE) body(std::integral_constant<int, VPN_SPHERE>{});
             else body(std::integral_constant<int, VPN_CUBOID>{});
+#ifdef R_DEBUG_LIN
+            if (g_dbg_lin.buf && T.b == g_dbg_lin.b && k == g_dbg_lin.k && T.tile == g_dbg_lin.tile)
+                for (int i = 0; i < 12; ++i) g_dbg_lin.buf[lane * 16 + i] = v[i];
+#endif
 #ifdef R_REDUCE_BUTTERFLY
             const float tot = wave_reduce16(v);
 #else
@@ -569,7 +590,6 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(const float4* __restrict
                                                          float z_far, float* __restrict__ alpha,
                                                          float* __restrict__ depth, float* __restrict__ aux, LossArgs la) {
     const Tile T = make_tile(H, W, tiles_x, tiles_y, B);
-    if (!T.valid) return;
     const int ntile = tiles_x * tiles_y, lane = threadIdx.x & 63;
     const float vz0 = __int_as_float(vzero());
     const float inv_sigma = 1.0f / (sigma + vz0), inv_gamma = 1.0f / (gamma + vz0), zref = cam[T.b * 3] + vz0;
@@ -620,7 +640,6 @@ __global__ __launch_bounds__(64, 4) void raster_bwd_kernel(const float4* __restr
                                                          const float* __restrict__ gdepth,
                                                          float* __restrict__ partial, LossArgs la) {
     const Tile T = make_tile(H, W, tiles_x, tiles_y, B);
-    if (!T.valid) return;
     const int ntile = tiles_x * tiles_y;
     const unsigned long long* mrow = masks + ((size_t)T.b * ntile + T.tile) * words;
     const float vz0 = __int_as_float(vzero());
@@ -715,7 +734,6 @@ __global__ __launch_bounds__(64, ENT ? R_ENT_WAVES : R_TOTAL_WAVES) void raster_
         e1q = e1; e2q = e2;
     }
     const Tile T = make_tile(H, W, tiles_x, tiles_y, B, tile_of_entry);
-    if (!T.valid) return;
     const float4* rec_b = rec + (size_t)T.b * K * R_REC;
     unsigned long long* mrow = masks + ((size_t)T.b * ntile + T.tile) * words;
     const float vz0 = __int_as_float(vzero());           // +0.0f in a VGPR: keeps the loop's uniform scalars out of SGPRs

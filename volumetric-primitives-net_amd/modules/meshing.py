@@ -49,10 +49,19 @@ class TriangleMesh:
     def from_obj(cls, path):
         return cls(*load_obj(path))
 
+    def faces_key(self):
+        """Content key of the face tensor (ops.faces_fingerprint): computed on the host tensor when there is one."""
+        from ..ops import faces_fingerprint
+        return faces_fingerprint(self.faces)
+
     def to(self, device):
+        from ..ops import faces_fingerprint, faces_remember
         moved = self.vertices.to(device)
         keep = self.primitives if moved is self.vertices else None
-        self.vertices, self.faces = moved, self.faces.to(device)
+        faces = self.faces.to(device)
+        if faces is not self.faces and not self.faces.is_cuda:
+            faces_remember(faces, faces_fingerprint(self.faces))       # hashed on the host: the device copy is never read back
+        self.vertices, self.faces = moved, faces
         self._primitives = keep
         self._stamp = (self.vertices, self.vertices._version) if keep is not None else None
         return self
@@ -150,6 +159,7 @@ def unit_box(n=5):
 
 class Meshing:
     _templates = {}          # (kind, device) -> (vertices, faces) on that device
+    _layouts = {}            # (kinds, device) -> (vertex offsets [K+1] int32, composed faces, total vertices)
     _sources = {SPHERE: None, CUBOID: None}
 
     def __init__(self):
@@ -160,6 +170,7 @@ class Meshing:
         """Use OBJ templates (e.g. the reference's modules/meshing/objects/sphere.obj / cuboid.obj)."""
         cls._sources = {SPHERE: sphere_obj, CUBOID: cuboid_obj}
         cls._templates = {}
+        cls._layouts = {}
 
     @classmethod
     def template(cls, kind, device):
@@ -179,19 +190,25 @@ class Meshing:
     def mesh_primitives(cls, params, kinds):
         """All K primitives of all B samples in one launch: params (B,K,10), kinds list ->
         vertices (B, P_total, 3) (differentiable) and the faces (F_total, 3) of the composed mesh."""
-        kinds = [int(k) for k in (kinds.tolist() if isinstance(kinds, torch.Tensor) else kinds)]
+        from ..ops import kinds_host
+        kinds = tuple(int(k) for k in (kinds_host(kinds) if isinstance(kinds, torch.Tensor) and kinds.is_cuda else
+                                       (kinds.tolist() if isinstance(kinds, torch.Tensor) else kinds)))
         dev = params.device
         tpl = {k: cls.template(k, dev) for k in set(kinds)}
-        offsets, faces = [0], []
-        for k in kinds:
-            v, f = tpl[k]
-            faces.append(f + offsets[-1])                       # meshing.py:38-39
-            offsets.append(offsets[-1] + v.shape[0])
-        off = torch.tensor(offsets, dtype=torch.int32, device=dev)
+        # vertex offsets and the composed face list depend on the kind list only: built once per (kinds, device) -- a host
+        # list turned into a device tensor is a synchronising copy, and this runs every training step
+        key = (kinds, str(dev))
+        if key not in cls._layouts:
+            offsets, faces = [0], []
+            for k in kinds:
+                v, f = tpl[k]
+                faces.append(f + offsets[-1])                   # meshing.py:38-39
+                offsets.append(offsets[-1] + v.shape[0])
+            cls._layouts[key] = (torch.tensor(offsets, dtype=torch.int32, device=dev), torch.cat(faces), offsets[-1])
+        off, faces, ptot = cls._layouts[key]
         verts = MeshFunction.apply(params, kinds_tensor(kinds, dev), off,
-                                   tpl[SPHERE][0] if SPHERE in tpl else None, tpl[CUBOID][0] if CUBOID in tpl else None,
-                                   offsets[-1])
-        return verts, torch.cat(faces)
+                                   tpl[SPHERE][0] if SPHERE in tpl else None, tpl[CUBOID][0] if CUBOID in tpl else None, ptot)
+        return verts, faces
 
     @classmethod
     def _one_kind(cls, v, q, t, kind):
@@ -226,7 +243,9 @@ class Meshing:
         packs = [getattr(m, 'primitives', None) for m in meshes]
         prims = None
         if all(p is not None for p in packs):                   # K single-primitive packs -> one [1,K,10] pack
-            prims = PrimitivePack(torch.cat([p.params for p in packs], 1), torch.cat([p.kinds for p in packs]))
+            from ..ops import kinds_host
+            kinds = [k for p in packs for k in kinds_host(p.kinds)]          # host tuples: no device round trip per mesh
+            prims = PrimitivePack(torch.cat([p.params for p in packs], 1), kinds)
         return TriangleMesh.from_tensors(vertices=torch.cat(vertices), faces=torch.cat(faces), primitives=prims)
 
     @staticmethod

@@ -59,8 +59,10 @@ class VertexRenderer:
         cam = torch.stack([_as_batch(dist, B, dev), _as_batch(elev, B, dev), _as_batch(azim, B, dev)], 1)
         out = [None] * B
         for idx, verts, faces in batches:
-            sel = torch.tensor(idx, device=dev)
-            a = MeshRasterFunction.apply(verts, faces_i32(faces, dev), cam[sel].contiguous(), H, W, cls.mesh_sigma)
+            # one topology (train_sphere.py: B copies of 386.obj): the whole camera tensor; otherwise rows picked as views
+            # (an index tensor made from a host list would be a synchronising copy)
+            cam_g = cam if idx == list(range(B)) else torch.stack([cam[i] for i in idx])
+            a = MeshRasterFunction.apply(verts, faces_i32(faces, dev), cam_g.contiguous(), H, W, cls.mesh_sigma)
             for j, i in enumerate(idx):
                 out[i] = a[j]
         return torch.stack(out), batches

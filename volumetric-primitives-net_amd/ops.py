@@ -25,20 +25,13 @@ def _f32c(t):
 
 import weakref
 
-# device kind tensors whose contents have been validated: id(tensor) -> (weak reference to it, the version counter it
-# had then).  The entry dies with its tensor (weakref callback) and a hit also requires the reference to be the same
-# object, so a later tensor that reuses the id or the device address is never mistaken for a validated one.
-_KINDS_OK = {}
-
-
-def _kinds_known(t):
-    hit = _KINDS_OK.get(id(t))
-    return hit is not None and hit[0]() is t and hit[1] == t._version
-
-
-def _kinds_remember(t):
-    key = id(t)
-    _KINDS_OK[key] = (weakref.ref(t, lambda _r, key=key: _KINDS_OK.pop(key, None)), t._version)
+# Host copies of device kind tensors: id(tensor) -> (weak reference to it, the version counter it had then, the kinds as a
+# tuple).  The entry dies with its tensor (weakref callback) and a hit also requires the reference to be the same object, so
+# a later tensor that reuses the id or the device address is never mistaken for a known one.  Kind tensors made from a
+# host list are cached per (kinds, device): the list train.py:112-116 implies is the same every step, and the B composed
+# meshes of a batch share ONE tensor -- equality checks and validation then never touch the device.
+_KINDS_HOST = {}
+_KINDS_BY_TUPLE = {}
 
 
 def _check_kinds(kinds):
@@ -47,23 +40,43 @@ def _check_kinds(kinds):
                          'in the reference either)' % (kinds,))
 
 
+def _kinds_remember(t, tup):
+    key = id(t)
+    _KINDS_HOST[key] = (weakref.ref(t, lambda _r, key=key: _KINDS_HOST.pop(key, None)), t._version, tup)
+
+
+def kinds_host(t):
+    """The kinds of a device kind tensor as a host tuple: from the registry, or -- the first time this (tensor, version) is
+    seen -- through one device-to-host copy, which also validates them."""
+    hit = _KINDS_HOST.get(id(t))
+    if hit is not None and hit[0]() is t and hit[1] == t._version:
+        return hit[2]
+    tup = tuple(int(k) for k in t.detach().cpu().tolist())
+    _check_kinds(tup)
+    _kinds_remember(t, tup)
+    return tup
+
+
 def kinds_tensor(kinds, device):
-    """int32 device tensor of primitive kinds; rejects cones (sampling.py:39-45 is `pass`).  A tensor already on
-    the device is validated once per (tensor object, version) -- one host copy the first time: kind tensors are made
-    once per run -- so that an unknown kind never reaches a kernel."""
+    """int32 device tensor of primitive kinds; rejects cones (sampling.py:39-45 is `pass`).  A tensor already on the
+    device is validated once per (tensor object, version) -- one host copy the first time -- so that an unknown kind never
+    reaches a kernel; a host list maps to one cached tensor per (list, device)."""
     device = torch.device(device)
     if isinstance(kinds, torch.Tensor):
         if kinds.device.type == device.type and kinds.dtype == torch.int32 and kinds.is_contiguous():
-            if not _kinds_known(kinds):
-                _check_kinds(kinds.detach().cpu().tolist())
-                _kinds_remember(kinds)
+            kinds_host(kinds)
             return kinds
         kinds = kinds.detach().cpu().tolist()
-    kinds = [int(k) for k in kinds]
-    _check_kinds(kinds)
-    t = torch.tensor(kinds, dtype=torch.int32, device=device)
-    if t.is_cuda:
-        _kinds_remember(t)
+    tup = tuple(int(k) for k in kinds)
+    _check_kinds(tup)
+    if device.type == 'cuda' and device.index is None:
+        device = torch.device('cuda', torch.cuda.current_device())
+    key = (tup, str(device))
+    t = _KINDS_BY_TUPLE.get(key)
+    if t is None:
+        t = torch.tensor(tup, dtype=torch.int32, device=device)
+        _KINDS_BY_TUPLE[key] = t
+        _kinds_remember(t, tup)
     return t
 
 
@@ -171,14 +184,33 @@ class MeshFunction(Function):
 
 
 _FACES = {}
+_FACES_FP = {}
+
+
+def faces_fingerprint(faces):
+    """Content key of a face tensor: (shape, hash of its bytes), computed once per (tensor object, version).  Free for a
+    host tensor; one device-to-host copy for a device tensor that is seen for the first time (TriangleMesh.to carries the
+    key of the host tensor over, so meshes loaded from OBJ files never pay it)."""
+    hit = _FACES_FP.get(id(faces))
+    if hit is not None and hit[0]() is faces and hit[1] == faces._version:
+        return hit[2]
+    host = faces.detach().cpu().contiguous()
+    fp = (tuple(host.shape), str(host.dtype), hash(host.numpy().tobytes()))
+    faces_remember(faces, fp)
+    return fp
+
+
+def faces_remember(faces, fp):
+    key = id(faces)
+    _FACES_FP[key] = (weakref.ref(faces, lambda _r, key=key: _FACES_FP.pop(key, None)), faces._version, fp)
 
 
 def faces_i32(faces, device):
-    """[F,3] int32 contiguous device copy of a face tensor (the reference's are int64: meshing.py:38-39), converted once
-    per (storage, version)."""
+    """[F,3] int32 contiguous device copy of a face tensor (the reference's are int64: meshing.py:38-39), one per CONTENT
+    and device: keyed by the fingerprint, never by an address the allocator may hand to another tensor."""
     if faces.dtype == torch.int32 and faces.is_cuda and faces.is_contiguous():
         return faces
-    key = (faces.data_ptr(), faces._version, faces.numel(), str(faces.device), str(device))
+    key = (faces_fingerprint(faces), str(torch.device(device)))
     hit = _FACES.get(key)
     if hit is None:
         if len(_FACES) > 256:
@@ -849,12 +881,14 @@ class TrainStepLossFunction(Function):
         dv = None
         if w_div:
             dv = (torch.empty((B, K), **f32), torch.empty((B, K), **i32), torch.empty((B, M), **f32), torch.empty((B, M), **i32))
+            dws = torch.empty((L.vpn_vpdiv_workspace(B, K) // 8,), dtype=torch.int64, device=dev)
             _lib.call('vpn_vpdiv_fwd', _lib.ptr(params), _lib.ptr(gt_view), B, K, M, _lib.ptr(dv[0]), _lib.ptr(dv[1]), _lib.ptr(dv[2]),
-                      _lib.ptr(dv[3]), s)
+                      _lib.ptr(dv[3]), _lib.ptr(dws), s)
         out = torch.empty((6,), **f32)
+        fws = torch.empty((L.vpn_trainstep_workspace(B) // 4,), **f32)
         _lib.call('vpn_trainstep_finalize', _lib.ptr(hot), _lib.ptr(emd_dist), _lib.ptr(cn[3]) if cn else None,
                   _lib.ptr(cn[5]) if cn else None, _lib.ptr(dv[0]) if dv else None, _lib.ptr(dv[2]) if dv else None, B, N, M,
-                  cn[7] if cn else 0, K, w_view, w_can, w_sil if render else 0.0, w_div, w_emd, cd_w1, cd_w2, _lib.ptr(out), s)
+                  cn[7] if cn else 0, K, w_view, w_can, w_sil if render else 0.0, w_div, w_emd, cd_w1, cd_w2, _lib.ptr(fws), _lib.ptr(out), s)
         ctx.meta = (B, K, n, M, H, W, seed_host, int(sample_base), cd_w1, cd_w2, w_view, w_can, w_div, w_emd, render,
                     seed_dev is not None, cn[7] if cn else 0)
         # the sampler's launch keeps the seed it used at loss_ws + 8: backward reads it from there

@@ -5,7 +5,7 @@ The reference carries K python lists of (B,3) volumes, (B,4) axis-angle rotation
 contiguous [B,K,10] tensor so a whole batch x primitive set is one coalesced read."""
 import torch
 
-from .ops import SPHERE, CUBOID, PARAM_STRIDE, kinds_tensor
+from .ops import SPHERE, CUBOID, PARAM_STRIDE, kinds_tensor, kinds_host, faces_fingerprint
 
 
 def pack_primitives(volumes, rotates, translates):
@@ -47,8 +47,10 @@ class PrimitivePack:
 
     @staticmethod
     def stack(packs):
+        # compared on the host (kinds_host: no device synchronisation; the B meshes of train.py:122-149 share one tensor)
+        k0 = kinds_host(packs[0].kinds)
         for p in packs[1:]:
-            if not torch.equal(p.kinds, packs[0].kinds):
+            if p.kinds is not packs[0].kinds and kinds_host(p.kinds) != k0:
                 raise ValueError('all samples of a batch must hold the same primitive kinds in the same order')
         return PrimitivePack(torch.cat([p.params for p in packs], 0), packs[0].kinds)
 
@@ -81,13 +83,11 @@ def mesh_batches(obj):
     for m in meshes:
         if not (hasattr(m, 'vertices') and hasattr(m, 'faces')):
             raise TypeError('cannot render %s: neither primitives nor vertices / faces' % type(m).__name__)
-    groups = []
+    # topologies are compared through host-side fingerprints (ops.faces_fingerprint): the B separately loaded spheres of
+    # train_sphere.py:58-59 each own a face tensor, and a device torch.equal per mesh would be B - 1 synchronisations
+    groups = {}
     for i, m in enumerate(meshes):
-        for g in groups:
-            f0, v0 = meshes[g[0]].faces, meshes[g[0]].vertices
-            if m.vertices.shape == v0.shape and (m.faces is f0 or (m.faces.shape == f0.shape and torch.equal(m.faces, f0))):
-                g.append(i)
-                break
-        else:
-            groups.append([i])
-    return [(g, torch.stack([meshes[i].vertices for i in g]), meshes[g[0]].faces) for g in groups]
+        fp = getattr(m, 'faces_key', None)
+        key = (tuple(m.vertices.shape), fp() if callable(fp) else faces_fingerprint(m.faces))
+        groups.setdefault(key, []).append(i)
+    return [(g, torch.stack([meshes[i].vertices for i in g]), meshes[g[0]].faces) for g in groups.values()]
