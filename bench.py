@@ -180,13 +180,26 @@ def raster_only(vpn_amd, _lib, dev, B, K, H, steps, warmup, windows, pmc_key, us
             'pmc_source': os.path.relpath(PMC_FILE, ROOT) if pmc else None}
 
 
-def c5_inputs(vpn_amd, B, K, n, H, dev):
+def c5_inputs(vpn_amd, B, K, n, H, dev, gt_mode='uniform'):
     """Synthetic batch of the reference's training step (train.py:227-262) at a given shape: packed primitive parameters,
     view-centred GT points (M = K*n: the only shape emd_module.py:36-39 admits), their object-centred counterpart
     (dataset.py:165 stores both; here canonical = view_to_obj_points(view_center)), the dataset's camera values, and a GT
-    silhouette rendered from a second primitive set."""
+    silhouette rendered from a second primitive set.
+    gt_mode 'uniform' (SURVEY.md 8d's inputs): GT cloud uniform in the cube, predicted primitives unrelated to it -- what the
+    first iterations of a training run look like, and the hardest case for the auction (500-1500 bidders in every round).
+    gt_mode 'surface': the GT cloud is sampled on the surfaces of a TARGET primitive set, the GT silhouette is its render, and
+    the predicted primitives are the target's perturbed by 10 % -- a step of a run that has partly converged."""
     M = K * n
     params, gt_view = synth_inputs(B, K, M, 1234, dev)
+    if gt_mode == 'surface':
+        kinds_t = vpn_amd.kinds_tensor([vpn_amd.SPHERE] * K, dev)
+        g2 = torch.Generator().manual_seed(99)
+        target = params.clone()
+        with torch.no_grad():
+            gt_view = vpn_amd.Sampling.sample_primitives(target, kinds_t, n, seed=4321).contiguous()
+        noise = torch.cat([1.0 + 0.1 * torch.randn(B, K, 3, generator=g2), torch.ones(B, K, 4), torch.ones(B, K, 3)], 2).to(dev)
+        shift = torch.cat([torch.zeros(B, K, 3), 0.02 * torch.randn(B, K, 4, generator=g2), 0.02 * torch.randn(B, K, 3, generator=g2)], 2).to(dev)
+        params = (target * noise + shift).contiguous()
     g = torch.Generator().manual_seed(77)
     dists = (1.0 + 0.5 * torch.rand(B, generator=g)).to(dev)          # rendering_metadata.txt: distance ratio (dataset.py:145-165)
     elevs = (20.0 + 20.0 * torch.rand(B, generator=g)).to(dev)        # degrees
@@ -195,7 +208,7 @@ def c5_inputs(vpn_amd, B, K, n, H, dev):
     kinds = vpn_amd.kinds_tensor([vpn_amd.SPHERE] * K, dev)           # config.py:33-34: all spheres
     with torch.no_grad():
         gt_canon = vpn_amd.view_to_obj_points(gt_view, dists, elevs, azims, angles).contiguous()
-        p2, _ = synth_inputs(B, K, 8, 4321, dev)
+        p2 = target if gt_mode == 'surface' else synth_inputs(B, K, 8, 4321, dev)[0]
         cam1 = torch.tensor([[1.0, 0.0, 0.0]], device=dev).expand(B, 3).contiguous()       # train.py:172-174
         a2, _ = vpn_amd.RasterFunction.apply(p2, kinds, cam1, H, H, vpn_amd.config.RASTER_SIGMA, vpn_amd.config.RASTER_GAMMA,
                                              vpn_amd.config.RASTER_Z_FAR)
@@ -208,12 +221,12 @@ C5_WEIGHTS = (1.0, 0.0, 1.0, 0.1, 1.0)      # L_VIEW_CD, L_CAN_CD, L_SIL, L_VP_D
 # silhouette term is evaluated here with weight 1; L_CAN_CD = 0 is the reference's value: that Chamfer is computed and weighted 0)
 
 
-def train_step_block(vpn_amd, _lib, dev, B, K, n, H, steps, warmup, windows, form, with_oracle):
+def train_step_block(vpn_amd, _lib, dev, B, K, n, H, steps, warmup, windows, form, with_oracle, gt_mode='uniform'):
     """The step train.py:243-262 runs: sampler -> view-centred Chamfer + object-centred Chamfer through view_to_obj_points
     + silhouette loss + VP-diversity loss + EMD (eps 0.005, 50 rounds) -> weighted total -> backward to d/d(v,q,t).
     form 'modules': the drop-in module surface called the way train.py calls it (one autograd node per reference call);
     form 'fused': one autograd node, no ATen kernel inside the step (TrainStepLossFunction)."""
-    params, kinds, gt_view, gt_canon, gt_sil, dists, elevs, azims, angles = c5_inputs(vpn_amd, B, K, n, H, dev)
+    params, kinds, gt_view, gt_canon, gt_sil, dists, elevs, azims, angles = c5_inputs(vpn_amd, B, K, n, H, dev, gt_mode)
     params.requires_grad_(True)
     w = C5_WEIGHTS
     ones, zeros = torch.ones(B, device=dev), torch.zeros(B, device=dev)
@@ -274,7 +287,9 @@ def train_step_block(vpn_amd, _lib, dev, B, K, n, H, steps, warmup, windows, for
     kern = kp.summary()
     ms = ev['median']
     res.update({'workload': 'train.py:243-262 step: B=%d, K=%d spheres, n=%d pts/prim (N=M=%d), %dx%d, weights (view_cd, can_cd, sil, '
-                            'vp_div, emd) = %s, EMD eps=0.005 iters=50' % (B, K, n, K * n, H, H, (w,)),
+                            'vp_div, emd) = %s, EMD eps=0.005 iters=50; %s' % (B, K, n, K * n, H, H, (w,),
+                            {'uniform': 'GT cloud uniform in the cube, unrelated predicted primitives (SURVEY 8d inputs: the first iterations of a run)',
+                             'surface': 'GT cloud on the surfaces of a target primitive set, predicted primitives = the target perturbed by 10 % (a partly converged run)'}[gt_mode]),
                 'ms_per_step': round(ms, 5), 'images_per_s': round(B / ms * 1e3, 1), 'timing': ev,
                 'losses': dict(zip(('view_cd', 'obj_cd', 'sil', 'vp_div', 'emd', 'total'), [float(x) for x in out])),
                 'finite_grad': bool(torch.isfinite(params.grad).all()),
@@ -349,6 +364,7 @@ def main():
     ap.add_argument('--windows', type=int, default=5, help='hipEvent windows of --steps replays each (median reported)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--c5-form', choices=['modules', 'fused', 'both'], default='both')
+    ap.add_argument('--c5-gt', choices=['uniform', 'surface'], default='uniform', help='GT cloud of the c5 workload (see c5_inputs)')
     ap.add_argument('--no-c5', action='store_true', help='skip the C5 train-step measurement of the default run')
     ap.add_argument('--no-c2', action='store_true', help='skip the C2 raster-only measurement of the default run')
     ap.add_argument('--no-extras', action='store_true', help='skip C2, EMD and the CPU baseline (profiling runs)')
@@ -414,7 +430,8 @@ def main():
     if args.workload == 'c5':
         forms = [args.c5_form] if args.c5_form != 'both' else ['modules', 'fused']
         res = {f: train_step_block(vpn_amd, _lib, dev, args.batch or 64, args.prims or 64, args.points if args.points != 256 else 32,
-                                   args.size or 256, args.steps, args.warmup, args.windows, f, f == 'fused' and not args.no_cpu_baseline)[0]
+                                   args.size or 256, args.steps, args.warmup, args.windows, f, f == 'fused' and not args.no_cpu_baseline,
+                                   args.c5_gt)[0]
                for f in forms}
         if rank == 0:
             best = min(res.values(), key=lambda r: r['ms_per_step'])
@@ -782,6 +799,7 @@ def main():
             out['c5'] = {
                 'fused': guarded(lambda: train_step_block(vpn_amd, _lib, dev, 64, 64, 32, 256, 50, 10, 3, 'fused', cpu is not None)[0]),
                 'modules': guarded(lambda: train_step_block(vpn_amd, _lib, dev, 64, 64, 32, 256, 30, 5, 3, 'modules', False)[0]),
+                'fused_partly_converged': guarded(lambda: train_step_block(vpn_amd, _lib, dev, 64, 64, 32, 256, 50, 10, 3, 'fused', False, 'surface')[0]),
                 'reference_default_shape_fused': guarded(lambda: train_step_block(vpn_amd, _lib, dev, 8, 16, 128, 128, 50, 10, 3, 'fused', False)[0]),
             }
         print(json.dumps(out), flush=True)

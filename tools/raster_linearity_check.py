@@ -76,6 +76,13 @@ if idx and hasattr(L, 'vpn_debug_raster_lin'):
         print('   lane %2d slot %d %-6s W: %.9e  2W: %.9e   (2^-126 = %.3e; the row of W: %s)' % (
             lane_, s_, n, float(p1[lane_, s_, lin[j]]), float(p2[lane_, s_, lin[j]]), tiny,
             ' '.join('%s=%.3e' % (names[q], float(p1[lane_, s_, q])) for q in (0, 1, 2, 3, 4, 11, 12, 13, 14, 15))))
+    # the lanes whose SUMS differ: their four pixels in full, W next to 2 W / 2 (hex: every bit)
+    hx = lambda v: float(v).hex()
+    for lane_, comp in bad.tolist()[:4]:
+        print('   lane %2d component %2d: sum(W) %s   sum(2W)/2 %s' % (lane_, comp, hx(lanes1[lane_, comp]), hx(lanes2[lane_, comp] / 2)))
+        for s_ in range(4):
+            print('      slot %d: a=%.3e wgt=%.3e  ' % (s_, float(p1[lane_, s_, 13]), float(p1[lane_, s_, 11])) +
+                  '  '.join('%s %s | %s' % (names[q], hx(p1[lane_, s_, q]), hx(p2[lane_, s_, q] / 2)) for q in (1, 4, 5, 6, 7, 8, 9, 10)))
     if not len(badp) and len(bad):
         print('every per-pixel intermediate doubles exactly: the difference arises in the accumulation of the lane sums (v += ...)')
         for lane_, comp in bad.tolist()[:6]:

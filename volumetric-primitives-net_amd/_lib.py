@@ -8,7 +8,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libvpn_hip.so')
+LIB_PATH = os.environ.get('VPN_HIP_LIB') or os.path.join(_HERE, 'libvpn_hip.so')     # VPN_HIP_LIB: the sanitizer build of the tests
 ABI_VERSION = 5
 
 _c_f = ctypes.c_void_p      # device pointers travel as void*

@@ -48,17 +48,33 @@ def digest():
     return h.hexdigest()
 
 
-def build(force=False, verbose=True):
-    stamp = LIB + '.stamp'
-    d = digest()
-    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == d:
-        return LIB
+ASAN_LIB = os.path.join(HERE, 'libvpn_hip_asan.so')
+# host-side AddressSanitizer build: the launch / validation code of every entry point instrumented, the
+# device code compiled as usual (-fno-gpu-sanitize: GPU ASan needs xnack+, which this pool does not offer).  Loaded by
+# tests/test_cabi_asan_cpu.py in a child process with the sanitizer runtime preloaded.
+ASAN_FLAGS = ['-g', '-fsanitize=address', '-fno-gpu-sanitize']
+
+
+def asan_runtime():
+    base = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(hipcc()))), 'lib', 'llvm', 'lib', 'clang')
+    for root, _dirs, files in os.walk(base):
+        if 'libclang_rt.asan-x86_64.so' in files:
+            return os.path.join(root, 'libclang_rt.asan-x86_64.so')
+    raise RuntimeError('libclang_rt.asan-x86_64.so not found under ' + base)
+
+
+def build(force=False, verbose=True, asan=False):
+    lib = ASAN_LIB if asan else LIB
+    stamp = lib + '.stamp'
+    d = digest() + ('asan' if asan else '')
+    if not force and os.path.exists(lib) and os.path.exists(stamp) and open(stamp).read() == d:
+        return lib
     cc = hipcc()
     objs = []
     procs = []
     for s in SOURCES:
-        o = os.path.join(CSRC, s.replace('.hip', '.o'))
-        cmd = [cc] + COMMON + PER_FILE.get(s, []) + ['-c', os.path.join(CSRC, s), '-o', o]
+        o = os.path.join(CSRC, s.replace('.hip', '.asan.o' if asan else '.o'))
+        cmd = [cc] + COMMON + (ASAN_FLAGS if asan else []) + PER_FILE.get(s, []) + ['-c', os.path.join(CSRC, s), '-o', o]
         if verbose:
             print(' '.join(cmd), flush=True)
         procs.append((s, subprocess.Popen(cmd)))
@@ -66,13 +82,13 @@ def build(force=False, verbose=True):
     for s, p in procs:
         if p.wait() != 0:
             raise RuntimeError('hipcc failed on ' + s)
-    cmd = [cc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+    cmd = [cc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib] + (['-fsanitize=address', '-fno-gpu-sanitize', '-shared-libasan'] if asan else []) + objs
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)
     open(stamp, 'w').write(d)
-    return LIB
+    return lib
 
 
 if __name__ == '__main__':
-    print(build(force='--force' in sys.argv))
+    print(build(force='--force' in sys.argv, asan='--asan' in sys.argv))

@@ -1065,11 +1065,7 @@ template <int PREC>   // 0: fp32-input MFMA (shares the fp32 vector datapath), 1
 #ifndef CM_WAVES_PER_EU
 #define CM_WAVES_PER_EU 6
 #endif
-#ifdef CM_EXP_NOBOUND
-__global__ __launch_bounds__(cm_block<PREC>()) void chamfer_nn_mfma_kernel(
-#else
 __global__ __launch_bounds__(cm_block<PREC>(), PREC == 1 ? 5 : CM_WAVES_PER_EU) void chamfer_nn_mfma_kernel(
-#endif
     const ScanJob j0, const ScanJob j1, int nsamples, const RasterOrderJob oj) {
     // LDS of the fp16 filter's tiles, declared here because the rider below borrows it
     __shared__ __attribute__((aligned(16))) unsigned char tileH16[PREC == 2 ? 2 * CM_TILE16 * CM_ROWB : 16];
@@ -1078,28 +1074,15 @@ __global__ __launch_bounds__(cm_block<PREC>(), PREC == 1 ? 5 : CM_WAVES_PER_EU) 
         // of the launch, where a third of the slots is idle) sort the raster's tiles, one image each.  The launch sits
         // between the one that writes the raster records and the one that reads masks and order, so neither a hand-off
         // nor a launch of its own is needed.
-#ifdef CM_RIDER_LAST
-        if ((int)blockIdx.x >= j0.G + j1.G) {
-            raster_order_wg<cm_block<PREC>()>(oj, (int)blockIdx.x - (j0.G + j1.G), tileH16);
-            return;
-        }
-#else
         // the rider (~10 us since it also tests the quadrants) is dispatched FIRST: ids [0, oj.B).  Last, it was the tail of
         // the launch (+10 us); first it costs 64 of 768 slots for its lifetime (not measurable)
         if ((int)blockIdx.x < oj.B) {
-#ifndef CM_RIDER_NOPRIO
             __builtin_amdgcn_s_setprio(3);               // few waves with a long dependent chain among scan waves at full tilt
-#endif
             raster_order_wg<cm_block<PREC>()>(oj, (int)blockIdx.x, tileH16);
             return;
         }
-#endif
     }
-#ifdef CM_RIDER_LAST
-    const int wg = (int)blockIdx.x;
-#else
     const int wg = (int)blockIdx.x - (PREC == 2 ? oj.B : 0);
-#endif
 #ifdef CM_EXP_TRACE
     const unsigned long long t_start = wall_clock64();
 #endif
@@ -1211,11 +1194,7 @@ __global__ __launch_bounds__(cm_block<PREC>(), PREC == 1 ? 5 : CM_WAVES_PER_EU) 
 // The tracked unit is a PAIR of blocks (64 targets): one 16-instruction tree over both accumulators and one
 // 4-instruction update per pair, 10 VALU instructions per block instead of 12 in a loop bound by VALU issue; the
 // exact finish then works on the winning half-wave's 32 rows of the pair (CM_CELL below).
-#ifdef CM_EXP_PRIO
-#define CM_PRIO(p) __builtin_amdgcn_s_setprio(p);
-#else
 #define CM_PRIO(p)
-#endif
 #define CM_PAIR(oa, ob, J)                                                                     \
     {                                                                                          \
         CM_PRIO(1)                                                                             \
@@ -1224,9 +1203,6 @@ __global__ __launch_bounds__(cm_block<PREC>(), PREC == 1 ? 5 : CM_WAVES_PER_EU) 
         const float mAB = min32(accA, accB);                                                   \
         CM_UPDATE_C(mAB, J)                                                                    \
     }
-#ifdef CM_EXP_PRIO_STATIC
-        if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
-#endif
         Pre pre = fetch(0);
         stash(0, pre);
         __syncthreads();
@@ -1237,19 +1213,6 @@ __global__ __launch_bounds__(cm_block<PREC>(), PREC == 1 ? 5 : CM_WAVES_PER_EU) 
             const int nblk = min(CM_TILE16, Ntp - t0) >> 5;          // 2, 4, 6 or 8 (Ntp is a multiple of 64)
             const unsigned char* T = &tileH[buf][jq * CM_ROWB + half * 16];
             const float before = best;
-#ifdef CM_EXP_NO_PINGPONG
-            float4 a0 = rd(T, 0), a1 = rd(T, 1);
-            CM_PAIR(a0, a1, 0)
-            if (nblk > 2) {
-                a0 = rd(T, 2); a1 = rd(T, 3);
-                CM_PAIR(a0, a1, 1)
-                if (nblk > 4) {
-                    a0 = rd(T, 4); a1 = rd(T, 5);
-                    CM_PAIR(a0, a1, 2)
-                    if (nblk > 6) { a0 = rd(T, 6); a1 = rd(T, 7); CM_PAIR(a0, a1, 3) }
-                }
-            }
-#else
             float4 a0 = rd(T, 0), a1 = rd(T, 1), b0 = rd(T, 2), b1 = rd(T, 3);
             CM_PAIR(a0, a1, 0)
             if (nblk > 2) {
@@ -1261,7 +1224,6 @@ __global__ __launch_bounds__(cm_block<PREC>(), PREC == 1 ? 5 : CM_WAVES_PER_EU) 
                     if (nblk > 6) CM_PAIR(b0, b1, 3)
                 }
             }
-#endif
             blk = best < before ? t0 + (blkc << 6) : blk;            // the tile improved this lane's minimum
             if (more) stash(buf ^ 1, pre);
             __syncthreads();
@@ -1549,7 +1511,6 @@ __global__ __launch_bounds__(cm_block<PREC>(), PREC == 1 ? 5 : CM_WAVES_PER_EU) 
     const unsigned long long t_epi = wall_clock64();
 #endif
     float sfin = (half == 0 && qi < Nq) ? s : 0.0f;                 // this query's final minimum (once per query)
-#ifndef CM_EXP_NOFIX
     if (cnt != 0) {
 #ifdef VPN_CHAMFER_DEBUG
         const unsigned long long t_fix = wall_clock64();
@@ -1564,7 +1525,6 @@ __global__ __launch_bounds__(cm_block<PREC>(), PREC == 1 ? 5 : CM_WAVES_PER_EU) 
         }
 #endif
     }
-#endif
     // sum of the workgroup's minima in a fixed order (lanes by butterfly, waves in order): the loss finalisation adds
     // gx numbers per sample and direction instead of re-reading dist [B,Nq]
     sfin = wave_sum(sfin);

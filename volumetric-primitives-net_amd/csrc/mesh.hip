@@ -144,9 +144,13 @@ __device__ inline FaceEval eval_face(float px, float py, const float4 f0, const 
     const float d0 = seg_d2(px, py, ax, ay, bx, by, t0, q0x, q0y);
     const float d1 = seg_d2(px, py, bx, by, cx, cy, t1, q1x, q1y);
     const float d2 = seg_d2(px, py, cx, cy, ax, ay, t2, q2x, q2y);
-    r.seg = 0; r.d2 = d0; r.t = t0; r.qx = q0x; r.qy = q0y;
-    if (d1 < r.d2) { r.seg = 1; r.d2 = d1; r.t = t1; r.qx = q1x; r.qy = q1y; }
-    if (d2 < r.d2) { r.seg = 2; r.d2 = d2; r.t = t2; r.qx = q2x; r.qy = q2y; }
+    // nearest of the three segments by two rounds of selects (written as `if`s that also set the segment number the
+    // compiler turned the choice into a nine-dword table in scratch memory indexed by it)
+    const bool b1 = d1 < d0;
+    const float dm = b1 ? d1 : d0, tm = b1 ? t1 : t0, qmx = b1 ? q1x : q0x, qmy = b1 ? q1y : q0y;
+    const bool b2 = d2 < dm;
+    r.d2 = b2 ? d2 : dm; r.t = b2 ? t2 : tm; r.qx = b2 ? q2x : qmx; r.qy = b2 ? q2y : qmy;
+    r.seg = b2 ? 2 : (b1 ? 1 : 0);
     const float e0 = (bx - ax) * (py - ay) - (by - ay) * (px - ax);
     const float e1 = (cx - bx) * (py - by) - (cy - by) * (px - bx);
     const float e2 = (ax - cx) * (py - cy) - (ay - cy) * (px - cx);
@@ -184,7 +188,7 @@ __global__ __launch_bounds__(64) void mesh_raster_fwd_kernel(const float4* __res
     }
 }
 
-__global__ __launch_bounds__(64) void mesh_raster_bwd_kernel(const float4* __restrict__ proj, const int32_t* __restrict__ faces,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4))) void mesh_raster_bwd_kernel(const float4* __restrict__ proj, const int32_t* __restrict__ faces,
                                                              int B, int P, int F, int H, int W, int tiles_x, float sigma,
                                                              const float* __restrict__ alpha, const float* __restrict__ galpha,
                                                              float* __restrict__ gproj) {

@@ -270,9 +270,7 @@ __host__ __device__ inline size_t raster_lds_bytes(int K) {
 // test; `mask_out`: where lane 0 stores the mask (forward kernels).  Returns the mask (wave-uniform).
 // quadrant words of the tile that arrived with its entry (training step): they are put where quadrant_bits_all would
 // have left them (LDS, behind the culling records) and the loops read them from there
-struct QuadMasks {
-    bool on = false;
-};
+// (`quad_ready` of the tile loops: a plain flag -- as a one-byte struct it was written to and re-read from scratch memory)
 
 __device__ inline unsigned long long stage_word(const Tile& T, const float4* __restrict__ rec_b, int w, int K, int H, int W,
                                                 float4* srec, const unsigned long long* mask_in,
@@ -460,19 +458,16 @@ __device__ inline void finalize_sample(const FinArgs& fin, const LossArgs& la, i
 __device__ inline unsigned long long tile_forward(const Tile& T, const float4* __restrict__ rec_b, unsigned long long* __restrict__ mrow,
                                     int words, int K, int H, int W, float4* srec, float inv_sigma, float inv_gamma,
                                     float zref, float P[R_PPL], float S0[R_PPL], float S1[R_PPL], bool masks_ready = false,
-                                    const QuadMasks qk = QuadMasks{}, bool has_m = false, unsigned long long m_val = 0ull) {
+                                    bool quad_ready = false, bool has_m = false, unsigned long long m_val = 0ull) {
 #pragma unroll
     for (int s = 0; s < R_PPL; ++s) { P[s] = 1.0f; S0[s] = 0.0f; S1[s] = 0.0f; }
     unsigned long long m0 = 0ull;
     for (int w = 0; w < words; ++w) {
-        const unsigned long long m = masks_ready ? stage_word(T, rec_b, w, K, H, W, srec, mrow, nullptr, !qk.on, has_m && w == 0, m_val)
+        const unsigned long long m = masks_ready ? stage_word(T, rec_b, w, K, H, W, srec, mrow, nullptr, !quad_ready, has_m && w == 0, m_val)
                                                    : stage_word(T, rec_b, w, K, H, W, srec, nullptr, mrow);
         if (w == 0) m0 = m;
         const int n = __builtin_popcountll(m);
-#ifdef R_EXP_PRIO
-        if (n >= R_EXP_PRIO) __builtin_amdgcn_s_setprio(2);          // heavy tiles: the launch's critical path
-#endif
-        if (!qk.on) quadrant_bits_all(T, srec, n, K, H, W);          // on: the entry's words are in LDS already
+        if (!quad_ready) quadrant_bits_all(T, srec, n, K, H, W);          // on: the entry's words are in LDS already
         unsigned long long qb = 0ull;
         for (int j = 0; j < n; ++j) {
             if ((j & 15) == 0) qb = uniform64(quadrant_words(srec, K)[j >> 4]);
@@ -520,7 +515,7 @@ __device__ inline void tile_backward(const Tile& T, const float4* __restrict__ r
                                      unsigned long long m0, float inv_sigma,
                                      float inv_gamma, float zref, const float P[R_PPL], const float zbar[R_PPL],
                                      const float invS[R_PPL], const float gAtot[R_PPL], const float gZbar[R_PPL],
-                                     float* __restrict__ partial, const QuadMasks qk = QuadMasks{}) {
+                                     float* __restrict__ partial, bool quad_ready = false) {
     const int lane = threadIdx.x & 63;
     for (int w = 0; w < words; ++w) {
         const unsigned long long mw = staged ? m0 : stage_word(T, rec_b, w, K, H, W, srec, mrow, nullptr);
@@ -570,11 +565,7 @@ __device__ inline void tile_backward(const Tile& T, const float4* __restrict__ r
             if (g_dbg_lin.buf && T.b == g_dbg_lin.b && k == g_dbg_lin.k && T.tile == g_dbg_lin.tile)
                 for (int i = 0; i < 12; ++i) g_dbg_lin.buf[lane * 16 + i] = v[i];
 #endif
-#ifdef R_REDUCE_BUTTERFLY
-            const float tot = wave_reduce16(v);
-#else
             const float tot = reduce12_lds(v, reduce_scratch(srec, K));
-#endif
             if ((lane & 3) == 0 && (lane >> 2) < 12)
                 partial[(((size_t)T.b * K + k) * ntile + T.tile) * 12 + (lane >> 2)] = tot;
         }
@@ -717,7 +708,7 @@ __global__ __launch_bounds__(64, ENT ? R_ENT_WAVES : R_TOTAL_WAVES) void raster_
     // training step: ONE 48-byte entry (written by the rider of the scan's launch) says which tile this wave takes, which
     // primitives it sees and which quadrants each of them reaches
     const int ntile = tiles_x * tiles_y, lane = threadIdx.x & 63;
-    QuadMasks qk;
+    bool quad_ready = false;
     unsigned long long m_entry = 0ull;
     int tile_of_entry = -1;
     uint4 e1q = make_uint4(0u, 0u, 0u, 0u), e2q = e1q;
@@ -730,7 +721,7 @@ __global__ __launch_bounds__(64, ENT ? R_ENT_WAVES : R_TOTAL_WAVES) void raster_
         };
         tile_of_entry = __builtin_amdgcn_readfirstlane((int)e0.x);
         m_entry = u64(e0.z, e0.w);
-        qk.on = true;
+        quad_ready = true;
         e1q = e1; e2q = e2;
     }
     const Tile T = make_tile(H, W, tiles_x, tiles_y, B, tile_of_entry);
@@ -756,7 +747,7 @@ __global__ __launch_bounds__(64, ENT ? R_ENT_WAVES : R_TOTAL_WAVES) void raster_
     }
     float P[R_PPL], S0[R_PPL], S1[R_PPL];
     // with entries the tile's mask is known (words == 1 there): stage_word takes it from `m_entry`
-    const unsigned long long m0 = tile_forward(T, rec_b, mrow, words, K, H, W, srec, inv_sigma, inv_gamma, zref, P, S0, S1, ENT, qk, ENT, m_entry);
+    const unsigned long long m0 = tile_forward(T, rec_b, mrow, words, K, H, W, srec, inv_sigma, inv_gamma, zref, P, S0, S1, ENT, quad_ready, ENT, m_entry);
 #ifdef R_EXP_TRACE
     const unsigned long long t_fwd = wall_clock64();
 #endif
@@ -812,7 +803,7 @@ __global__ __launch_bounds__(64, ENT ? R_ENT_WAVES : R_TOTAL_WAVES) void raster_
     // K > 64: the backward restages word by word from the masks this wave stored (or read) in the forward half -- lane 0
     // reads back its own stores, program order -- instead of repeating the visibility test
     tile_backward(T, rec_b, mrow, words, K, ntile, H, W, srec, ENT || words == 1, m0, inv_sigma, inv_gamma, zref, P, zbar, invS,
-                  gAtot, gZbar, partial, qk);
+                  gAtot, gZbar, partial, quad_ready);
 #ifdef R_EXP_TRACE
     const unsigned long long t_bwd = wall_clock64();
 #endif

@@ -47,14 +47,6 @@ __device__ inline void cuboid_quota(const float v[3], int n, int cum[7]) {
 // canonical coefficient c with p_c = c * v  (unit sphere point, or unit box point snapped to a face)
 __device__ inline void canonical_coeff(const PrimLds& P, int p, const float u[3], float c[3]) {
     if (P.kind == VPN_SPHERE) {
-#ifdef SAMP_REFERENCE_TRIG
-        float elev = -acosf(1.0f - 2.0f * u[0]) + VPN_PI * 0.5f;   // sphere.py:26
-        float azim = u[1] * 2.0f * VPN_PI;                          // sphere.py:27
-        float ce = cosf(elev);
-        c[0] = ce * sinf(azim);                                     // sphere.py:38-40
-        c[1] = sinf(elev);
-        c[2] = ce * cosf(azim);
-#else
         // sphere.py:26, :38-40: elev = -acos(w) + pi/2 with w = 1 - 2 u0, then sin(elev) and cos(elev): in closed form
         // sin(elev) = w and cos(elev) = sqrt(1 - w^2) = 2 sqrt(u0 (1 - u0)) -- no acos, no sin, no cos (three of the five
         // transcendental calls of a point: the kernel is bound by instruction issue).  The reference's own chain carries
@@ -68,7 +60,6 @@ __device__ inline void canonical_coeff(const PrimLds& P, int p, const float u[3]
         c[0] = ce * sa;                                             // sphere.py:38-40
         c[1] = w;
         c[2] = ce * ca;
-#endif
     } else {
         c[0] = -1.0f + 2.0f * u[0];                                 // cuboid.py:66
         c[1] = -1.0f + 2.0f * u[1];
@@ -120,11 +111,7 @@ __device__ inline void sample_wg(PrimLds& P, float* red, int b, int k,
     // camera while the pose lane makes the pose (two chains of sin / cos side by side in front of the barrier), and
     // finishes the record from both after it, while the other waves are already sampling.
     Camera C;
-#ifndef SAMP_EXP_NOREC
     const bool rec_lane = rp.rec && threadIdx.x == 64;
-#else
-    const bool rec_lane = false;
-#endif
     if (rec_lane) C = make_camera(rp.cam + b * 3);
     // head of the loss workspace: the arrival counter is zeroed, the Philox seed this step really uses is kept (the
     // backward reads it from there: the caller's device counter may have advanced by then); per sample: tile counter
@@ -165,9 +152,7 @@ __device__ inline void sample_wg(PrimLds& P, float* red, int b, int k,
             pz = (R.m[2][0] * x + R.m[2][1] * y + R.m[2][2] * z) + tz;
         }
         st3(out + p * 3, px, py, pz);
-#ifndef SAMP_EXP_NOFEAT
         if (feat) nv = fmaxf(nv, feat_point(*feat, b, k * n + p, px, py, pz));
-#endif
     }
     if (feat) {
         // the last primitive's workgroup also writes the padding rows [N, Np) of the sample (fewer than 64)
@@ -206,11 +191,7 @@ __global__ __launch_bounds__(SAMP_BLOCK) void sample_feat_fwd_kernel(
     // silhouette hexagon).  One lane per record in workgroups of their own at the HEAD of the grid (dispatched first, done
     // long before the launch is) -- as the record lane of every sampler workgroup they were that workgroup's critical
     // path (2.6 us of the launch at C3).
-#ifdef SAMP_REC_IN_WG
-    const int nrec = 0;                                // A/B: the record lane of every sampler workgroup
-#else
     const int nrec = rp.rec ? rec_workgroups(B * K) : 0;
-#endif
     if ((int)blockIdx.x < nrec) {
         const int bk = blockIdx.x * SAMP_BLOCK + threadIdx.x;
         if (bk < B * K) {
@@ -225,19 +206,11 @@ __global__ __launch_bounds__(SAMP_BLOCK) void sample_feat_fwd_kernel(
         return;
     }
     RasterPrep rq = rp;
-#ifndef SAMP_REC_IN_WG
     rq.rec = nullptr;                                  // the sampler workgroups keep the counters and the seed only
-#endif
     int b, sy;
     feat_decode((int)blockIdx.x - nrec, B, b, sy);
-#ifdef SAMP_GT_AFTER
-    sample_wg(P, red, b, sy, params, kinds, u, seed, sample_base, K, n, points, rq, &pred);
-    __syncthreads();                                   // `red` of the sampled cloud's slice has been read
-    feat_slice(gt, b, sy, red);
-#else
     __shared__ float red_gt[SAMP_BLOCK / 64];
     sample_wg(P, red, b, sy, params, kinds, u, seed, sample_base, K, n, points, rq, &pred, &gt, red_gt);
-#endif
 }
 
 __global__ __launch_bounds__(SAMP_BLOCK) void sample_bwd_kernel(
@@ -877,11 +850,7 @@ extern "C" int vpn_hotpath_sample_fwd(const float* params, const int32_t* kinds,
     if (rc) return rc;
     pred.ysplit = K;                      // one slice (and one max-norm slot) per primitive
     gt.ysplit = K;                        // ... and the same workgroups share the ground-truth cloud
-#ifdef SAMP_REC_IN_WG
-    const unsigned nrec = 0;
-#else
     const unsigned nrec = (unsigned)rec_workgroups(B * K);
-#endif
     VPN_LAUNCH(sample_feat_fwd_kernel, dim3((unsigned)B * (unsigned)K + nrec), dim3(SAMP_BLOCK), 0, (hipStream_t)stream,
                params, kinds, u, seed, seed_dev, sample_base, B, K, n, points, rp, pred, gt);
     VPN_LAUNCH_CHECK();
