@@ -31,7 +31,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3     # fp32 vector peak = fp32-input MFMA peak (MI355X_MICROARCH.md chip table)
 F16_PEAK_TFLOPS = 2500.0     # dense fp16 / bf16 MFMA (MI355X_MICROARCH.md; not the 2:1-sparsity figure)
 N_SIMD = 1024                # 256 CUs x 4 SIMD-32
-PMC_FILE = os.path.join(ROOT, 'profiles', 'r03_pmc.json')     # written by tools/pmc_collect.py from rocprofv3 passes
+PMC_FILE = os.path.join(ROOT, 'profiles', 'r04_pmc.json')     # written by tools/pmc_collect.py from rocprofv3 passes
 
 
 def synth_inputs(B, K, M, seed, device):
@@ -60,7 +60,7 @@ def event_windows(run, steps, windows):
 
 
 def load_pmc(workload_key):
-    """Counter summaries of the same command collected with rocprofv3 (tools/pmc_collect.py -> profiles/r03_pmc.json):
+    """Counter summaries of the same command collected with rocprofv3 (tools/pmc_collect.py -> profiles/r04_pmc.json):
     {kernel: {counter: mean per dispatch}} for this workload, or {}."""
     try:
         return json.load(open(PMC_FILE)).get(workload_key, {})
@@ -69,9 +69,9 @@ def load_pmc(workload_key):
 
 
 def load_isa_mix():
-    """Static issue-class mix of the raster kernels (tools/isa_mix.py -> profiles/r03_isa_mix.json)."""
+    """Static issue-class mix of the raster kernels (tools/isa_mix.py -> profiles/r04_isa_mix.json)."""
     try:
-        return json.load(open(os.path.join(ROOT, 'profiles', 'r03_isa_mix.json')))
+        return json.load(open(os.path.join(ROOT, 'profiles', 'r04_isa_mix.json')))
     except (OSError, ValueError):
         return {}
 
@@ -221,7 +221,7 @@ C5_WEIGHTS = (1.0, 0.0, 1.0, 0.1, 1.0)      # L_VIEW_CD, L_CAN_CD, L_SIL, L_VP_D
 # silhouette term is evaluated here with weight 1; L_CAN_CD = 0 is the reference's value: that Chamfer is computed and weighted 0)
 
 
-def train_step_block(vpn_amd, _lib, dev, B, K, n, H, steps, warmup, windows, form, with_oracle, gt_mode='uniform'):
+def train_step_block(vpn_amd, _lib, dev, B, K, n, H, steps, warmup, windows, form, with_oracle, gt_mode='uniform', use_graph=True):
     """The step train.py:243-262 runs: sampler -> view-centred Chamfer + object-centred Chamfer through view_to_obj_points
     + silhouette loss + VP-diversity loss + EMD (eps 0.005, 50 rounds) -> weighted total -> backward to d/d(v,q,t).
     form 'modules': the drop-in module surface called the way train.py calls it (one autograd node per reference call);
@@ -266,6 +266,8 @@ def train_step_block(vpn_amd, _lib, dev, B, K, n, H, steps, warmup, windows, for
     torch.cuda.synchronize()
     res = {'form': form}
     try:
+        if not use_graph:
+            raise RuntimeError('--no-graph')
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             g_out = compute(0)
@@ -431,7 +433,7 @@ def main():
         forms = [args.c5_form] if args.c5_form != 'both' else ['modules', 'fused']
         res = {f: train_step_block(vpn_amd, _lib, dev, args.batch or 64, args.prims or 64, args.points if args.points != 256 else 32,
                                    args.size or 256, args.steps, args.warmup, args.windows, f, f == 'fused' and not args.no_cpu_baseline,
-                                   args.c5_gt)[0]
+                                   args.c5_gt, not args.no_graph)[0]
                for f in forms}
         if rank == 0:
             best = min(res.values(), key=lambda r: r['ms_per_step'])
@@ -695,7 +697,7 @@ def main():
             step_hbm = {'traffic_bytes_per_step': int(tot), 'achieved_GBps': round(gbs, 1), 'peak_GBps': HBM_PEAK_GBS,
                         'frac': round(gbs / HBM_PEAK_GBS, 4), 'algorithmic_bytes_per_step': int(alg),
                         'note': 'sum over the kernels of one step of FETCH_SIZE (x2 for the 16-B-per-lane streams) + '
-                                'WRITE_SIZE from profiles/r03_pmc.json, over the hipEvent median step time: the step is '
+                                'WRITE_SIZE from profiles/r04_pmc.json, over the hipEvent median step time: the step is '
                                 'issue-bound (VALU / matrix pipe), not HBM-bound'}
 
     # The legs below are reported NEXT to the headline: a failure in one of them (host out of memory in the CPU leg, ...)

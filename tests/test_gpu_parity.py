@@ -833,10 +833,14 @@ def test_raster_full_size_properties(vpn):
     g1b, = torch.autograd.grad([a, d], [pg], [Wa, Wd], retain_graph=True)
     g2, = torch.autograd.grad([a, d], [pg], [2 * Wa, 2 * Wd], retain_graph=True)
     assert torch.equal(g1, g1b), 'backward is not deterministic'
-    # doubling is exact in every operation except where a product falls into the flushed denormal range in one run and not
-    # in the other (the kernels flush denormals): measured on this very case, ONE of the 6.3 M tile partials differs by one
-    # ulp between W and 2 W (tools/raster_linearity_check.py; with either reduction of the tile sums), which may or may not survive the
-    # rounding of the sums behind it.  Linear to a few ulps of the largest entry, and exactly reproducible.
+    # Doubling the incoming gradient is exact in every operation except underflow (the kernels flush denormals), and on
+    # this very case that is what happens, once (tools/raster_linearity_check.py with -DR_DEBUG_LIN, profiles/r04_raster_linearity.txt):
+    # image 19, primitive 31, tile 78, lane 31 holds one pixel in the CLAMPED tail of the coverage (a = e^-80 = 1.8e-35), whose
+    # gradient terms are ~1e-37; an intermediate of that pixel underflows for W and not for 2 W, so its (irrelevant) term comes
+    # out with another value and sign -- and it is the ADDEND of the FMA that accumulates the lane's next pixel, v += py * gd,
+    # whose exact product sits on a rounding tie (py, a pixel coordinate, has a short mantissa): the sign of a 1e-37 addend
+    # decides the last bit of a sum of magnitude 1.  One of the 6.3 M tile partials differs by one ulp; linear to a few
+    # ulps of the largest entry, and exactly reproducible.
     assert float((g2 - 2 * g1).abs().max()) <= 1e-6 * float(g1.abs().max()), 'backward is not linear in the incoming gradient'
     assert bool(torch.isfinite(g1).all())
     assert 0.02 < float(a.mean()) < 0.9
@@ -1279,3 +1283,51 @@ def test_raster_escape_report():
     for e in ESCAPES:
         print('fp64 clause used: seed %d, slice %d, e_gpu %.2e, e_cpu %.2e' % e)
     assert len(ESCAPES) <= 2, ESCAPES
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('concurrent', [False, True])
+@pytest.mark.parametrize('M', [2048, 8192])
+def test_hot_path_advance_seed(vpn, concurrent, M):
+    """the step's device seed with advance_seed=True (what bench.py's headline runs): the counter moves by
+    exactly one, the losses and the gradient are bit-equal to the same step with that seed given on the host -- also with a
+    THIN primitive (the backward redraws its Philox uniforms instead of recovering the coefficients from the points, so a
+    backward that read the already-advanced counter would redraw other points), with a ground-truth cloud beyond the fused
+    backward's limit (the two-kernel backward), and on the side-stream form (VPN_CONCURRENT)."""
+    import vpn_amd.ops as ops
+    gen = torch.Generator().manual_seed(31)
+    B, K, n, H = 4, 16, 64, 64
+    params = rand_params(gen, B, K)
+    params[0, 0, :3] = torch.tensor([1e-5, 0.05, 0.04])              # thin: the exact recomputation path of the backward
+    gt = torch.rand(B, M, 3, generator=gen) - 0.5
+    kinds = vpn.kinds_tensor([0] * K, torch.device(DEV))
+    cam = g(torch.tensor([[1.0, 0.0, 0.0]]).expand(B, 3).contiguous())
+    gs = g((torch.rand(B, H, H, generator=gen) > 0.5).float())
+    gd = g(1.0 + torch.rand(B, H, H, generator=gen))
+
+    def run(seed, adv):
+        p = g(params).requires_grad_(True)
+        out = vpn.HotPathLossFunction.apply(p, kinds, cam, g(gt), gs, gd, n, seed, 0, H, H, 0.05, 0.1, 2.0, 1.0, 1.0, 1.0, 1.0, 1.0,
+                                            False, adv)
+        out[2].backward()
+        torch.cuda.synchronize()
+        return torch.stack([o.detach() for o in out]).cpu(), p.grad.cpu()
+    old = ops.CONCURRENT_BRANCHES
+    ops.CONCURRENT_BRANCHES = concurrent
+    try:
+        ref_l, ref_g = run(77, False)
+        counter = torch.full((1,), 77, dtype=torch.int64, device=DEV)
+        l1, g1 = run(counter, True)
+        # bit-equal where the backward is the fused kernel (fixed summation order); beyond its ground-truth limit the
+        # two-kernel backward scatters with LDS atomics, whose order is not fixed: equal to rounding there -- a redraw with
+        # another seed moves the thin primitive's gradient by orders of magnitude more
+        same = (lambda a, b: torch.equal(a, b)) if M <= ops.FUSED_BWD_MAX_GT else (lambda a, b: rel_err(a, b) <= 1e-5)
+        assert int(counter.item()) == 78
+        assert torch.equal(l1, ref_l) and same(g1, ref_g)
+        l2, g2 = run(counter, True)                                      # the next step draws other points
+        assert int(counter.item()) == 79 and not torch.equal(l2, l1)
+        assert rel_err(g2[0, 0], g1[0, 0]) > 1e-3                        # ... and the thin primitive's gradient with them
+        ref2_l, ref2_g = run(78, False)
+        assert torch.equal(l2, ref2_l) and same(g2, ref2_g)
+    finally:
+        ops.CONCURRENT_BRANCHES = old

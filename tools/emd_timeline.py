@@ -33,7 +33,7 @@ for b in (0, B // 2):
         if r[0, 0] == 0: break
         U = r[0, 5] & 0xffff; uown = (r[:, 5] >> 16)
         T = 1
-        while T < int(os.environ.get('VPN_EMD_TMAX', 16)) and 2 * T * int(uown.max()) <= int(os.environ.get('VPN_EMD_TNUM', 512)): T *= 2
+        while T < int(os.environ.get('VPN_EMD_TMAX', 16)) and 2 * T * int(uown.max()) <= int(os.environ.get('VPN_EMD_TNUM', 1024)): T *= 2
         us = lambda a: a / 100.0
         print(' %2d  %4d  %4d      %2d  %7.1f %8.1f | %4.1f  %6.1f  %6.1f   %6.1f   %5.1f | %6.1f' % (
             it, U, uown.max(), T, r[:, 7].sum() / max(1, uown.sum()), r[:, 6].sum() / max(1, uown.sum()),

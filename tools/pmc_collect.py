@@ -31,7 +31,7 @@ def short(name):
 
 
 out = {}
-for wl in ('c3', 'c2'):
+for wl in ('c3', 'c2', 'c5'):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for d in sorted(glob.glob(os.path.join(src, '%s_%s_pmc*' % (tag, wl)))):
         # gpurun merges every call's output into gpurun_out/: a pass directory may hold files of earlier runs of
@@ -45,7 +45,7 @@ for wl in ('c3', 'c2'):
     lines = ['# rocprofv3 --kernel-trace --pmc <counters> -- python3 bench.py --steps 10 --warmup 3 --no-extras --no-graph '
              '--workload %s  (separate passes, tools/profile_all.sh; mean per dispatch)' % wl]
     for k, c in sorted(acc.items()):
-        if not k.startswith(('chamfer', 'raster', 'sample', 'loss_')):
+        if not k.startswith(('chamfer', 'raster', 'sample', 'loss_', 'emd_', 'vpdiv', 'trainstep', 'camera')):
             continue
         ker[k] = {cn: sum(v) / len(v) for cn, v in c.items()}
         ker[k]['dispatches'] = max(len(v) for v in c.values())

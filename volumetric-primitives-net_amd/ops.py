@@ -705,11 +705,15 @@ class HotPathLossFunction(Function):
                 raster_branch(s, 1)
             _lib.call('vpn_loss_finalize', _lib.ptr(lws), B, H, W, _lib.ptr(d1), _lib.ptr(d2), N, M, cd_w1, cd_w2, float(w_cd),
                       float(w_sil), float(w_depth), _lib.ptr(losses), None, s)
-            if advance_seed:
-                seed.add_(1)
         pattern = _grad_pattern(B, w_cd, dev)
         empty = torch.empty(0, device=dev)
         seed_t = seed if isinstance(seed, torch.Tensor) else empty
+        if advance_seed and not fused_fin:
+            # the side-stream / unfused form advances the caller's counter here; when the sampler launch did not keep the
+            # seed it used (side stream), the backward must not read the advanced counter: it gets a copy of the old one
+            if not (side is None and seed_dev is not None):
+                seed_t = seed.clone()
+            seed.add_(1)
         # the sampler's launch of the one-stream path keeps the seed it used at loss_ws + 8: backward reads it from there,
         # whatever has happened to the caller's counter since
         seed_saved = side is None and seed_dev is not None
