@@ -358,14 +358,17 @@ int vpn_head_pack_bwd(const float* volumes, const float* rotates, const float* t
  *         + L_EMD     * sqrt(EMD dist).mean()                             (train.py:193-195) [vpn_emd_fwd]
  * vpn_vpdiv_fwd: the nearest neighbours of VPDiverseLoss -- centres = params[b,k,7:10] (the reference cats the K
  *   translations), both directions: dist1/idx1 [B,K] (centre -> nearest ground-truth point), dist2/idx2 [B,M]; same
- *   arithmetic and tie rule as vpn_chamfer_fwd (chamfer_distance.py:14-23).
+ *   arithmetic and tie rule as vpn_chamfer_fwd (chamfer_distance.py:14-23).  dist1 = idx1 = NULL: the centres' direction stays
+ *   as per-slice results in `workspace` for vpn_trainstep_finalize to merge.
  * vpn_camera_matrix: mat [B,9] row-major with view_to_obj_points(p) = mat p (to_object != 0; transform.py:21-47) or
  *   obj_to_view_points(p) = mat p (to_object == 0; :50-73), the scale by dist included.
  * vpn_trainstep_finalize: out [6] = (L_VIEW_CD*view_cd, L_CAN_CD*obj_cd, L_SIL*sil, L_VP_DIV*vp_div, L_EMD*emd, their sum)
  *   from hot_losses [4] as vpn_raster_total_fwd_fin leaves them (w_cd = L_VIEW_CD, w_sil = L_SIL, w_dep = 0), the
  *   auction's dist [B,N], the object-centred cloud's nearest-neighbour distances cn_dist1 [B,N] / cn_dist2 [B,Mc] and
  *   the VP-diversity distances dv_dist1 [B,K] / dv_dist2 [B,M]; any of the three groups may be NULL (term = 0).
- *   Fixed summation order.
+ *   Fixed summation order.  dv_workspace != NULL (then dv_dist1 == NULL): the workspace a preceding vpn_vpdiv_fwd call
+ *   with dist1 = idx1 = NULL left its per-slice results in; they are merged into dv_dist1_out / dv_idx1_out [B,K] by the
+ *   same per-sample pass (one launch less in the training step).
  * vpn_trainstep_bwd: grad_params [B,K,10] = (*grad_total) * d total / d params in ONE launch: vpn_hotpath_bwd (w1 =
  *   cd_w1 * L_VIEW_CD / B, w2 = cd_w2 * L_VIEW_CD / B; records / workspace NULL when the silhouette term is off) plus
  *   - the EMD term through the assignment (emd_cuda.cu:284-300 and the sqrt / mean of train.py:195): emd_coef = L_EMD / (B N);
@@ -382,7 +385,8 @@ size_t vpn_trainstep_workspace(int B);             /* scratch of vpn_trainstep_f
 int vpn_trainstep_finalize(const float* hot_losses, const float* emd_dist, const float* cn_dist1, const float* cn_dist2,
                            const float* dv_dist1, const float* dv_dist2, int B, int N, int M, int Mc, int K,
                            float w_view, float w_can, float w_sil, float w_div, float w_emd, float cd_w1, float cd_w2,
-                           void* workspace, float* out, void* stream);
+                           void* workspace, const void* dv_workspace, float* dv_dist1_out, int32_t* dv_idx1_out,
+                           float* out, void* stream);
 int vpn_trainstep_bwd(const float* params, const int32_t* kinds, uint64_t seed, const uint64_t* seed_dev,
                       uint64_t sample_base, int B, int K, int n, const float* points, const float* gt_points, int M,
                       const float* dist1, const int32_t* idx1, const float* dist2, const int32_t* idx2,

@@ -66,7 +66,7 @@ SIGNATURES = {
     'vpn_vpdiv_fwd': (_i, [_c_f, _c_f, _i, _i, _i, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f]),
     'vpn_trainstep_workspace': (_sz, [_i]),
     'vpn_camera_matrix': (_i, [_c_f, _c_f, _c_f, _c_f, _i, _i, _c_f, _c_f]),
-    'vpn_trainstep_finalize': (_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _c_f, _c_f, _c_f]),
+    'vpn_trainstep_finalize': (_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f]),
     'vpn_trainstep_bwd': (_i, [_c_f, _c_f, _u64, _c_f, _u64, _i, _i, _i, _c_f, _c_f, _i, _c_f, _c_f, _c_f, _c_f, _f, _f, _c_f, _i, _i,
                                _c_f, _c_f, _c_f, _c_f, _c_f, _f, _c_f, _c_f, _c_f, _c_f, _f, _f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f,
                                _f, _f, _i, _c_f, _c_f]),

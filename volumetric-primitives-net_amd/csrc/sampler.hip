@@ -381,13 +381,13 @@ __global__ __launch_bounds__(SCB_BLOCK) void sample_chamfer_bwd_kernel(
     };
     // object-centred Chamfer: canon = S p with S = cn_mat_b (3x3, the camera rotations times dist); a gradient g of a
     // canonical point is S^T g for the view-centred point it came from
-    float S[9];
-    if (EXTRAS && ex.cn_points) {
-#pragma unroll
-        for (int i = 0; i < 9; ++i) S[i] = ex.cn_mat[b * 9 + i];
-    }
+    // (named scalars: as an array that is only filled on one branch the matrix went to scratch memory)
+    const bool cn_on = EXTRAS && ex.cn_points;
+    const float* Sm = ex.cn_mat + b * 9;
+    const float S0 = cn_on ? Sm[0] : 0.f, S1 = cn_on ? Sm[1] : 0.f, S2 = cn_on ? Sm[2] : 0.f, S3 = cn_on ? Sm[3] : 0.f, S4 = cn_on ? Sm[4] : 0.f,
+                S5 = cn_on ? Sm[5] : 0.f, S6 = cn_on ? Sm[6] : 0.f, S7 = cn_on ? Sm[7] : 0.f, S8 = cn_on ? Sm[8] : 0.f;
     auto add_canon = [&](int pl, float gx, float gy, float gz) {
-        add(pl, S[0] * gx + S[3] * gy + S[6] * gz, S[1] * gx + S[4] * gy + S[7] * gz, S[2] * gx + S[5] * gy + S[8] * gz);
+        add(pl, S0 * gx + S3 * gy + S6 * gz, S1 * gx + S4 * gy + S7 * gz, S2 * gx + S5 * gy + S8 * gz);
     };
     for (int pl = threadIdx.x; pl < n; pl += SCB_BLOCK) {              // own nearest neighbour
         const int i = k * n + pl, j = idx1[(size_t)b * N + i];
@@ -424,16 +424,28 @@ __global__ __launch_bounds__(SCB_BLOCK) void sample_chamfer_bwd_kernel(
     int2* mine = match + wave * cap;
     int cnt = 0;
     // 8 passes at a time: their loads are issued together (each pass used to wait out its own L2 round trip)
+    // (training step: the VP-diversity term's scatter -- ground-truth points whose nearest CENTRE is this primitive's -- rides
+    // in the same pass over the M entries; the centre of primitive k IS t_k, so its gradient goes straight into sum g)
+    float dvx = 0.f, dvy = 0.f, dvz = 0.f;
+    const bool dv_on = EXTRAS && ex.dv_dist1;
+    const float dv_c2 = dv_on ? gl * ex.dv_c2 : 0.0f;
     for (int e0 = 0; e0 < M; e0 += 8 * SCB_BLOCK) {
-        int iv[8];
+        int iv[8], dvi[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int e = e0 + u * SCB_BLOCK + threadIdx.x;
             iv[u] = e < M ? idx2[(size_t)b * M + e] : -1;
+            dvi[u] = (dv_on && e < M) ? ex.dv_idx2[(size_t)b * M + e] : -1;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             if (e0 + u * SCB_BLOCK >= M) break;
+            if (dv_on && dvi[u] == k) {
+                const int e = e0 + u * SCB_BLOCK + (int)threadIdx.x;
+                const float cc = dv_c2 / ex.dv_dist2[(size_t)b * M + e];
+                const F3 g = ld3(G2 + e * 3);
+                dvx += cc * (tx - g.x); dvy += cc * (ty - g.y); dvz += cc * (tz - g.z);
+            }
             const bool hit = iv[u] >= k * n && iv[u] < (k + 1) * n;
             const unsigned long long m = __ballot(hit);
             if (hit) mine[cnt + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = make_int2(e0 + u * SCB_BLOCK + (int)threadIdx.x, iv[u]);
@@ -460,16 +472,9 @@ __global__ __launch_bounds__(SCB_BLOCK) void sample_chamfer_bwd_kernel(
             add_canon(i - k * n, cc * (ac.x - gc.x), cc * (ac.y - gc.y), cc * (ac.z - gc.z));
         }
     }
-    if (EXTRAS && ex.dv_dist1) {
-        // VP-diversity: the centre of primitive k IS t_k, so its gradient goes straight into sum g (acc[9..11])
-        float sx = 0.f, sy = 0.f, sz = 0.f;
-        const float c2 = gl * ex.dv_c2;
-        for (int e = threadIdx.x; e < M; e += SCB_BLOCK) {
-            if (ex.dv_idx2[(size_t)b * M + e] != k) continue;
-            const float cc = c2 / ex.dv_dist2[(size_t)b * M + e];
-            const F3 g = ld3(G2 + e * 3);
-            sx += cc * (tx - g.x); sy += cc * (ty - g.y); sz += cc * (tz - g.z);
-        }
+    if (dv_on) {
+        // VP-diversity: the scatter part was gathered in the pass over the M entries above; the centre's own nearest neighbour
+        float sx = dvx, sy = dvy, sz = dvz;
         if (threadIdx.x == 0) {
             const int j = ex.dv_idx1[b * K + k];
             const float cc = (gl * ex.dv_c1) / ex.dv_dist1[b * K + k];

@@ -100,11 +100,20 @@ __device__ inline float vd_block_sum(const float* __restrict__ v, int count, flo
 // sum dv_dist1, sum dv_dist2, 0, 0, 0)
 constexpr int TP_THREADS = 256;
 __global__ __launch_bounds__(TP_THREADS) void trainstep_partial_kernel(const float* __restrict__ emd_dist, const float* __restrict__ cn_dist1,
-                                                                       const float* __restrict__ cn_dist2, const float* __restrict__ dv_dist1,
+                                                                       const float* __restrict__ cn_dist2, float* __restrict__ dv_dist1,
                                                                        const float* __restrict__ dv_dist2, int N, int M, int Mc, int K,
-                                                                       float* __restrict__ part) {
+                                                                       float* __restrict__ part,
+                                                                       const unsigned long long* __restrict__ dv_keys, int32_t* __restrict__ dv_idx1) {
     __shared__ float red[TP_THREADS / 64];
     const int b = blockIdx.x;
+    if (dv_keys) {                                       // the centres' partial nearest neighbours of vpdiv_fwd_kernel: merged here
+        for (int k = threadIdx.x; k < K; k += TP_THREADS) {
+            unsigned long long key = ~0ull;
+            for (int s = 0; s < VD_SLICES; ++s) { const unsigned long long c = dv_keys[((size_t)b * VD_SLICES + s) * K + k]; key = c < key ? c : key; }
+            dv_dist1[(size_t)b * K + k] = __int_as_float((int)(unsigned)(key >> 32)); dv_idx1[(size_t)b * K + k] = (int)(unsigned)key;
+        }
+        __syncthreads();                                 // this workgroup sums what it has just written
+    }
     const float s_emd = vd_block_sum<true, TP_THREADS>(emd_dist ? emd_dist + (size_t)b * N : nullptr, N, red);   // torch.sqrt(dist), train.py:195
     const float s_c1 = vd_block_sum<false, TP_THREADS>(cn_dist1 ? cn_dist1 + (size_t)b * N : nullptr, N, red);
     const float s_c2 = vd_block_sum<false, TP_THREADS>(cn_dist2 ? cn_dist2 + (size_t)b * Mc : nullptr, Mc, red);
@@ -123,9 +132,17 @@ __global__ __launch_bounds__(64) void trainstep_finalize_kernel(const float* __r
                                                                float w_view, float w_can, float w_sil, float w_div, float w_emd,
                                                                float cd_w1, float cd_w2, float* __restrict__ out) {
     const int lane = threadIdx.x;
-    float v = 0.0f;                                                         // lane l < 5 adds column l over the samples, in order
-    if (lane < 5) for (int b = 0; b < B; ++b) v += part[(size_t)b * 8 + lane];
-    const float s_emd = __shfl(v, 0, 64), s_c1 = __shfl(v, 1, 64), s_c2 = __shfl(v, 2, 64), s_d1 = __shfl(v, 3, 64), s_d2 = __shfl(v, 4, 64);
+    // lane l adds the samples l, l + 64, ... of every column, then a butterfly over the lanes: a fixed order, all loads in flight
+    float c[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int b = lane; b < B; b += 64) {
+        const float4 p = *reinterpret_cast<const float4*>(part + (size_t)b * 8);
+        c[0] += p.x; c[1] += p.y; c[2] += p.z; c[3] += p.w; c[4] += part[(size_t)b * 8 + 4];
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c[i] += __shfl_xor(c[i], o, 64);
+    const float s_emd = c[0], s_c1 = c[1], s_c2 = c[2], s_d1 = c[3], s_d2 = c[4];
     if (lane == 0) {
         const float view_cd = w_view * hot[3];
         const float obj_cd = has_cn ? w_can * (cd_w1 * (s_c1 / ((float)B * (float)N)) + cd_w2 * (s_c2 / ((float)B * (float)Mc))) : 0.0f;
@@ -145,14 +162,15 @@ extern "C" size_t vpn_vpdiv_workspace(int B, int K) { return B > 0 && K > 0 ? (s
 
 extern "C" int vpn_vpdiv_fwd(const float* params, const float* gt_points, int B, int K, int M, float* dist1, int32_t* idx1,
                              float* dist2, int32_t* idx2, void* workspace, void* stream) {
-    if (!params || !gt_points || !dist1 || !idx1 || !dist2 || !idx2 || !workspace || B <= 0 || K <= 0 || M <= 0) return VPN_E_BADARG;
-    if (((uintptr_t)workspace & 7) != 0) return VPN_E_BADARG;
+    if (!params || !gt_points || !dist2 || !idx2 || !workspace || B <= 0 || K <= 0 || M <= 0) return VPN_E_BADARG;
+    if ((dist1 != nullptr) != (idx1 != nullptr) || ((uintptr_t)workspace & 7) != 0) return VPN_E_BADARG;
     if (K > VPN_MAX_PRIMS || B > 65535 || B > 0x7fffffff / max(K, M)) return VPN_E_TOOBIG;
     const int nsl = max(1, VD_THREADS / K);
     const size_t lds = (size_t)(3 * K + (K & 1)) * sizeof(float) + (size_t)nsl * min(K, VD_THREADS) * sizeof(unsigned long long);
     unsigned long long* keys_part = (unsigned long long*)workspace;
     VPN_LAUNCH(vpdiv_fwd_kernel, dim3(VD_SLICES, B), dim3(VD_THREADS), lds, (hipStream_t)stream, params, gt_points, K, M, keys_part, dist2, idx2);
     VPN_LAUNCH_CHECK();
+    if (!dist1) return 0;                                // the caller merges (vpn_trainstep_finalize does, in its per-sample pass)
     VPN_LAUNCH(vpdiv_merge_kernel, dim3((B * K + 255) / 256), dim3(256), 0, (hipStream_t)stream, keys_part, B * K, K, dist1, idx1);
     VPN_LAUNCH_CHECK();
     return 0;
@@ -163,16 +181,20 @@ extern "C" size_t vpn_trainstep_workspace(int B) { return B > 0 ? (size_t)B * 8 
 extern "C" int vpn_trainstep_finalize(const float* hot_losses, const float* emd_dist, const float* cn_dist1, const float* cn_dist2,
                                       const float* dv_dist1, const float* dv_dist2, int B, int N, int M, int Mc, int K,
                                       float w_view, float w_can, float w_sil, float w_div, float w_emd, float cd_w1, float cd_w2,
-                                      void* workspace, float* out, void* stream) {
+                                      void* workspace, const void* dv_workspace, float* dv_dist1_out, int32_t* dv_idx1_out,
+                                      float* out, void* stream) {
     if (!hot_losses || !out || !workspace || B <= 0 || N <= 0 || M <= 0 || K <= 0) return VPN_E_BADARG;
-    if ((cn_dist1 != nullptr) != (cn_dist2 != nullptr) || (dv_dist1 != nullptr) != (dv_dist2 != nullptr)) return VPN_E_BADARG;
+    if (dv_workspace && (!dv_dist1_out || !dv_idx1_out || !dv_dist2 || dv_dist1)) return VPN_E_BADARG;
+    if ((cn_dist1 != nullptr) != (cn_dist2 != nullptr) || ((dv_dist1 != nullptr || dv_workspace != nullptr) != (dv_dist2 != nullptr))) return VPN_E_BADARG;
     if (cn_dist1 && Mc <= 0) return VPN_E_BADARG;
     float* part = (float*)workspace;
-    VPN_LAUNCH(trainstep_partial_kernel, dim3(B), dim3(TP_THREADS), 0, (hipStream_t)stream, emd_dist, cn_dist1, cn_dist2, dv_dist1, dv_dist2,
-               N, M, Mc, K, part);
+    // dv_workspace given: the VP-diversity keys of vpn_vpdiv_fwd(dist1 = NULL) are merged into dv_dist1_out / dv_idx1_out first
+    float* d1 = dv_workspace ? dv_dist1_out : const_cast<float*>(dv_dist1);
+    VPN_LAUNCH(trainstep_partial_kernel, dim3(B), dim3(TP_THREADS), 0, (hipStream_t)stream, emd_dist, cn_dist1, cn_dist2, d1, dv_dist2,
+               N, M, Mc, K, part, (const unsigned long long*)dv_workspace, dv_idx1_out);
     VPN_LAUNCH_CHECK();
     VPN_LAUNCH(trainstep_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, hot_losses, part, emd_dist ? 1 : 0, cn_dist1 ? 1 : 0,
-               dv_dist1 ? 1 : 0, B, N, M, Mc, K, w_view, w_can, w_sil, w_div, w_emd, cd_w1, cd_w2, out);
+               (dv_dist1 || dv_workspace) ? 1 : 0, B, N, M, Mc, K, w_view, w_can, w_sil, w_div, w_emd, cd_w1, cd_w2, out);
     VPN_LAUNCH_CHECK();
     return 0;
 }

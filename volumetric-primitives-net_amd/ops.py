@@ -882,17 +882,19 @@ class TrainStepLossFunction(Function):
                           _lib.ptr(mat), s)
             cn = (canon, gt_canon, mat, cd1, ci1, cd2, ci2, Mc)
         # ---- VP-diversity (train.py:185)
-        dv = None
+        dv = dws = None
         if w_div:
             dv = (torch.empty((B, K), **f32), torch.empty((B, K), **i32), torch.empty((B, M), **f32), torch.empty((B, M), **i32))
             dws = torch.empty((L.vpn_vpdiv_workspace(B, K) // 8,), dtype=torch.int64, device=dev)
-            _lib.call('vpn_vpdiv_fwd', _lib.ptr(params), _lib.ptr(gt_view), B, K, M, _lib.ptr(dv[0]), _lib.ptr(dv[1]), _lib.ptr(dv[2]),
+            # the centres' direction stays in the workspace: the finalisation's per-sample pass merges it
+            _lib.call('vpn_vpdiv_fwd', _lib.ptr(params), _lib.ptr(gt_view), B, K, M, None, None, _lib.ptr(dv[2]),
                       _lib.ptr(dv[3]), _lib.ptr(dws), s)
         out = torch.empty((6,), **f32)
         fws = torch.empty((L.vpn_trainstep_workspace(B) // 4,), **f32)
         _lib.call('vpn_trainstep_finalize', _lib.ptr(hot), _lib.ptr(emd_dist), _lib.ptr(cn[3]) if cn else None,
-                  _lib.ptr(cn[5]) if cn else None, _lib.ptr(dv[0]) if dv else None, _lib.ptr(dv[2]) if dv else None, B, N, M,
-                  cn[7] if cn else 0, K, w_view, w_can, w_sil if render else 0.0, w_div, w_emd, cd_w1, cd_w2, _lib.ptr(fws), _lib.ptr(out), s)
+                  _lib.ptr(cn[5]) if cn else None, None, _lib.ptr(dv[2]) if dv else None, B, N, M,
+                  cn[7] if cn else 0, K, w_view, w_can, w_sil if render else 0.0, w_div, w_emd, cd_w1, cd_w2, _lib.ptr(fws),
+                  _lib.ptr(dws) if dv else None, _lib.ptr(dv[0]) if dv else None, _lib.ptr(dv[1]) if dv else None, _lib.ptr(out), s)
         ctx.meta = (B, K, n, M, H, W, seed_host, int(sample_base), cd_w1, cd_w2, w_view, w_can, w_div, w_emd, render,
                     seed_dev is not None, cn[7] if cn else 0)
         # the sampler's launch keeps the seed it used at loss_ws + 8: backward reads it from there
