@@ -708,6 +708,20 @@ def main():
         except Exception as e:        # noqa: BLE001 -- reported, not swallowed
             return {'error': '%s: %s' % (type(e).__name__, e)}
 
+    # BASELINE config C5, one GPU: the step train.py really runs (all five losses, train.py:243-262), as one fused autograd
+    # node and as the module composition a train.py user writes; on a partly converged batch; and at the reference's default
+    # shape (config.py:8-9,34,49: K = 16, n = 128, B = 8, 128 x 128).  Measured BEFORE the CPU legs: after them the host
+    # issues launches several times slower for a while (observed: +40 us per launch, graph replays of many nodes 1.3-3x
+    # longer), which is the host's business, not the step's.
+    c5 = None
+    if rank == 0 and world == 1 and not args.no_extras and not args.no_c5:
+        c5 = {
+            'fused': guarded(lambda: train_step_block(vpn_amd, _lib, dev, 64, 64, 32, 256, 50, 10, 3, 'fused', not args.no_cpu_baseline)[0]),
+            'modules': guarded(lambda: train_step_block(vpn_amd, _lib, dev, 64, 64, 32, 256, 30, 5, 3, 'modules', False)[0]),
+            'fused_partly_converged': guarded(lambda: train_step_block(vpn_amd, _lib, dev, 64, 64, 32, 256, 50, 10, 3, 'fused', False, 'surface')[0]),
+            'reference_default_shape_fused': guarded(lambda: train_step_block(vpn_amd, _lib, dev, 8, 16, 128, 128, 50, 10, 3, 'fused', False)[0]),
+        }
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = guarded(cpu_baseline, params_all[:args.cpu_sample].detach().cpu(), gt_all[:args.cpu_sample].cpu(),
@@ -794,16 +808,8 @@ def main():
                                          guarded(variant, [vpn_amd.CUBOID] * (K // 2) + [vpn_amd.SPHERE] * (K - K // 2))}
         if world == 1 and not args.no_extras:      # row f1, outside the metric: the auction EMD loss of the same step
             out['emd'] = guarded(emd_extra, B, M, dev, vpn_amd, cpu is not None and 'error' not in cpu)
-        if world == 1 and not args.no_extras and not args.no_c5:
-            # BASELINE config C5, one GPU: the step train.py really runs (all five losses, train.py:243-262), as one fused
-            # autograd node and as the module composition a train.py user writes; then the reference's default shape
-            # (config.py:8-9,34,49: K = 16, n = 128, B = 8, 128 x 128)
-            out['c5'] = {
-                'fused': guarded(lambda: train_step_block(vpn_amd, _lib, dev, 64, 64, 32, 256, 50, 10, 3, 'fused', cpu is not None)[0]),
-                'modules': guarded(lambda: train_step_block(vpn_amd, _lib, dev, 64, 64, 32, 256, 30, 5, 3, 'modules', False)[0]),
-                'fused_partly_converged': guarded(lambda: train_step_block(vpn_amd, _lib, dev, 64, 64, 32, 256, 50, 10, 3, 'fused', False, 'surface')[0]),
-                'reference_default_shape_fused': guarded(lambda: train_step_block(vpn_amd, _lib, dev, 8, 16, 128, 128, 50, 10, 3, 'fused', False)[0]),
-            }
+        if c5 is not None:
+            out['c5'] = c5
         print(json.dumps(out), flush=True)
     if multi:
         dist.destroy_process_group()

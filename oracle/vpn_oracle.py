@@ -297,6 +297,7 @@ def philox_uniforms(seed, sample_base, B, K, n):
 FOVY_DEG = 49.13434207744484   # kaolin v0.1 DIBRenderer default field of view (recalled)
 X_CLAMP = 80.0                 # clamp of the coverage logit
 E_CLAMP = 8.0                  # clamp of the soft-min depth logit
+MESH_MIN_AREA2 = 1e-12         # twice the NDC area below which a face of mesh_raster has no inside
 EPS_H = 1e-3                   # squareplus smoothing of relu(1 - m2) inside the chord-length sqrt
 DELTA_S0 = 1e-12               # guard of the soft-min normaliser
 EPS_D = 1e-9                   # guard for ray components parallel to a box face
@@ -475,7 +476,8 @@ def mesh_raster(verts, faces, cam, H, W, sigma=1e-4):
         return (x1 - x0)[..., None] * (gy[None, None, :] - y0[..., None]) - (y1 - y0)[..., None] * (gx[None, None, :] - x0[..., None])
     d2 = torch.minimum(torch.minimum(seg_d2(ax, ay, bx, by), seg_d2(bx, by, cx, cy)), seg_d2(cx, cy, ax, ay))
     e0, e1, e2 = edge(ax, ay, bx, by), edge(bx, by, cx, cy), edge(cx, cy, ax, ay)
-    inside = ((e0 >= 0) & (e1 >= 0) & (e2 >= 0)) | ((e0 <= 0) & (e1 <= 0) & (e2 <= 0))
+    # e0 + e1 + e2 = twice the signed area: a face of (next to) no area has no inside (it used to be inside everywhere)
+    inside = (((e0 >= 0) & (e1 >= 0) & (e2 >= 0)) | ((e0 <= 0) & (e1 <= 0) & (e2 <= 0))) & (((e0 + e1) + e2).abs() > MESH_MIN_AREA2)
     logit = torch.where(inside, d2, -d2) / sigma
     a = torch.sigmoid(logit.clamp(-80.0, 80.0))
     a = torch.where(ok[..., None], a, torch.zeros_like(a))

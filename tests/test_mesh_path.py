@@ -177,6 +177,17 @@ def test_mesh_raster_edge_cases(vpn):
     a.sum().backward()
     ref = O.mesh_raster(v, torch.tensor([[0, 1, 2], [0, 0, 6], [0, 1, 6]]), cam, 32, 32, 1e-3)   # index 99 clamps to the last vertex
     assert bool(torch.isfinite(a).all()) and bool(torch.isfinite(vg.grad).all())
+    # a fully collapsed face covers nothing (it used to paint alpha ~ 1 over the tiles around it, the oracle
+    # over the whole image): at 128 x 128, several tile rings wide, the image with and without it is the same but for the
+    # one soft dot at the point itself
+    f_no = torch.tensor([[0, 1, 2]], dtype=torch.int32)
+    f_deg = torch.tensor([[0, 1, 2], [3, 3, 3], [0, 0, 6]], dtype=torch.int32)
+    v2 = v.clone(); v2[0, 3] = torch.tensor([0.0, -0.2, 0.2])                 # the collapsed face sits away from the real one
+    a_no = MeshRasterFunction.apply(v2.to(dev), f_no.to(dev), cam.to(dev), 128, 128, 1e-3)
+    a_deg = MeshRasterFunction.apply(v2.to(dev), f_deg.to(dev), cam.to(dev), 128, 128, 1e-3)
+    assert int(((a_deg - a_no).abs() > 0.05).sum()) <= 64 and float(a_deg.mean()) < 0.05
+    r_deg = O.mesh_raster(v2, f_deg.long(), cam, 128, 128, 1e-3)
+    assert float((a_deg.cpu() - r_deg).abs().max()) <= 2e-5
     assert float((a.detach().cpu() - ref).abs().max()) <= 2e-5
     assert float(vg.grad[0, 3:6].abs().max()) == 0.0                  # the face behind the camera got no gradient
     far = (v + torch.tensor([0.0, 5.0, 0.0])).to(dev).requires_grad_(True)

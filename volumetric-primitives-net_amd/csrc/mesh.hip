@@ -24,6 +24,7 @@ constexpr float MR_NEAR = 1e-3f;          // faces with a corner closer to the c
 constexpr float MR_X_CLAMP = 80.0f;
 constexpr float MR_X_CUT = 16.0f;         // outside a face's box inflated by sqrt(X_CUT sigma) its coverage is < 1.2e-7: skipped
 constexpr int MR_LDS_F4 = 64 * 2;         // staged faces per pass: (ax, ay, bx, by), (cx, cy, face, -)
+constexpr float MR_MIN_AREA2 = 1e-12f;    // twice the NDC area below which a face has no inside (oracle MESH_MIN_AREA2): 1e-8 of a 256^2 pixel
 
 // ---- projection: (x, y) in NDC (y in [-1,1] over the image height, +x right, +y up), z = depth along the optical axis
 __global__ __launch_bounds__(256) void mesh_project_kernel(const float* __restrict__ verts, const float* __restrict__ cam,
@@ -154,7 +155,9 @@ __device__ inline FaceEval eval_face(float px, float py, const float4 f0, const 
     const float e0 = (bx - ax) * (py - ay) - (by - ay) * (px - ax);
     const float e1 = (cx - bx) * (py - by) - (cy - by) * (px - bx);
     const float e2 = (ax - cx) * (py - cy) - (ay - cy) * (px - cx);
-    r.inside = (e0 >= 0.f && e1 >= 0.f && e2 >= 0.f) || (e0 <= 0.f && e1 <= 0.f && e2 <= 0.f);
+    // e0 + e1 + e2 = twice the signed area, whatever p: a face of (next to) no area has no inside -- with all three
+    // edge functions 0 it used to be "inside" for every pixel and painted alpha = 1 over every tile its box touched
+    r.inside = ((e0 >= 0.f && e1 >= 0.f && e2 >= 0.f) || (e0 <= 0.f && e1 <= 0.f && e2 <= 0.f)) && fabsf((e0 + e1) + e2) > MR_MIN_AREA2;
     const float xr = (r.inside ? r.d2 : -r.d2) * inv_sigma;
     r.live = fabsf(xr) <= MR_X_CLAMP;
     const float x = __builtin_amdgcn_fmed3f(xr, -MR_X_CLAMP, MR_X_CLAMP);
