@@ -477,6 +477,13 @@ def main():
     if multi:
         reducer = (GradAllReduce if args.collective == 'allreduce' else GradAllGather)(Bg, K, dev, rank, world)
     one = torch.ones((), device=dev)
+
+    def probe(tag):         # VPN_BENCH_C5_PROBE=1 (diagnostic): the fused C5 step timed at this point of the run
+        if os.environ.get('VPN_BENCH_C5_PROBE') and rank == 0 and world == 1:
+            r = train_step_block(vpn_amd, _lib, dev, 64, 64, 32, 256, 30, 5, 3, 'fused', False)[0]
+            print('PROBE %-28s c5 fused %.3f ms %s' % (tag, r['ms_per_step'], {k: v['avg_us'] for k, v in list(r['kernel_us'].items())[:3]}),
+                  file=sys.stderr, flush=True)
+    probe('after setup')
     # Philox key of the step: a device counter bumped on the stream at the end of every step, read by the sampler
     # kernels, so every replay of the captured graph draws fresh surface points (the reference resamples each step)
     seed_buf = torch.full((1,), 1234, dtype=torch.int64, device=dev)
@@ -553,6 +560,7 @@ def main():
         dt = float(tmax)
     ms_per_step = dt / args.steps * 1e3
     value = Bg * args.steps / dt
+    probe('after timed region')
     # ---- the same steps again under a HIP event pair on the launch stream: median of `windows` windows
     ev = event_windows(run_step, args.steps, args.windows)
     if multi:
@@ -610,6 +618,7 @@ def main():
                      'device_names': names, 'compute_us': round(float(tt[0]), 2), 'collective_us': round(float(tt[1]), 2),
                      'collective': args.collective, 'rehearsal': bool(args.rehearse)}
     seed_after = int(seed_buf.item())
+    probe('after steady')
 
     # ---- device time per C-ABI entry point and per KERNEL (HIP events on the launch stream, recorded by the
     # binding / by the library around every launch), same steps again, eagerly
@@ -619,6 +628,7 @@ def main():
             step(i)
         entry = kt.summary()            # entry point -> (calls, mean ms)
     kern = kp.summary()                 # kernel      -> (calls, mean ms)
+    probe('after profile loop')
     entry_us = {k: round(v[1] * 1e3, 2) for k, v in entry.items()}
     kernel_us = {k: {'calls_per_step': round(v[0] / ksteps, 2), 'avg_us': round(v[1] * 1e3, 2)} for k, v in kern.items()}
 

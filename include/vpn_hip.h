@@ -413,10 +413,13 @@ int vpn_trainstep_bwd(const float* params, const int32_t* kinds, uint64_t seed, 
  * become one workspace of vpn_emd_workspace(B, n) bytes.  iters >= 1, eps >= 0.  n need not be a multiple
  * of 1024 and B is not limited to 512 (emd_module.py:38-39). */
 /* max_group: cap on the number of workgroups that cooperate on one sample (0 = automatic: as many as can be
- * resident together, power of two <= 16; 1 = one workgroup per sample, no inter-workgroup barrier).  With more than
- * one the kernel is launched cooperatively (the runtime checks residency; the call falls back to 1 if it refuses) and
- * its group barrier gives up after ~0.5 s (dist = NaN, assignment = -1 for that sample) rather than hang when
- * something else holds the CUs: pass 1 when other streams or processes share the GPU.  Results do not depend on it. */
+ * resident together by hipOccupancyMaxActiveBlocksPerMultiprocessor x #CU, power of two <= 16; 1 = one workgroup per
+ * sample, nothing shared between workgroups).  The workgroups of a sample wait for each other's bids: the whole grid must
+ * be resident, which the occupancy bound guarantees for a plain launch on a GPU that runs nothing else at the time; the
+ * wait is bounded (~0.5 s: dist = NaN, assignment = -1 for that sample rather than a hang).  Pass 1 when other streams or
+ * processes share the GPU.  VPN_EMD_COOP_LAUNCH=1 in the environment launches cooperatively (the runtime then checks
+ * residency itself; the call falls back to 1 if it refuses) -- not the default: a cooperative launch in a process that has
+ * captured a HIP graph slows every later dispatch of that process by ~50 us.  Results do not depend on any of this. */
 size_t vpn_emd_workspace(int B, int n);
 int vpn_emd_fwd(const float* xyz1, const float* xyz2, int B, int n, float eps, int iters,
                 float* dist, int32_t* assignment, void* workspace, int max_group, void* stream);

@@ -240,3 +240,22 @@ def test_emd_group_size_does_not_change_the_result():
         d2, i2 = EmdFunction.apply(a, b, eps, iters, 4)
         assert torch.equal(i0, i1) and torch.equal(d0, d1) and torch.equal(i0, i2) and torch.equal(d0, d2)
         assert bool(torch.isfinite(d0).all()) and int(i0.min()) >= 0
+
+
+@pytest.mark.gpu
+def test_emd_cooperative_launch_is_opt_in_and_agrees(emd):
+    """Round 4: the group's grid is bounded by the occupancy query and launched plainly; VPN_EMD_COOP_LAUNCH=1 adds the
+    runtime's residency check (hipLaunchCooperativeKernel).  Same bits either way, for the team kernel (n <= 2048) and the
+    streaming one."""
+    import os
+    from vpn_amd.ops import EmdFunction
+    cases = [_clouds(3, 700, 41) + (0.005, 30), _clouds(1, 4500, 42) + (0.005, 8)]
+    refs = [O.emd_auction(a, b, e, it) for a, b, e, it in cases]
+    try:
+        for coop in ('0', '1'):
+            os.environ['VPN_EMD_COOP_LAUNCH'] = coop
+            for (a, b, e, it), (rd, ra) in zip(cases, refs):
+                dist, assign = EmdFunction.apply(a.to(DEV), b.to(DEV), e, it, None)
+                assert torch.equal(assign.cpu(), ra) and torch.equal(dist.cpu(), rd), (coop, a.shape)
+    finally:
+        os.environ.pop('VPN_EMD_COOP_LAUNCH', None)

@@ -1,7 +1,6 @@
 #!/bin/bash
 # usage: tools/exp_emd_variants.sh   (GPU box): walk / grid variants of the team auction kernel x team-size knobs
 cd $GRAFT_REPO_ROOT
-export VPN_EMD_PLAIN_LAUNCH=1
 for v in "-DEMD_WALK_SPLIT" "-DEMD_WALK_SPLIT -DEMD_EG=8 -DEMD_EGX=32" "-DEMD_EG=16 -DEMD_EGX=16" "-DEMD_EG=8 -DEMD_EGX=32"; do
   VPN_EXTRA_FLAGS="$v" python volumetric-primitives-net_amd/build.py --force > /dev/null 2>&1
   for t in "1024 64" "512 16" "1024 16" "2048 64" "256 8"; do

@@ -713,7 +713,6 @@ __global__ __launch_bounds__(EMD_THREADS) void emd_auction_grid_kernel(const flo
 #endif
 constexpr int EG3 = EMD_EG, EGX3 = EMD_EGX, ENC3 = EG3 * EG3 * EGX3;     // cells along y and z; at most EGX3 along x (the contiguous axis)
 constexpr unsigned EMD_MEM_NONE = 0xffffffffu;
-constexpr int EMD_NBKT = 16;             // work classes of a bid (radius of the last bid in half cells) the own bidders are grouped by
 
 struct EmdGrid3 { float mn[3], sc[3], cw[3], mg; int egx; };     // origin, cells per unit, cell width; geometric margin; cells along x
 __device__ inline int emd_cell3(float x, float mn, float sc, int cells = EG3) {
@@ -861,7 +860,7 @@ __global__ __launch_bounds__(EMD_THREADS, 8) void emd_auction_team_kernel(const 
                                                                           const float* __restrict__ xyz2, int B, int n,
                                                                           int npad, int G, int lgG, float eps, int iters,
                                                                           float* __restrict__ dist, int32_t* assignment,
-                                                                          float* wsf, unsigned* counters, int tnum, int tmax, int sort_on) {
+                                                                          float* wsf, unsigned* counters, int tnum, int tmax) {
     extern __shared__ __attribute__((aligned(16))) float emd_lds[];
     const int nown = npad >> lgG;                                // points this workgroup bids for (local index i >> lgG)
     float4* t4 = reinterpret_cast<float4*>(emd_lds);                                               // SORTED by cell, then index
@@ -873,8 +872,6 @@ __global__ __launch_bounds__(EMD_THREADS, 8) void emd_auction_team_kernel(const 
     short* inv_l = assign_l + npad;                                                                // sorted position -> point | -1
     unsigned short* ulist = reinterpret_cast<unsigned short*>(inv_l + npad);                       // unassigned points, ascending
     unsigned short* ownu = ulist + npad;                                                           // list positions of the own ones
-    unsigned char* rbkt = reinterpret_cast<unsigned char*>(ownu + nown);                           // work class of each own bidder's last bid
-    __shared__ unsigned bcnt[EMD_NBKT];
     __shared__ unsigned short cell_start[ENC3 + 8];
     __shared__ float red[EMD_WAVES][6];
     __shared__ EmdGrid3 grid;
@@ -977,7 +974,6 @@ __global__ __launch_bounds__(EMD_THREADS, 8) void emd_auction_team_kernel(const 
             const int i = min((l << lgG) + g, n - 1);
             ox[l] = p1[(size_t)i * 3]; oy[l] = p1[(size_t)i * 3 + 1]; oz[l] = p1[(size_t)i * 3 + 2];
             mem[l] = EMD_MEM_NONE;
-            rbkt[l] = 0;
         }
         __syncthreads();                                         // cursor (aliases top_l) and the unsorted member lists are done with
         for (int j = tid; j < npad; j += EMD_THREADS) { assign_l[j] = -1; inv_l[j] = -1; top_l[j] = 0ull; }
@@ -995,7 +991,6 @@ __global__ __launch_bounds__(EMD_THREADS, 8) void emd_auction_team_kernel(const 
     const float r_first_floor = 0.03f * fmaxf(fmaxf(grid.cw[0] * (float)egx, grid.cw[1] * EG3), grid.cw[2] * EG3);
     const float r0 = fmaxf(r_first, r_first_floor) > 0.0f ? fmaxf(r_first, r_first_floor) : 1.0f;
     const float slack = 1.0e-5f + 4.0f * grid.mg;
-    const float bkt_scale = 2.0f * fmaxf(grid.sc[1], grid.sc[2]);     // half (y, z) cells per unit of radius (0 for a flat cloud: one class)
 
     for (int it = 0; ok && it < iters; ++it) {
         const bool last = it == iters - 1;
@@ -1008,7 +1003,6 @@ __global__ __launch_bounds__(EMD_THREADS, 8) void emd_auction_team_kernel(const 
         // ---- unassigned points in ascending order (every copy builds the same list) and the own ones among them:
         //      thread t looks at points t and t + 1024 (same residue mod G); four 8-bit counters in one DPP scan
         const bool mine = (tid & (G - 1)) == g;
-        if (tid < EMD_NBKT) bcnt[tid] = 0;                       // (read last before the previous round's last barrier)
         const int c0 = (tid < n && assign_l[tid] == -1) ? 1 : 0;
         const int c1 = (tid + EMD_THREADS < n && assign_l[tid + EMD_THREADS] == -1) ? 1 : 0;
         const int pk = c0 | (c1 << 8) | ((mine ? c0 : 0) << 16) | ((mine ? c1 : 0) << 24);
@@ -1039,26 +1033,7 @@ __global__ __launch_bounds__(EMD_THREADS, 8) void emd_auction_team_kernel(const 
             const int u1 = (int)((totA & 0xffffu) + (befB & 0xffffu) + ((ex >> 8) & 0xffu));
             if (c0) ulist[u0] = (unsigned short)tid;
             if (c1) ulist[u1] = (unsigned short)(tid + EMD_THREADS);
-            // The own bidders are GROUPED BY THE WORK of their last bid (its radius in half cells), heaviest class first: a
-            // wave's teams then walk balls of similar size -- in index order a wave mixed the bidders of several primitives,
-            // and ran as long as its heaviest (the order of the own list means nothing: granules carry the list position)
-            int br0 = 0, br1 = 0;                                // class | rank inside it << 8
-            if (sort_on && mine) {
-                if (c0) { const int bk = rbkt[tid >> lgG]; br0 = bk | ((int)atomicAdd(&bcnt[bk], 1u) << 8); }
-                if (c1) { const int bk = rbkt[(tid + EMD_THREADS) >> lgG]; br1 = bk | ((int)atomicAdd(&bcnt[bk], 1u) << 8); }
-            }
-            if (sort_on) {
-                __syncthreads();
-                if (mine && (c0 || c1)) {
-                    int base0 = 0, base1 = 0;
-                    for (int q = EMD_NBKT - 1; q > 0; --q) {     // classes above one's own come first
-                        const int cq = (int)bcnt[q];
-                        base0 += q > (br0 & 255) ? cq : 0; base1 += q > (br1 & 255) ? cq : 0;
-                    }
-                    if (c0) ownu[base0 + (br0 >> 8)] = (unsigned short)u0;
-                    if (c1) ownu[base1 + (br1 >> 8)] = (unsigned short)u1;
-                }
-            } else if (mine) {
+            if (mine) {
                 if (c0) ownu[(befA >> 16) + ((ex >> 16) & 0xffu)] = (unsigned short)u0;
                 if (c1) ownu[(totA >> 16) + (befB >> 16) + ((ex >> 24) & 0xffu)] = (unsigned short)u1;
             }
@@ -1123,9 +1098,6 @@ __global__ __launch_bounds__(EMD_THREADS, 8) void emd_auction_team_kernel(const 
                 }
             }
             if (have && tl == 0) {
-                // work class of the NEXT bid: the radius its memory will give is at least the one that held this bid's top two
-                const float rn = (r.j >= 0 && r.s > -1e8f) ? (3.0f - r.s) * bkt_scale : 0.0f;
-                rbkt[l] = (unsigned char)min(max((int)rn, 0), EMD_NBKT - 1);
                 mem[l] = (r.i >= 0 && r.j >= 0 && r.i != r.j) ? ((unsigned)r.i | ((unsigned)r.j << 16)) : EMD_MEM_NONE;
                 const float v = (r.b - r.s) + eps;                                          // :175-176
                 const unsigned t = (unsigned)min(max(r.i, 0), n - 1);
@@ -1260,6 +1232,13 @@ static bool emd_env_flag(const char* name) {
     return e && e[0] == '1';
 }
 static bool emd_force_streaming() { return emd_env_flag("VPN_EMD_STREAMING"); }
+// The group size G is bounded by hipOccupancyMaxActiveBlocksPerMultiprocessor x #CU on every call, so the grid of a PLAIN
+// launch is resident as a whole unless something else holds the CUs (then the bounded spin gives up: NaN / -1, a loud
+// failure).  VPN_EMD_COOP_LAUNCH=1 launches cooperatively instead, which adds the runtime's own residency check -- off by
+// default since round 4: in a process that has captured a HIP graph, ONE cooperative launch makes every later dispatch of
+// the process ~50 us slower (profiles/r04_coop_launch_side_effect.txt: the C5 step 1.90 -> 2.55 ms, every kernel of it
+// +45..65 us, eager and replayed), and it costs ~40 us of host time per call.
+static bool emd_coop_launch() { return emd_env_flag("VPN_EMD_COOP_LAUNCH"); }
 
 static size_t emd_state_bytes(int B, int n) { return (size_t)B * n * EMD_WS_PLANES * sizeof(float); }
 
@@ -1283,7 +1262,7 @@ extern "C" int vpn_emd_fwd(const float* xyz1, const float* xyz2, int B, int n, f
         // the training call (n = SAMPLE_NUM * VP_NUM = 2048): pruned scan, static ownership, granule exchange
         const int npad = (n + 63) / 64 * 64;
         const void* kern = reinterpret_cast<const void*>(emd_auction_team_kernel);
-        auto lds_of = [&](int G) { return (size_t)npad * 32 + (size_t)(npad / G) * 19; };
+        auto lds_of = [&](int G) { return (size_t)npad * 32 + (size_t)(npad / G) * 18; };
         static size_t raised = 0;
         if (lds_of(1) > raised) {
             const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(1));
@@ -1304,15 +1283,14 @@ extern "C" int vpn_emd_fwd(const float* xyz1, const float* xyz2, int B, int n, f
             if ((long long)padded * cand <= (long long)cus * per_cu) { G = cand; lgG = lg; break; }
         }
         const unsigned lds = (unsigned)lds_of(G);
-        const bool coop = G > 1 && !emd_env_flag("VPN_EMD_PLAIN_LAUNCH");
+        const bool coop = G > 1 && emd_coop_launch();
         int tnum = 1024, tmax = 16;                              // lanes the own bidders of a round are spread over; largest team
         if (const char* e = getenv("VPN_EMD_TNUM")) tnum = atoi(e) > 0 ? atoi(e) : tnum;
         if (const char* e = getenv("VPN_EMD_TMAX")) tmax = atoi(e) > 0 ? atoi(e) : tmax;
         if (tmax > 64) tmax = 64;
-        int sort_on = emd_env_flag("VPN_EMD_NOSORT") ? 0 : 1;     // A/B: the own bidders in index order
         if (coop) {
             void* args[] = {(void*)&xyz1, (void*)&xyz2, (void*)&B, (void*)&n, (void*)&npad, (void*)&G, (void*)&lgG, (void*)&eps, (void*)&iters,
-                            (void*)&dist, (void*)&assignment, (void*)&wsf, (void*)&counters, (void*)&tnum, (void*)&tmax, (void*)&sort_on};
+                            (void*)&dist, (void*)&assignment, (void*)&wsf, (void*)&counters, (void*)&tnum, (void*)&tmax};
             vpn::prof_begin("emd_auction_team_kernel", s);
             const hipError_t e = hipLaunchCooperativeKernel(kern, dim3(padded * G), dim3(EMD_THREADS), args, lds, s);
             vpn::prof_end(s);
@@ -1322,7 +1300,7 @@ extern "C" int vpn_emd_fwd(const float* xyz1, const float* xyz2, int B, int n, f
             G = 1; lgG = 0;
         }
         VPN_LAUNCH(emd_auction_team_kernel, dim3(padded * G), dim3(EMD_THREADS), (unsigned)lds_of(G), s, xyz1, xyz2, B, n, npad, G, lgG, eps,
-                   iters, dist, assignment, wsf, counters, tnum, tmax, sort_on);
+                   iters, dist, assignment, wsf, counters, tnum, tmax);
         VPN_LAUNCH_CHECK();
         return 0;
     }
@@ -1340,7 +1318,7 @@ extern "C" int vpn_emd_fwd(const float* xyz1, const float* xyz2, int B, int n, f
             raised[grid] = lds;
         }
         int G = emd_group_size_of(kern, lds, B, n, max_group);
-        if (G > 1) {
+        if (G > 1 && emd_coop_launch()) {
             void* args[] = {(void*)&xyz1, (void*)&xyz2, (void*)&B, (void*)&n, (void*)&npad, (void*)&G, (void*)&eps, (void*)&iters,
                             (void*)&dist, (void*)&assignment, (void*)&wsf, (void*)&counters};
             vpn::prof_begin(grid ? "emd_auction_grid_kernel" : "emd_auction_local_kernel", s);
@@ -1361,7 +1339,7 @@ extern "C" int vpn_emd_fwd(const float* xyz1, const float* xyz2, int B, int n, f
         return 0;
     }
     int G = emd_group_size(B, n, max_group);
-    if (G > 1) {
+    if (G > 1 && emd_coop_launch()) {
         // the G workgroups of a sample synchronise with each other: a COOPERATIVE launch makes the runtime check that
         // the whole grid can be resident at once; if it says no, fall back to one workgroup per sample
         void* args[] = {(void*)&xyz1, (void*)&xyz2, (void*)&B, (void*)&n, (void*)&G, (void*)&eps, (void*)&iters,
