@@ -720,9 +720,10 @@ def main():
 
     # BASELINE config C5, one GPU: the step train.py really runs (all five losses, train.py:243-262), as one fused autograd
     # node and as the module composition a train.py user writes; on a partly converged batch; and at the reference's default
-    # shape (config.py:8-9,34,49: K = 16, n = 128, B = 8, 128 x 128).  Measured BEFORE the CPU legs: after them the host
-    # issues launches several times slower for a while (observed: +40 us per launch, graph replays of many nodes 1.3-3x
-    # longer), which is the host's business, not the step's.
+    # shape (config.py:8-9,34,49: K = 16, n = 128, B = 8, 128 x 128).  (The slowdown of this block seen inside
+    # the full line in round 4 -- every dispatch +45-65 us, eager and replayed -- was NOT the CPU legs: it was the EMD
+    # kernel's cooperative launch in a process that had captured a HIP graph before, profiles/r04_coop_launch_side_effect.txt;
+    # the kernel is launched plainly since.)
     c5 = None
     if rank == 0 and world == 1 and not args.no_extras and not args.no_c5:
         c5 = {

@@ -676,10 +676,11 @@ __global__ __launch_bounds__(64, 4) void raster_bwd_kernel(const float4* __restr
 // once, and there is one launch (and one tail) instead of two.  The gradient partials are those of d total / d(ray
 // coefficients) for an upstream gradient of 1: d total is linear in it, raster_bwd_finish_kernel multiplies by the
 // actual upstream gradient when backward runs.
-// waves per SIMD the register allocation aims at.  5 = 96 VGPRs with four spilled dwords (101 without the bound):
-// measured 55.5 us against 56.6-57.8 with 4 on the same box; 6 (80 VGPRs) spills in earnest: 63 us.
+// waves per SIMD the register allocation aims at, module-path instantiation.  4 = 107 VGPRs and no scratch; 5 = 96 VGPRs
+// with nine spilled dwords (36 B scratch) -- the C2 step times the same with either on one box
+// (profiles/r04_c2_waves_ab.txt: 34.9 us both, the kernel 22.3 against 21.9 us); 6 (80 VGPRs) spills in earnest: 63 us.
 #ifndef R_TOTAL_WAVES
-#define R_TOTAL_WAVES 5
+#define R_TOTAL_WAVES 4
 #endif
 #ifdef R_EXP_TRACE
 // timeline experiment (tools/raster_timeline.py): per tile wave (blockIdx) its start and end on the 100 MHz wall clock,

@@ -25,15 +25,20 @@ __device__ inline unsigned long long vd_key(float d2, int e) {
 __global__ __launch_bounds__(VD_THREADS) void vpdiv_fwd_kernel(const float* __restrict__ params, const float* __restrict__ gt,
                                                                int K, int M, unsigned long long* __restrict__ keys_part,
                                                                float* __restrict__ dist2, int32_t* __restrict__ idx2) {
-    extern __shared__ __attribute__((aligned(16))) float vd_lds[];          // K centres (x, y, z), then nsl x K 64-bit keys
+    extern __shared__ __attribute__((aligned(16))) float vd_lds[];          // K centres (x, y, z), nsl x K 64-bit keys, the slice's points
     float* cx = vd_lds; float* cy = cx + K; float* cz = cy + K;
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(cz + K + (K & 1));
+    const int nslk = max(1, VD_THREADS / K) * min(K, VD_THREADS);
+    float* gs = reinterpret_cast<float*>(keys + nslk);                     // [3 * per]: the slice of the cloud (both scans read it 64+ times)
     const int sl = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const float* prm = params + (size_t)b * K * VPN_PARAM_STRIDE;
     for (int k = tid; k < K; k += VD_THREADS) { cx[k] = prm[k * VPN_PARAM_STRIDE + 7]; cy[k] = prm[k * VPN_PARAM_STRIDE + 8]; cz[k] = prm[k * VPN_PARAM_STRIDE + 9]; }
     __syncthreads();
-    const float* G = gt + (size_t)b * M * 3;
+    const float* Gg = gt + (size_t)b * M * 3;
     const int per = (M + VD_SLICES - 1) / VD_SLICES, e0 = sl * per, e1 = min(M, e0 + per);
+    for (int i = tid; i < 3 * (e1 - e0); i += VD_THREADS) gs[i] = Gg[(size_t)e0 * 3 + i];
+    __syncthreads();
+    const float* G = gs - (size_t)e0 * 3;                                   // indexed by the global point number like the cloud itself
     auto near = [](float d2, float m) { return __float_as_int(d2) <= __float_as_int(m) + 2; };      // d2, m >= 0: bits order like values
     // direction 2: every ground-truth point's nearest centre
     for (int e = e0 + tid; e < e1; e += VD_THREADS) {
@@ -104,7 +109,6 @@ __global__ __launch_bounds__(TP_THREADS) void trainstep_partial_kernel(const flo
                                                                        const float* __restrict__ dv_dist2, int N, int M, int Mc, int K,
                                                                        float* __restrict__ part,
                                                                        const unsigned long long* __restrict__ dv_keys, int32_t* __restrict__ dv_idx1) {
-    __shared__ float red[TP_THREADS / 64];
     const int b = blockIdx.x;
     if (dv_keys) {                                       // the centres' partial nearest neighbours of vpdiv_fwd_kernel: merged here
         for (int k = threadIdx.x; k < K; k += TP_THREADS) {
@@ -114,11 +118,26 @@ __global__ __launch_bounds__(TP_THREADS) void trainstep_partial_kernel(const flo
         }
         __syncthreads();                                 // this workgroup sums what it has just written
     }
-    const float s_emd = vd_block_sum<true, TP_THREADS>(emd_dist ? emd_dist + (size_t)b * N : nullptr, N, red);   // torch.sqrt(dist), train.py:195
-    const float s_c1 = vd_block_sum<false, TP_THREADS>(cn_dist1 ? cn_dist1 + (size_t)b * N : nullptr, N, red);
-    const float s_c2 = vd_block_sum<false, TP_THREADS>(cn_dist2 ? cn_dist2 + (size_t)b * Mc : nullptr, Mc, red);
-    const float s_d1 = vd_block_sum<false, TP_THREADS>(dv_dist1 ? dv_dist1 + (size_t)b * K : nullptr, K, red);
-    const float s_d2 = vd_block_sum<false, TP_THREADS>(dv_dist2 ? dv_dist2 + (size_t)b * M : nullptr, M, red);
+    // the five sums in ONE pass: every thread's loads are in flight together, one exchange through LDS (fixed order:
+    // thread-strided partial sums, lanes by butterfly, waves in order)
+    float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (emd_dist) for (int i = threadIdx.x; i < N; i += TP_THREADS) v[0] += sqrtf(emd_dist[(size_t)b * N + i]);     // torch.sqrt(dist), train.py:195
+    if (cn_dist1) for (int i = threadIdx.x; i < N; i += TP_THREADS) v[1] += cn_dist1[(size_t)b * N + i];
+    if (cn_dist2) for (int i = threadIdx.x; i < Mc; i += TP_THREADS) v[2] += cn_dist2[(size_t)b * Mc + i];
+    if (dv_dist1) for (int i = threadIdx.x; i < K; i += TP_THREADS) v[3] += dv_dist1[(size_t)b * K + i];
+    if (dv_dist2) for (int i = threadIdx.x; i < M; i += TP_THREADS) v[4] += dv_dist2[(size_t)b * M + i];
+    __shared__ float red5[TP_THREADS / 64][5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v[q] += __shfl_xor(v[q], o, 64);
+        if ((threadIdx.x & 63) == 0) red5[threadIdx.x >> 6][q] = v[q];
+    }
+    __syncthreads();
+    float t5[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) { t5[q] = 0.0f; for (int w = 0; w < TP_THREADS / 64; ++w) t5[q] += red5[w][q]; }
+    const float s_emd = t5[0], s_c1 = t5[1], s_c2 = t5[2], s_d1 = t5[3], s_d2 = t5[4];
     if (threadIdx.x == 0) {
         float* o = part + (size_t)b * 8;
         o[0] = s_emd; o[1] = s_c1; o[2] = s_c2; o[3] = s_d1; o[4] = s_d2; o[5] = 0.0f; o[6] = 0.0f; o[7] = 0.0f;
@@ -166,7 +185,10 @@ extern "C" int vpn_vpdiv_fwd(const float* params, const float* gt_points, int B,
     if ((dist1 != nullptr) != (idx1 != nullptr) || ((uintptr_t)workspace & 7) != 0) return VPN_E_BADARG;
     if (K > VPN_MAX_PRIMS || B > 65535 || B > 0x7fffffff / max(K, M)) return VPN_E_TOOBIG;
     const int nsl = max(1, VD_THREADS / K);
-    const size_t lds = (size_t)(3 * K + (K & 1)) * sizeof(float) + (size_t)nsl * min(K, VD_THREADS) * sizeof(unsigned long long);
+    const int per = (M + VD_SLICES - 1) / VD_SLICES;
+    const size_t lds = (size_t)(3 * K + (K & 1)) * sizeof(float) + (size_t)nsl * min(K, VD_THREADS) * sizeof(unsigned long long)
+                       + (size_t)3 * per * sizeof(float);
+    if (lds > 64 * 1024) return VPN_E_TOOBIG;
     unsigned long long* keys_part = (unsigned long long*)workspace;
     VPN_LAUNCH(vpdiv_fwd_kernel, dim3(VD_SLICES, B), dim3(VD_THREADS), lds, (hipStream_t)stream, params, gt_points, K, M, keys_part, dist2, idx2);
     VPN_LAUNCH_CHECK();
