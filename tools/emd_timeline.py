@@ -27,7 +27,8 @@ for b in (0, B // 2):
     G = int((tr[:, 0, 0] != 0).sum())
     t_launch = tr[:G, 63, 7].min()
     print('sample %d: G = %d; first round starts %.1f us after the kernel began; last round ends at %.1f us' % (b, G, (tr[:G, 0, 0].min() - t_launch) / 100.0, (tr[:G, :50, 4].max() - t_launch) / 100.0))
-    print(' it     U  Uown(max)  T  rows/bid evals/bid | list  bid(max) bid(min)  wait(min)  assign | round us')
+    ft = w[b * 10 * n + 8 * n: b * 10 * n + 8 * n + 16 * 64 * 4].reshape(16, 64, 4).astype('int64')   # balanced form: stamps after A, B, C; rows + batches << 24
+    print(' it     U  Uown(max)  T  rows/bid evals/bid | list  bid(max) bid(min)  wait(min)  assign | round us | balanced form, slowest workgroup: A  B  C  D us, rows, batches')
     for it in range(50):
         r = tr[:G, it]
         if r[0, 0] == 0: break
@@ -38,4 +39,11 @@ for b in (0, B // 2):
         print(' %2d  %4d  %4d      %2d  %7.1f %8.1f | %4.1f  %6.1f  %6.1f   %6.1f   %5.1f | %6.1f' % (
             it, U, uown.max(), T, r[:, 7].sum() / max(1, uown.sum()), r[:, 6].sum() / max(1, uown.sum()),
             us((r[:, 1] - r[:, 0]).max()), us((r[:, 2] - r[:, 1]).max()), us((r[:, 2] - r[:, 1]).min()), us((r[:, 3] - r[:, 2]).min()),
-            us((r[:, 4] - r[:, 3]).max()), us(r[:, 4].max() - r[:, 0].min())))
+            us((r[:, 4] - r[:, 3]).max()), us(r[:, 4].max() - r[:, 0].min())), end='')
+        f = ft[:G, it]
+        if f[:, 3].any():
+            gs = int((r[:, 2] - r[:, 1]).argmax())
+            print(' | %5.1f %5.1f %5.1f %5.1f  %5d %d' % (us(f[gs, 0] - r[gs, 1]), us(f[gs, 1] - f[gs, 0]), us(f[gs, 2] - f[gs, 1]), us(r[gs, 2] - f[gs, 2]),
+                                                         f[gs, 3] & 0xffff, f[gs, 3] >> 24), ' ~%dk targets' % ((f[gs, 3] >> 16) & 0xff))
+        else:
+            print()

@@ -797,6 +797,18 @@ __device__ inline int emd_team_min(int v, int T) {
     return v;
 }
 
+// a value as an unsigned key of the same order (and back); 0 is no value
+__device__ inline unsigned emd_ord(float v) { const unsigned u = __float_as_uint(v); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ inline float emd_unord(unsigned o) { return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o); }
+// the price filter of the Bid scans: can target t reach a value of 3 - R for the bidder at (x1, y1, z1)?  d <= R - price,
+// tested on the squares (no square root; R carries the auction's `slack`, many times the rounding of this test)
+__device__ inline bool emd_may_matter(const float4 t, float x1, float y1, float z1, float R) {
+    const float dx = t.x - x1, dy = t.y - y1, dz = t.z - z1;
+    const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+    const float q = R - t.w;
+    return d2 <= q * fabsf(q);                                    // q < 0 (the price alone is too high): -q^2 < d2
+}
+
 struct EmdTables3 {
     const float4* t4;                 // targets (x, y, z, price), sorted by cell then index
     const unsigned short* orig;
@@ -848,6 +860,338 @@ __device__ inline void emd_walk(float x1, float y1, float z1, float R, int tl, i
     }
 }
 
+// one (y, z) row of cells against the ball of radius R (R2 = R * R) around the bidder: the sorted positions [kst, kst + cnt)
+// of the row's chord -- the arithmetic of emd_walk, for the balanced form of the Bid phase
+__device__ inline void emd_row_chord(float x1, float y1, float z1, float R2, int cy, int cz, const EmdGrid3& g,
+                                     const unsigned short* cell_start, int& kst, int& cnt) {
+    const float ylo = g.mn[1] + (float)cy * g.cw[1], zlo = g.mn[2] + (float)cz * g.cw[2];
+    const float dy = fmaxf(fmaxf(ylo - y1, y1 - (ylo + g.cw[1])) - g.mg, 0.0f);
+    const float dz = fmaxf(fmaxf(zlo - z1, z1 - (zlo + g.cw[2])) - g.mg, 0.0f);
+    const float h2 = (R2 - dy * dy) - dz * dz;
+    kst = 0; cnt = 0;
+    if (!(h2 >= 0.0f)) return;
+    const float h = __builtin_amdgcn_sqrtf(h2) * 1.000001f + g.mg;
+    const int cx0 = emd_cell3(x1 - h, g.mn[0], g.sc[0], g.egx), cx1 = emd_cell3(x1 + h, g.mn[0], g.sc[0], g.egx);
+    const int base = (cz * EG3 + cy) * g.egx;
+    kst = (int)cell_start[base + cx0];
+    cnt = (int)cell_start[base + cx1 + 1] - kst;
+}
+
+// state of emd_auction_team_kernel that its out-of-line part shares (static LDS; the dynamic part is laid out from npad, lgG)
+__shared__ unsigned short emd3_cell_start[ENC3 + 8];
+__shared__ EmdGrid3 emd3_grid;
+__shared__ unsigned emd3_wtot[16];
+extern __shared__ __attribute__((aligned(16))) float emd3_dyn[];
+#ifdef EMD_TRACE
+__shared__ unsigned emd3_tr_evals, emd3_tr_rows;
+#endif
+
+// BALANCED FORM (rounds with many bidders).  In a team a lane's work is whole rows of its own bidder and a wave
+// waits for its heaviest lane: ~2.2x the mean on the step's clouds (tools/emd_balance_sim.py).  Here the rows of
+// ALL own bidders become one list -- (first position, count, bidder slot) per row --, the list is counting-sorted
+// by count, and lane t takes the rows of rank t, 2047 - t, 2048 + t, ...: the 64 lanes of a wave hold rows of
+// (nearly) the same length, every lane gets long and short ones.  The lanes no longer belong to a bidder, so the
+// survivors of the price filter go to the bidder's best / second through two LDS 64-bit atomic maxima of
+// (value, lowest original index first, position): `old = max(best, key); max(second, min(old, key))` leaves the
+// largest key in best and the largest of the rest in second whatever the order -- the same two values the
+// teams find, and the index rule of the tie pass for free.
+// Its lists have LDS of their own behind the auction's state (one workgroup per CU: 160 KB).  A batch is up to
+// EMD_FLAT_SLOTS bidders and EMD_FLAT_ROWS rows: one batch per round at G >= 4.
+constexpr int EMD_FLAT_SLOTS = 512, EMD_FLAT_ROWS = 8192, EMD_FLAT_RPL = EMD_FLAT_ROWS / EMD_THREADS;
+constexpr int EMD_FLAT_BYTES = 32 * EMD_FLAT_SLOTS + 4 * EMD_FLAT_ROWS + 2 * EMD_FLAT_SLOTS + 2 * (EMD_FLAT_SLOTS + 4) + 512;
+static_assert(EMD_FLAT_BYTES % 8 == 0 && EMD_FLAT_SLOTS <= 512 && EMD_FLAT_ROWS <= 65535, "nine slot bits in a row entry; 16-bit row numbers");
+__shared__ int emd3_flat_off;        // a bidder lost its memory (degenerate clouds): its ball has to grow again, the teams do that
+
+__device__ __forceinline__ void emd_flat_bid(int npad, int lgG, int Uown, int n, float eps, float slack, unsigned tag,
+                                             unsigned long long* bid_w, unsigned* ftrace) {
+    const int nown = npad >> lgG;
+    float4* t4 = reinterpret_cast<float4*>(emd3_dyn);
+    unsigned long long* top_l = reinterpret_cast<unsigned long long*>(t4 + npad);
+    float* ox = reinterpret_cast<float*>(top_l + npad); float* oy = ox + nown; float* oz = oy + nown;
+    unsigned* mem = reinterpret_cast<unsigned*>(oz + nown);
+    unsigned short* orig = reinterpret_cast<unsigned short*>(mem + nown);
+    unsigned short* ulist = orig + 3 * (size_t)npad;             // behind assign_l and inv_l
+    unsigned short* ownu = ulist + npad;
+    const unsigned short* cell_start = emd3_cell_start;
+    const EmdGrid3& grid = emd3_grid;
+    unsigned* const wtot = emd3_wtot;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    static_assert(EG3 <= 8, "three bits per cell coordinate in fbox");
+    constexpr int NB = EMD_FLAT_SLOTS;
+    float4* fxyzr = reinterpret_cast<float4*>(ownu + nown);                       // [NB] the slot's bidder and its radius
+    unsigned long long* fbest = reinterpret_cast<unsigned long long*>(fxyzr + NB);// [NB]
+    unsigned long long* fsecond = fbest + NB;                                     // [NB]
+    unsigned* fsorted = reinterpret_cast<unsigned*>(fsecond + NB);                // [EMD_FLAT_ROWS] rows by count, descending
+    unsigned short* fbox = reinterpret_cast<unsigned short*>(fsorted + EMD_FLAT_ROWS);   // [NB] cy0 | cz0 << 3 | (ny - 1) << 6
+    unsigned short* frow = fbox + NB;                                             // [NB + 4] first row of the slot
+    unsigned* fhist = reinterpret_cast<unsigned*>(frow + NB + 4);                 // [64] rows per count
+    unsigned* fcur = fhist + 64;                                                  // [64]
+    __shared__ int f_nb, f_nr, f_nz;
+#ifdef EMD_TRACE
+    __shared__ unsigned f_nc;
+    if (tid == 0) f_nc = 0u;
+#endif
+    for (int k0 = 0; k0 < Uown;) {
+        // -- A: one lane per bidder: radius from its memory, the square of rows around it
+        int nrows = 0, kb = k0 + tid;
+        const bool slot = tid < NB && kb < Uown;
+        if (tid == 0) { f_nb = 0; f_nr = 0; }
+        if (tid < 64) fhist[tid] = 0u;
+        if (tid < NB) { fbest[tid] = 0ull; fsecond[tid] = 0ull; }
+        if (slot) {
+            const int l = (int)ulist[ownu[kb]] >> lgG;
+            const float x1 = ox[l], y1 = oy[l], z1 = oz[l];
+            const unsigned m = mem[l];
+            const float v1 = emd_value(t4[m & 0xffffu], x1, y1, z1), v2 = emd_value(t4[m >> 16], x1, y1, z1);
+            float R = (3.0f - fminf(v1, v2)) + slack;
+            if (!(R < 1e30f)) R = __builtin_inff();
+            const int cy0 = emd_cell3(y1 - R, grid.mn[1], grid.sc[1]), cy1 = emd_cell3(y1 + R, grid.mn[1], grid.sc[1]);
+            const int cz0 = emd_cell3(z1 - R, grid.mn[2], grid.sc[2]), cz1 = emd_cell3(z1 + R, grid.mn[2], grid.sc[2]);
+            const int ny = cy1 - cy0 + 1;
+            nrows = ny * (cz1 - cz0 + 1);
+            fxyzr[tid] = make_float4(x1, y1, z1, R);
+            fbox[tid] = (unsigned short)(cy0 | (cz0 << 3) | ((ny - 1) << 6));
+        }
+        const int incl = emd_wave_scan_incl(nrows);
+        if (lane == 63) wtot[wave] = (unsigned)incl;
+        __syncthreads();
+        if (tid < NB) {
+            int before = 0;
+            for (int w = 0; w < wave; ++w) before += (int)wtot[w];
+            const int end = before + incl;
+            frow[tid] = (unsigned short)min(end - nrows, 0xffff);      // lanes past the last bidder: the total (the end of the last slot)
+            if (tid == NB - 1) frow[NB] = (unsigned short)min(end, 0xffff);
+            const bool fits = slot && end <= EMD_FLAT_ROWS;      // a prefix of the slots: the batch
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(fits);
+            if (bal && lane == 63 - __builtin_clzll(bal)) { atomicAdd(&f_nb, __builtin_popcountll(bal)); atomicMax(&f_nr, end); }
+        }
+        __syncthreads();
+        const int nb = f_nb, NR = f_nr;
+#ifdef EMD_TRACE
+        if (ftrace) { ftrace[0] = (unsigned)__builtin_amdgcn_s_memrealtime(); ftrace[3] = (k0 == 0 ? 0u : ftrace[3]) + 0x1000000u; }
+#endif
+        // -- B: the rows' chords, EMD_THREADS lanes over NR rows in runs of `rpl` consecutive ones (one search for the
+        //       slot per lane, then steps); histogram of the counts
+        unsigned ent[EMD_FLAT_RPL];
+#ifdef EMD_TRACE
+        int tr_nc = 0;
+#endif
+        {
+            const int rpl = (NR + EMD_THREADS - 1) / EMD_THREADS;
+            int f = tid * rpl, lo = 0, ry = 0, rz = 0, ny = 1, cy0 = 0, cz0 = 0, nxt = 0;
+            float4 bd = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (f < NR) {
+                int hi = nb;
+                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int)frow[mid] <= f) lo = mid; else hi = mid; }
+                const int r = f - (int)frow[lo], box = fbox[lo];
+                ny = ((box >> 6) & 7) + 1; cy0 = box & 7; cz0 = (box >> 3) & 7;
+                rz = (int)(((float)r + 0.5f) * __builtin_amdgcn_rcpf((float)ny)); ry = r - rz * ny;   // r + 0.5 is >= 1/16 from a multiple of ny
+                nxt = frow[lo + 1];
+                bd = fxyzr[lo];
+            }
+#pragma unroll
+            for (int j = 0; j < EMD_FLAT_RPL; ++j, ++f) {
+                ent[j] = 0u;
+                if (j >= rpl || f >= NR) continue;
+                if (f == nxt) {                                  // the next slot's first row (every slot has rows)
+                    ++lo;
+                    const int box = fbox[lo];
+                    ny = ((box >> 6) & 7) + 1; cy0 = box & 7; cz0 = (box >> 3) & 7; ry = 0; rz = 0;
+                    nxt = frow[lo + 1];
+                    bd = fxyzr[lo];
+                }
+                int kst, cnt;
+                emd_row_chord(bd.x, bd.y, bd.z, bd.w * bd.w, cy0 + ry, cz0 + rz, grid, cell_start, kst, cnt);
+                if (++ry == ny) { ry = 0; ++rz; }
+                if (cnt > 0) {
+                    ent[j] = (unsigned)kst | ((unsigned)cnt << 11) | ((unsigned)lo << 23);
+                    atomicAdd(&fhist[min(cnt, 63)], 1u);
+#ifdef EMD_TRACE
+                    tr_nc += cnt;
+#endif
+                }
+            }
+        }
+#ifdef EMD_TRACE
+        { const int t = emd_wave_scan_incl(tr_nc); if (lane == 63) atomicAdd(&f_nc, (unsigned)t); }
+#endif
+        __syncthreads();
+        if (wave == 0) {                                 // longest rows first
+            const int h = (int)fhist[63 - lane];
+            const int in = emd_wave_scan_incl(h);
+            fcur[63 - lane] = (unsigned)(in - h);
+            if (lane == 63) f_nz = in;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < EMD_FLAT_RPL; ++j)
+            if (ent[j]) fsorted[atomicAdd(&fcur[min((int)((ent[j] >> 11) & 4095u), 63)], 1u)] = ent[j];
+        __syncthreads();
+        // -- C: the rows, dealt back and forth over the lanes
+        const int NZ = f_nz;
+#ifdef EMD_TRACE
+        if (ftrace) { ftrace[1] = (unsigned)__builtin_amdgcn_s_memrealtime(); ftrace[3] += (unsigned)NR; }
+#endif
+        for (int p = 0; p * EMD_THREADS < NZ; ++p) {
+            const int rank = p * EMD_THREADS + ((p & 1) ? EMD_THREADS - 1 - tid : tid);
+            int k = 0, kend = 0, sl = 0, pend = -1;
+            float x1 = 0.0f, y1 = 0.0f, z1 = 0.0f, R = -1.0f;
+            if (rank < NZ) {
+                const unsigned e = fsorted[rank];
+                k = (int)(e & 2047u); kend = k + (int)((e >> 11) & 4095u); sl = (int)(e >> 23);
+                const float4 bd = fxyzr[sl];
+                x1 = bd.x; y1 = bd.y; z1 = bd.z; R = bd.w;
+            }
+            auto offer = [&](int kk) {
+                const float v = emd_value(t4[kk], x1, y1, z1);
+                const unsigned long long key = ((unsigned long long)emd_ord(v) << 32) |
+                                               ((unsigned long long)(0xffffu - (unsigned)orig[kk]) << 16) | (unsigned)kk;
+                const unsigned long long old = atomicMax(&fbest[sl], key);
+                atomicMax(&fsecond[sl], old < key ? old : key);
+            };
+            unsigned long long has = 0ull;               // lanes with a parked survivor
+            // four targets per trip, their loads in flight together (the lanes of a wave hold rows of one length: the
+            // tail masks cost little; a load past the row's end reads the next cells or, past n, the padding -- it is
+            // masked, a target outside its row's chord must not be offered: its own row offers it)
+            for (; k < kend; k += 4) {
+                const float4* c = t4 + k;
+                const float4 c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
+                const bool p[4] = {emd_may_matter(c0, x1, y1, z1, R), k + 1 < kend && emd_may_matter(c1, x1, y1, z1, R),
+                                   k + 2 < kend && emd_may_matter(c2, x1, y1, z1, R), k + 3 < kend && emd_may_matter(c3, x1, y1, z1, R)};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned long long pm = __builtin_amdgcn_ballot_w64(p[j]);
+                    if (pm & has) {                      // some lane found its second one: the wave evaluates the parked ones
+                        if (pend >= 0) { offer(pend); pend = -1; }
+                        has = 0ull;
+                    }
+                    pend = p[j] ? k + j : pend;
+                    has |= pm;
+                }
+            }
+            if (pend >= 0) offer(pend);
+        }
+        __syncthreads();
+#ifdef EMD_TRACE
+        if (ftrace) { ftrace[2] = (unsigned)__builtin_amdgcn_s_memrealtime(); ftrace[3] = (ftrace[3] & 0xff00ffffu) | (min(f_nc >> 10, 255u) << 16); }
+#endif
+        // -- D: the bids
+        if (tid < nb) {
+            const int u = ownu[k0 + tid], l = (int)ulist[u] >> lgG;
+            const unsigned long long kb1 = fbest[tid], kb2 = fsecond[tid];
+            Top2 r{-1e9f, -1e9f, -1, -1};
+            if (kb1) { r.b = emd_unord((unsigned)(kb1 >> 32)); r.i = (int)(kb1 & 0xffffu); }
+            if (kb2) { r.s = emd_unord((unsigned)(kb2 >> 32)); r.j = (int)(kb2 & 0xffffu); }
+            const bool two = r.i >= 0 && r.j >= 0 && r.i != r.j;
+            mem[l] = two ? ((unsigned)r.i | ((unsigned)r.j << 16)) : EMD_MEM_NONE;
+            if (!two) emd3_flat_off = 1;
+            const float v = (r.b - r.s) + eps;                                          // :175-176
+            const unsigned t = (unsigned)min(max(r.i, 0), n - 1);
+            emd_st(bid_w + u, ((unsigned long long)((tag << 16) | t) << 32) | (unsigned)__float_as_int(v));
+        }
+        k0 += nb;
+        if (k0 < Uown) __syncthreads();                  // the next batch reuses the lists
+    }
+}
+
+// The team form of the Bid phase
+__device__ __forceinline__ void emd_team_bid(int npad, int lgG, int Uown, int n, float eps, float slack, float r0,
+                                                       unsigned tag, unsigned long long* bid_w, int tnum, int tmax) {
+    const int nown = npad >> lgG;
+    float4* t4 = reinterpret_cast<float4*>(emd3_dyn);
+    unsigned long long* top_l = reinterpret_cast<unsigned long long*>(t4 + npad);
+    float* ox = reinterpret_cast<float*>(top_l + npad); float* oy = ox + nown; float* oz = oy + nown;
+    unsigned* mem = reinterpret_cast<unsigned*>(oz + nown);
+    unsigned short* orig = reinterpret_cast<unsigned short*>(mem + nown);
+    unsigned short* ulist = orig + 3 * (size_t)npad;             // behind assign_l and inv_l
+    unsigned short* ownu = ulist + npad;
+    const int tid = threadIdx.x;
+#ifdef EMD_TRACE
+    const EmdTables3 Tb{t4, orig, emd3_cell_start, &emd3_grid, &emd3_tr_evals, &emd3_tr_rows};
+#else
+    const EmdTables3 Tb{t4, orig, emd3_cell_start, &emd3_grid};
+#endif
+    int T = 1, lgT = 0;
+    while (T < tmax && 2 * T * Uown <= tnum) { T *= 2; ++lgT; }
+    const int per_pass = EMD_THREADS >> lgT, tl = tid & (T - 1);
+    for (int k0 = 0; k0 < Uown; k0 += per_pass) {
+        const int kb = k0 + (tid >> lgT);
+        const bool have = kb < Uown;
+        int u = 0, l = 0;
+        float x1 = 0.0f, y1 = 0.0f, z1 = 0.0f, R = -1.0f;
+        unsigned m = EMD_MEM_NONE;
+        if (have) {
+            u = ownu[kb]; l = (int)ulist[u] >> lgG;
+            x1 = ox[l]; y1 = oy[l]; z1 = oz[l]; m = mem[l];
+        }
+        Top2 r{-1e9f, -1e9f, -1, -1};                        // :116
+        if (have && m != EMD_MEM_NONE) {
+            // any two distinct targets bound the second-best value from below: the best two of the last bid, repriced
+            const float v1 = emd_value(t4[m & 0xffffu], x1, y1, z1), v2 = emd_value(t4[m >> 16], x1, y1, z1);
+            R = (3.0f - fminf(v1, v2)) + slack;
+            if (!(R < 1e30f)) R = __builtin_inff();
+            // PRICE FILTER.  A target can enter the best two only if its value reaches the bound the radius came from,
+            // 3 - d - price >= 3 - R: d <= R - price.  In a crowded auction that holds for ~4 of the ~200-400 targets a
+            // late bid walks (profiles/r04_emd_price_sim.txt), so the walk tests d^2 <= (R - price)^2 -- ten plain
+            // instructions, no square root; R carries `slack`, which covers the rounding of this test against the exact
+            // value many times over -- and only the survivors get the exact value and the top-two update: a lane parks
+            // its survivor and the wave evaluates the parked ones together when any lane finds a second one.  (The
+            // best two over the survivors ARE the best two: both remembered targets survive, everything left out is
+            // below both.)
+            int pend = -1;
+            emd_walk(x1, y1, z1, R, tl, T, Tb, [&](int k) {
+                const bool pass = emd_may_matter(t4[k], x1, y1, z1, R);
+                if (__builtin_amdgcn_ballot_w64(pass && pend >= 0)) {
+                    if (pend >= 0) { top2_put(r, pend, emd_value(t4[pend], x1, y1, z1)); pend = -1; }
+                }
+                pend = pass ? k : pend;
+            });
+            if (pend >= 0) top2_put(r, pend, emd_value(t4[pend], x1, y1, z1));
+        }
+        top2_team(r, T);
+        // first bid of a point (no memory yet): grow a ball until it holds the two best
+        float Rt = (have && m == EMD_MEM_NONE) ? r0 : -1.0f;
+        while (__builtin_amdgcn_ballot_w64(Rt > 0.0f)) {
+            Top2 w{-1e9f, -1e9f, -1, -1};
+            if (Rt > 0.0f) emd_walk(x1, y1, z1, Rt, tl, T, Tb, [&](int k) { top2_put(w, k, emd_value(t4[k], x1, y1, z1)); });
+            top2_team(w, T);                                 // teams that are done fold empty results: theirs stays as it is
+            if (Rt > 0.0f) {
+                r = w;
+                // every target outside the ball of radius 3 - second is strictly below the runner-up found so far
+                const float need = (r.j >= 0 && r.s > -1e8f) ? (3.0f - r.s) + slack : __builtin_inff();
+                if (need <= Rt || !(Rt < 1e30f)) Rt = -1.0f;                  // the ball already held them (or was everything)
+                else Rt = (need < 1e30f) ? need : ((Rt < 64.0f * r0) ? Rt * 2.0f : __builtin_inff());
+            }
+        }
+        // equal values at the top (lattices, duplicated targets): the lowest ORIGINAL index wins (:144-151 scans in
+        // index order) -- the walk's order is not the index order, so the holders of the maximum are collected again
+        const bool tie = have && r.i >= 0 && r.s == r.b;
+        if (__builtin_amdgcn_ballot_w64(tie)) {
+            int key = 0x7fffffff;
+            if (tie) {
+                const float Rw = (3.0f - r.b) + slack;
+                emd_walk(x1, y1, z1, (Rw < 1e30f) ? Rw : __builtin_inff(), tl, T, Tb, [&](int k) {
+                    if (emd_value(t4[k], x1, y1, z1) == r.b) key = min(key, ((int)orig[k] << 12) | k);
+                });
+            }
+            key = emd_team_min(key, T);
+            if (tie && key != 0x7fffffff) {
+                const int ki = key & 0xfff;
+                if (ki != r.i) { r.j = r.i; r.i = ki; }      // the displaced one holds the same value: still a valid memory
+            }
+        }
+        if (have && tl == 0) {
+            const bool two = r.i >= 0 && r.j >= 0 && r.i != r.j;
+            mem[l] = two ? ((unsigned)r.i | ((unsigned)r.j << 16)) : EMD_MEM_NONE;
+            if (!two) emd3_flat_off = 1;
+            const float v = (r.b - r.s) + eps;                                          // :175-176
+            const unsigned t = (unsigned)min(max(r.i, 0), n - 1);
+            emd_st(bid_w + u, ((unsigned long long)((tag << 16) | t) << 32) | (unsigned)__float_as_int(v));
+        }
+    }
+
+}
+
 // -DEMD_TRACE (tools/emd_timeline.py): per workgroup and round, 100-MHz timestamps of the round's phases and the work
 // counters, written behind the bid granules in the sample's workspace (8 words per (workgroup, round), 64 rounds)
 #ifdef EMD_TRACE
@@ -856,11 +1200,11 @@ __device__ inline void emd_walk(float x1, float y1, float z1, float R, int tl, i
 #define EMD_TR(slot) do {} while (0)
 #endif
 
-__global__ __launch_bounds__(EMD_THREADS, 8) void emd_auction_team_kernel(const float* __restrict__ xyz1,
+__global__ __launch_bounds__(EMD_THREADS, 4) void emd_auction_team_kernel(const float* __restrict__ xyz1,
                                                                           const float* __restrict__ xyz2, int B, int n,
                                                                           int npad, int G, int lgG, float eps, int iters,
                                                                           float* __restrict__ dist, int32_t* assignment,
-                                                                          float* wsf, unsigned* counters, int tnum, int tmax) {
+                                                                          float* wsf, unsigned* counters, int tnum, int tmax, int flat_min, int flat_lds) {
     extern __shared__ __attribute__((aligned(16))) float emd_lds[];
     const int nown = npad >> lgG;                                // points this workgroup bids for (local index i >> lgG)
     float4* t4 = reinterpret_cast<float4*>(emd_lds);                                               // SORTED by cell, then index
@@ -872,12 +1216,12 @@ __global__ __launch_bounds__(EMD_THREADS, 8) void emd_auction_team_kernel(const 
     short* inv_l = assign_l + npad;                                                                // sorted position -> point | -1
     unsigned short* ulist = reinterpret_cast<unsigned short*>(inv_l + npad);                       // unassigned points, ascending
     unsigned short* ownu = ulist + npad;                                                           // list positions of the own ones
-    __shared__ unsigned short cell_start[ENC3 + 8];
+    unsigned short* const cell_start = emd3_cell_start;
     __shared__ float red[EMD_WAVES][6];
-    __shared__ EmdGrid3 grid;
-    __shared__ unsigned wtot[EMD_WAVES];
+    EmdGrid3& grid = emd3_grid;
+    unsigned* const wtot = emd3_wtot;
     __shared__ int gave_up;
-    if (threadIdx.x == 0) gave_up = 0;
+    if (threadIdx.x == 0) { gave_up = 0; emd3_flat_off = 0; }
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
     const int b = (q / G) * 8 + xcd, g = q % G;
     if (b >= B) return;
@@ -890,7 +1234,7 @@ __global__ __launch_bounds__(EMD_THREADS, 8) void emd_auction_team_kernel(const 
     unsigned passed = 0;
 #ifdef EMD_TRACE
     unsigned* trace = reinterpret_cast<unsigned*>(wsf + (size_t)b * EMD_WS_PLANES * n + 4 * (size_t)n);
-    __shared__ unsigned tr_evals, tr_rows;
+    unsigned& tr_evals = emd3_tr_evals; unsigned& tr_rows = emd3_tr_rows;
     { const int it = 0; if (tid == 0) trace[(g * 64 + 63) * 8 + 7] = (unsigned)__builtin_amdgcn_s_memrealtime(); (void)it; }
 #endif
     int* cursor = reinterpret_cast<int*>(top_l);                 // init only: per-cell counters (4096 ints = top_l's 16 KB at n = 2048)
@@ -980,11 +1324,6 @@ __global__ __launch_bounds__(EMD_THREADS, 8) void emd_auction_team_kernel(const 
     }
     for (int j = g * EMD_THREADS + tid; j < 2 * n; j += G * EMD_THREADS) emd_st(bids + j, 0ull);
     bool ok = emd_group_sync(counter, passed, G, &gave_up);       // the launch's only counter barrier: granule tags start at 0
-#ifdef EMD_TRACE
-    const EmdTables3 Tb{t4, orig, cell_start, &grid, &tr_evals, &tr_rows};
-#else
-    const EmdTables3 Tb{t4, orig, cell_start, &grid};
-#endif
     // first bid of a point (no memory yet): radius that holds ~6 targets of a cloud that fills its box; doubled until two are found
     const float r_first = 1.5f * cbrtf(fmaxf(grid.cw[0] * (float)egx, 1e-30f) * fmaxf(grid.cw[1] * EG3, 1e-30f) * fmaxf(grid.cw[2] * EG3, 1e-30f)
                                        * (6.0f / (4.0f * 3.14159265f)) / (float)n);
@@ -1044,66 +1383,15 @@ __global__ __launch_bounds__(EMD_THREADS, 8) void emd_auction_team_kernel(const 
         // ---- Bid (:95-179), pruned: teams of T lanes, one own bidder each
         // T lanes per bidder: the own bidders spread over ~tnum lanes, not over all 1024 -- a team's lanes repeat the row
         // set-up, and the rounds are bound by instruction issue (two workgroups share a CU), not by idle lanes
-        int T = 1, lgT = 0;
-        while (T < tmax && 2 * T * Uown <= tnum) { T *= 2; ++lgT; }
-        const int per_pass = EMD_THREADS >> lgT, tl = tid & (T - 1);
-        for (int k0 = 0; k0 < Uown; k0 += per_pass) {
-            const int kb = k0 + (tid >> lgT);
-            const bool have = kb < Uown;
-            int u = 0, l = 0;
-            float x1 = 0.0f, y1 = 0.0f, z1 = 0.0f, R = -1.0f;
-            unsigned m = EMD_MEM_NONE;
-            if (have) {
-                u = ownu[kb]; l = (int)ulist[u] >> lgG;
-                x1 = ox[l]; y1 = oy[l]; z1 = oz[l]; m = mem[l];
-            }
-            Top2 r{-1e9f, -1e9f, -1, -1};                        // :116
-            if (have && m != EMD_MEM_NONE) {
-                // any two distinct targets bound the second-best value from below: the best two of the last bid, repriced
-                const float v1 = emd_value(t4[m & 0xffffu], x1, y1, z1), v2 = emd_value(t4[m >> 16], x1, y1, z1);
-                R = (3.0f - fminf(v1, v2)) + slack;
-                if (!(R < 1e30f)) R = __builtin_inff();
-                emd_walk(x1, y1, z1, R, tl, T, Tb, [&](int k) { top2_put(r, k, emd_value(t4[k], x1, y1, z1)); });
-            }
-            top2_team(r, T);
-            // first bid of a point (no memory yet): grow a ball until it holds the two best
-            float Rt = (have && m == EMD_MEM_NONE) ? r0 : -1.0f;
-            while (__builtin_amdgcn_ballot_w64(Rt > 0.0f)) {
-                Top2 w{-1e9f, -1e9f, -1, -1};
-                if (Rt > 0.0f) emd_walk(x1, y1, z1, Rt, tl, T, Tb, [&](int k) { top2_put(w, k, emd_value(t4[k], x1, y1, z1)); });
-                top2_team(w, T);                                 // teams that are done fold empty results: theirs stays as it is
-                if (Rt > 0.0f) {
-                    r = w;
-                    // every target outside the ball of radius 3 - second is strictly below the runner-up found so far
-                    const float need = (r.j >= 0 && r.s > -1e8f) ? (3.0f - r.s) + slack : __builtin_inff();
-                    if (need <= Rt || !(Rt < 1e30f)) Rt = -1.0f;                  // the ball already held them (or was everything)
-                    else Rt = (need < 1e30f) ? need : ((Rt < 64.0f * r0) ? Rt * 2.0f : __builtin_inff());
-                }
-            }
-            // equal values at the top (lattices, duplicated targets): the lowest ORIGINAL index wins (:144-151 scans in
-            // index order) -- the walk's order is not the index order, so the holders of the maximum are collected again
-            const bool tie = have && r.i >= 0 && r.s == r.b;
-            if (__builtin_amdgcn_ballot_w64(tie)) {
-                int key = 0x7fffffff;
-                if (tie) {
-                    const float Rw = (3.0f - r.b) + slack;
-                    emd_walk(x1, y1, z1, (Rw < 1e30f) ? Rw : __builtin_inff(), tl, T, Tb, [&](int k) {
-                        if (emd_value(t4[k], x1, y1, z1) == r.b) key = min(key, ((int)orig[k] << 12) | k);
-                    });
-                }
-                key = emd_team_min(key, T);
-                if (tie && key != 0x7fffffff) {
-                    const int ki = key & 0xfff;
-                    if (ki != r.i) { r.j = r.i; r.i = ki; }      // the displaced one holds the same value: still a valid memory
-                }
-            }
-            if (have && tl == 0) {
-                mem[l] = (r.i >= 0 && r.j >= 0 && r.i != r.j) ? ((unsigned)r.i | ((unsigned)r.j << 16)) : EMD_MEM_NONE;
-                const float v = (r.b - r.s) + eps;                                          // :175-176
-                const unsigned t = (unsigned)min(max(r.i, 0), n - 1);
-                emd_st(bid_w + u, ((unsigned long long)((tag << 16) | t) << 32) | (unsigned)__float_as_int(v));
-            }
-        }
+        // rounds with many bidders: the balanced form (emd_flat_bid above)
+#ifdef EMD_TRACE
+        unsigned* ftrace = (tid == 0 && it < 64) ? reinterpret_cast<unsigned*>(wsf + (size_t)b * EMD_WS_PLANES * n + 8 * (size_t)n) + (g * 64 + it) * 4 : nullptr;
+#else
+        unsigned* ftrace = nullptr;
+#endif
+        const bool flat = flat_min > 0 && it > 0 && Uown >= flat_min && flat_lds && !emd3_flat_off;
+        if (flat) emd_flat_bid(npad, lgG, Uown, n, eps, slack, tag, bid_w, ftrace);
+        if (!flat) emd_team_bid(npad, lgG, Uown, n, eps, slack, r0, tag, bid_w, tnum, tmax);
 
         EMD_TR(2);
 #ifdef EMD_TRACE
@@ -1262,7 +1550,8 @@ extern "C" int vpn_emd_fwd(const float* xyz1, const float* xyz2, int B, int n, f
         // the training call (n = SAMPLE_NUM * VP_NUM = 2048): pruned scan, static ownership, granule exchange
         const int npad = (n + 63) / 64 * 64;
         const void* kern = reinterpret_cast<const void*>(emd_auction_team_kernel);
-        auto lds_of = [&](int G) { return (size_t)npad * 32 + (size_t)(npad / G) * 18; };
+        const int flat_lds = npad >= 1024 ? 1 : 0;               // the balanced form's lists (small clouds never need it)
+        auto lds_of = [&](int G) { return (size_t)npad * 32 + (size_t)(npad / G) * 18 + (flat_lds ? EMD_FLAT_BYTES : 0); };
         static size_t raised = 0;
         if (lds_of(1) > raised) {
             const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(1));
@@ -1288,9 +1577,11 @@ extern "C" int vpn_emd_fwd(const float* xyz1, const float* xyz2, int B, int n, f
         if (const char* e = getenv("VPN_EMD_TNUM")) tnum = atoi(e) > 0 ? atoi(e) : tnum;
         if (const char* e = getenv("VPN_EMD_TMAX")) tmax = atoi(e) > 0 ? atoi(e) : tmax;
         if (tmax > 64) tmax = 64;
+        int flat_min = 64;                                       // own bidders of a round from which the balanced form bids (0: never)
+        if (const char* e = getenv("VPN_EMD_FLAT_MIN")) flat_min = atoi(e);
         if (coop) {
             void* args[] = {(void*)&xyz1, (void*)&xyz2, (void*)&B, (void*)&n, (void*)&npad, (void*)&G, (void*)&lgG, (void*)&eps, (void*)&iters,
-                            (void*)&dist, (void*)&assignment, (void*)&wsf, (void*)&counters, (void*)&tnum, (void*)&tmax};
+                            (void*)&dist, (void*)&assignment, (void*)&wsf, (void*)&counters, (void*)&tnum, (void*)&tmax, (void*)&flat_min, (void*)&flat_lds};
             vpn::prof_begin("emd_auction_team_kernel", s);
             const hipError_t e = hipLaunchCooperativeKernel(kern, dim3(padded * G), dim3(EMD_THREADS), args, lds, s);
             vpn::prof_end(s);
@@ -1300,7 +1591,7 @@ extern "C" int vpn_emd_fwd(const float* xyz1, const float* xyz2, int B, int n, f
             G = 1; lgG = 0;
         }
         VPN_LAUNCH(emd_auction_team_kernel, dim3(padded * G), dim3(EMD_THREADS), (unsigned)lds_of(G), s, xyz1, xyz2, B, n, npad, G, lgG, eps,
-                   iters, dist, assignment, wsf, counters, tnum, tmax);
+                   iters, dist, assignment, wsf, counters, tnum, tmax, flat_min, flat_lds);
         VPN_LAUNCH_CHECK();
         return 0;
     }
