@@ -584,6 +584,9 @@ _PATTERNS = {}
 FUSED_BWD_MAX_GT = 7680       # vpn_sample_chamfer_bwd keeps per-wave match lists of the GT points in LDS (include/vpn_hip.h)
 _SIDE = {}
 # optionally run the raster branch of HotPathLossFunction on a second HIP stream (VPN_CONCURRENT=1)
+# TrainStepLossFunction: the auction on a second stream, beside the scans and the raster (measured at C5: 1.10 -> 0.94 ms per
+# step; VPN_EMD_SIDE=0 puts it back in line)
+EMD_SIDE_STREAM = os.environ.get('VPN_EMD_SIDE', '1') == '1'
 CONCURRENT_BRANCHES = os.environ.get('VPN_CONCURRENT', '0') == '1'   # measured: no gain at C3 (each kernel already fills the GPU)
 
 
@@ -832,6 +835,23 @@ class TrainStepLossFunction(Function):
         _lib.call('vpn_hotpath_sample_fwd', _lib.ptr(params), _lib.ptr(kinds), None, seed_host, seed_dev, int(sample_base), B, K, n,
                   _lib.ptr(points), _lib.ptr(cam), Hr, Wr, float(sigma), _lib.ptr(rec), _lib.ptr(lws), _lib.ptr(gt_view), M,
                   _lib.ptr(cws), cws.numel() * 4, s)
+        # ---- EMD auction on the sampled cloud (train.py:193).  On a second stream when EMD_SIDE_STREAM: it needs only the
+        #      sampler's points, nothing needs it before the final sums, and its workgroups (one per CU, 16 waves) leave
+        #      every CU half of its wave slots and 32 KB of LDS -- the Chamfer scans and the raster run beside it
+        emd_dist = emd_assign = None
+        side = None
+        if w_emd:
+            emd_dist = torch.empty((B, N), **f32)
+            emd_assign = torch.empty((B, N), **i32)
+            ews = torch.empty((max(1, L.vpn_emd_workspace(B, N) // 4),), **f32)
+            es = s
+            if EMD_SIDE_STREAM:
+                main = torch.cuda.current_stream()
+                side = _side_stream(dev)
+                side.wait_stream(main)
+                es = ctypes.c_void_p(side.cuda_stream)
+            _lib.call('vpn_emd_fwd', _lib.ptr(points), _lib.ptr(gt_view), B, N, float(eps), int(iters), _lib.ptr(emd_dist),
+                      _lib.ptr(emd_assign), _lib.ptr(ews), 1 if CONCURRENT_BRANCHES else int(os.environ.get('VPN_EMD_GROUP', '0')), es)
         ntile = ((Wr + 15) // 16) * ((Hr + 15) // 16)
         use_order = render and TILE_ORDER and K <= 64 and ntile <= 16384 and K * 84 + (K + 2) * 4 + ntile <= 24576
         order = None
@@ -853,14 +873,6 @@ class TrainStepLossFunction(Function):
                       _lib.ptr(hot), None, s)
             if advance_seed:
                 raise ValueError('advance_seed rides in the raster launch: it needs the silhouette term (L_SIL != 0)')
-        # ---- EMD auction on the same clouds (train.py:193)
-        emd_dist = emd_assign = None
-        if w_emd:
-            emd_dist = torch.empty((B, N), **f32)
-            emd_assign = torch.empty((B, N), **i32)
-            ews = torch.empty((max(1, L.vpn_emd_workspace(B, N) // 4),), **f32)
-            _lib.call('vpn_emd_fwd', _lib.ptr(points), _lib.ptr(gt_view), B, N, float(eps), int(iters), _lib.ptr(emd_dist),
-                      _lib.ptr(emd_assign), _lib.ptr(ews), 1 if CONCURRENT_BRANCHES else int(os.environ.get('VPN_EMD_GROUP', '0')), s)
         # ---- object-centred Chamfer (train.py:158-161): computed even at weight 0, like the reference
         cn = None
         if gt_canon is not None:
@@ -890,6 +902,8 @@ class TrainStepLossFunction(Function):
             _lib.call('vpn_vpdiv_fwd', _lib.ptr(params), _lib.ptr(gt_view), B, K, M, None, None, _lib.ptr(dv[2]),
                       _lib.ptr(dv[3]), _lib.ptr(dws), s)
         out = torch.empty((6,), **f32)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
         fws = torch.empty((L.vpn_trainstep_workspace(B) // 4,), **f32)
         _lib.call('vpn_trainstep_finalize', _lib.ptr(hot), _lib.ptr(emd_dist), _lib.ptr(cn[3]) if cn else None,
                   _lib.ptr(cn[5]) if cn else None, None, _lib.ptr(dv[2]) if dv else None, B, N, M,
