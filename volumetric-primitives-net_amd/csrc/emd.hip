@@ -1050,24 +1050,27 @@ __device__ __forceinline__ void emd_flat_bid(int npad, int lgG, int Uown, int n,
                 atomicMax(&fsecond[sl], old < key ? old : key);
             };
             unsigned long long has = 0ull;               // lanes with a parked survivor
-            // four targets per trip, their loads in flight together (the lanes of a wave hold rows of one length: the
-            // tail masks cost little; a load past the row's end reads the next cells or, past n, the padding -- it is
-            // masked, a target outside its row's chord must not be offered: its own row offers it)
+            // four targets per trip, their loads in flight together, no branches: the results are lane masks, the tail of
+            // a row (the lanes of a wave hold rows of one length) is a mask too.  A load past the row's end reads the next
+            // cells or, past n, the padding: it is masked -- a target outside its row's chord must not be offered, its
+            // own row offers it
+            auto park = [&](unsigned long long pm, int kk) {
+                if (pm & has) {                          // some lane found its second one: the wave evaluates the parked ones
+                    if (pend >= 0) { offer(pend); pend = -1; }
+                    has = 0ull;
+                }
+                __asm__("v_cndmask_b32 %0, %1, %2, %3" : "=v"(pend) : "v"(pend), "v"(kk), "s"(pm));
+                has |= pm;
+            };
             for (; k < kend; k += 4) {
                 const float4* c = t4 + k;
                 const float4 c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
-                const bool p[4] = {emd_may_matter(c0, x1, y1, z1, R), k + 1 < kend && emd_may_matter(c1, x1, y1, z1, R),
-                                   k + 2 < kend && emd_may_matter(c2, x1, y1, z1, R), k + 3 < kend && emd_may_matter(c3, x1, y1, z1, R)};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const unsigned long long pm = __builtin_amdgcn_ballot_w64(p[j]);
-                    if (pm & has) {                      // some lane found its second one: the wave evaluates the parked ones
-                        if (pend >= 0) { offer(pend); pend = -1; }
-                        has = 0ull;
-                    }
-                    pend = p[j] ? k + j : pend;
-                    has |= pm;
-                }
+                const int left = kend - k;
+                const unsigned long long m0 = __builtin_amdgcn_ballot_w64(emd_may_matter(c0, x1, y1, z1, R));
+                const unsigned long long m1 = __builtin_amdgcn_ballot_w64(emd_may_matter(c1, x1, y1, z1, R)) & __builtin_amdgcn_ballot_w64(left > 1);
+                const unsigned long long m2 = __builtin_amdgcn_ballot_w64(emd_may_matter(c2, x1, y1, z1, R)) & __builtin_amdgcn_ballot_w64(left > 2);
+                const unsigned long long m3 = __builtin_amdgcn_ballot_w64(emd_may_matter(c3, x1, y1, z1, R)) & __builtin_amdgcn_ballot_w64(left > 3);
+                park(m0, k); park(m1, k + 1); park(m2, k + 2); park(m3, k + 3);
             }
             if (pend >= 0) offer(pend);
         }
