@@ -259,3 +259,36 @@ def test_emd_cooperative_launch_is_opt_in_and_agrees(emd):
                 assert torch.equal(assign.cpu(), ra) and torch.equal(dist.cpu(), rd), (coop, a.shape)
     finally:
         os.environ.pop('VPN_EMD_COOP_LAUNCH', None)
+
+
+@pytest.mark.gpu
+def test_emd_balanced_form_agrees(emd):
+    """Round 4: rounds with many bidders bid in the balanced form (emd.hip: the rows of all own bidders counting-sorted by
+    length and dealt over the lanes, the price filter, best / second by LDS atomic maxima of (value, lowest index)); rounds
+    with few in the team form.  VPN_EMD_FLAT_MIN moves the switch: 0 = teams only, 1 = balanced from the second round on,
+    default 64.  Same bits as the oracle whichever form bids, for every group size -- uniform clouds, the crowded auction
+    of the training step (points on small primitives against a cloud that fills the cube: 500+ bidders in every round),
+    lattices (ties everywhere: the index rule lives in the keys), clouds far from the origin, and one workgroup per sample
+    (2048 own bidders: several batches per round)."""
+    import os
+    from vpn_amd.ops import EmdFunction
+    gen = torch.Generator().manual_seed(77)
+    uni = (torch.rand(2, 2048, 3, generator=gen), torch.rand(2, 2048, 3, generator=gen), 0.005, 50)
+    centres = torch.rand(2, 64, 1, 3, generator=gen) * 0.7 + 0.15
+    blobs = (centres + 0.04 * torch.randn(2, 64, 32, 3, generator=gen)).reshape(2, 2048, 3)
+    crowded = (blobs, torch.rand(2, 2048, 3, generator=gen), 0.005, 50)
+    lat1 = torch.randint(0, 6, (1, 1024, 3), generator=gen).float() / 6
+    lat2 = torch.randint(0, 6, (1, 1024, 3), generator=gen).float() / 6
+    lattice = (lat1, lat2, 0.005, 40)
+    far = (blobs[:1] * 50.0 + 1000.0, torch.rand(1, 2048, 3, generator=gen) * 50.0 + 1000.0, 0.05, 30)
+    cases = [uni, crowded, lattice, far]
+    refs = [O.emd_auction(a, b, e, it) for a, b, e, it in cases]
+    try:
+        for flat_min in ('0', '1', '64'):
+            os.environ['VPN_EMD_FLAT_MIN'] = flat_min
+            for (a, b, e, it), (rd, ra) in zip(cases, refs):
+                for G in (None, 1, 4):
+                    dist, assign = EmdFunction.apply(a.to(DEV), b.to(DEV), e, it, G)
+                    assert torch.equal(assign.cpu(), ra) and torch.equal(dist.cpu(), rd), (flat_min, G, a.shape)
+    finally:
+        os.environ.pop('VPN_EMD_FLAT_MIN', None)

@@ -44,6 +44,6 @@ for b in (0, B // 2):
         if f[:, 3].any():
             gs = int((r[:, 2] - r[:, 1]).argmax())
             print(' | %5.1f %5.1f %5.1f %5.1f  %5d %d' % (us(f[gs, 0] - r[gs, 1]), us(f[gs, 1] - f[gs, 0]), us(f[gs, 2] - f[gs, 1]), us(r[gs, 2] - f[gs, 2]),
-                                                         f[gs, 3] & 0xffff, f[gs, 3] >> 24), ' ~%dk targets' % ((f[gs, 3] >> 16) & 0xff))
+                                                         f[gs, 3] & 0xffff, f[gs, 3] >> 24), ' ~%dk targets' % ((f[gs, 3] >> 16) & 0xff), ' C of wave 0: loop %d, last offers %d cycles' % (r[gs, 6], r[gs, 7]))
         else:
             print()

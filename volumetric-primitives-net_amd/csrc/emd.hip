@@ -1062,6 +1062,9 @@ __device__ __forceinline__ void emd_flat_bid(int npad, int lgG, int Uown, int n,
                 __asm__("v_cndmask_b32 %0, %1, %2, %3" : "=v"(pend) : "v"(pend), "v"(kk), "s"(pm));
                 has |= pm;
             };
+#ifdef EMD_TRACE
+            const unsigned long long tc0 = __builtin_readcyclecounter();
+#endif
             for (; k < kend; k += 4) {
                 const float4* c = t4 + k;
                 const float4 c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
@@ -1072,7 +1075,13 @@ __device__ __forceinline__ void emd_flat_bid(int npad, int lgG, int Uown, int n,
                 const unsigned long long m3 = __builtin_amdgcn_ballot_w64(emd_may_matter(c3, x1, y1, z1, R)) & __builtin_amdgcn_ballot_w64(left > 3);
                 park(m0, k); park(m1, k + 1); park(m2, k + 2); park(m3, k + 3);
             }
+#ifdef EMD_TRACE
+            const unsigned long long tc1 = __builtin_readcyclecounter();
+#endif
             if (pend >= 0) offer(pend);
+#ifdef EMD_TRACE
+            if (tid == 0) { emd3_tr_evals += (unsigned)(tc1 - tc0); emd3_tr_rows += (unsigned)(__builtin_readcyclecounter() - tc1); }
+#endif
         }
         __syncthreads();
 #ifdef EMD_TRACE
