@@ -901,6 +901,7 @@ constexpr int EMD_FLAT_SLOTS = 512, EMD_FLAT_ROWS = 8192, EMD_FLAT_RPL = EMD_FLA
 constexpr int EMD_FLAT_BYTES = 32 * EMD_FLAT_SLOTS + 4 * EMD_FLAT_ROWS + 2 * EMD_FLAT_SLOTS + 2 * (EMD_FLAT_SLOTS + 4) + 512;
 static_assert(EMD_FLAT_BYTES % 8 == 0 && EMD_FLAT_SLOTS <= 512 && EMD_FLAT_ROWS <= 65535, "nine slot bits in a row entry; 16-bit row numbers");
 __shared__ int emd3_flat_off;        // a bidder lost its memory (degenerate clouds): its ball has to grow again, the teams do that
+__shared__ float emd3_flat_tpb;      // targets per bid in the rows of the last balanced round
 
 __device__ __forceinline__ void emd_flat_bid(int npad, int lgG, int Uown, int n, float eps, float slack, unsigned tag,
                                              unsigned long long* bid_w, unsigned* ftrace) {
@@ -927,10 +928,8 @@ __device__ __forceinline__ void emd_flat_bid(int npad, int lgG, int Uown, int n,
     unsigned* fhist = reinterpret_cast<unsigned*>(frow + NB + 4);                 // [64] rows per count
     unsigned* fcur = fhist + 64;                                                  // [64]
     __shared__ int f_nb, f_nr, f_nz;
-#ifdef EMD_TRACE
-    __shared__ unsigned f_nc;
+    __shared__ unsigned f_nc;                            // targets in the round's rows: the work the next round's choice of form goes by
     if (tid == 0) f_nc = 0u;
-#endif
     for (int k0 = 0; k0 < Uown;) {
         // -- A: one lane per bidder: radius from its memory, the square of rows around it
         int nrows = 0, kb = k0 + tid;
@@ -973,9 +972,7 @@ __device__ __forceinline__ void emd_flat_bid(int npad, int lgG, int Uown, int n,
         // -- B: the rows' chords, EMD_THREADS lanes over NR rows in runs of `rpl` consecutive ones (one search for the
         //       slot per lane, then steps); histogram of the counts
         unsigned ent[EMD_FLAT_RPL];
-#ifdef EMD_TRACE
         int tr_nc = 0;
-#endif
         {
             const int rpl = (NR + EMD_THREADS - 1) / EMD_THREADS;
             int f = tid * rpl, lo = 0, ry = 0, rz = 0, ny = 1, cy0 = 0, cz0 = 0, nxt = 0;
@@ -1006,15 +1003,11 @@ __device__ __forceinline__ void emd_flat_bid(int npad, int lgG, int Uown, int n,
                 if (cnt > 0) {
                     ent[j] = (unsigned)kst | ((unsigned)cnt << 11) | ((unsigned)lo << 23);
                     atomicAdd(&fhist[min(cnt, 63)], 1u);
-#ifdef EMD_TRACE
                     tr_nc += cnt;
-#endif
                 }
             }
         }
-#ifdef EMD_TRACE
-        { const int t = emd_wave_scan_incl(tr_nc); if (lane == 63) atomicAdd(&f_nc, (unsigned)t); }
-#endif
+        { const int t = emd_wave_scan_incl(tr_nc); if (lane == 63 && t) atomicAdd(&f_nc, (unsigned)t); }
         __syncthreads();
         if (wave == 0) {                                 // longest rows first
             const int h = (int)fhist[63 - lane];
@@ -1104,6 +1097,7 @@ __device__ __forceinline__ void emd_flat_bid(int npad, int lgG, int Uown, int n,
         k0 += nb;
         if (k0 < Uown) __syncthreads();                  // the next batch reuses the lists
     }
+    if (tid == 0) emd3_flat_tpb = (float)f_nc / (float)Uown;     // (every batch's B phase, hence its f_nc, lies before a barrier)
 }
 
 // The team form of the Bid phase
@@ -1216,7 +1210,7 @@ __global__ __launch_bounds__(EMD_THREADS, 4) void emd_auction_team_kernel(const 
                                                                           const float* __restrict__ xyz2, int B, int n,
                                                                           int npad, int G, int lgG, float eps, int iters,
                                                                           float* __restrict__ dist, int32_t* assignment,
-                                                                          float* wsf, unsigned* counters, int tnum, int tmax, int flat_min, int flat_lds) {
+                                                                          float* wsf, unsigned* counters, int tnum, int tmax, int flat_min, int flat_lds, int flat_work) {
     extern __shared__ __attribute__((aligned(16))) float emd_lds[];
     const int nown = npad >> lgG;                                // points this workgroup bids for (local index i >> lgG)
     float4* t4 = reinterpret_cast<float4*>(emd_lds);                                               // SORTED by cell, then index
@@ -1233,7 +1227,7 @@ __global__ __launch_bounds__(EMD_THREADS, 4) void emd_auction_team_kernel(const 
     EmdGrid3& grid = emd3_grid;
     unsigned* const wtot = emd3_wtot;
     __shared__ int gave_up;
-    if (threadIdx.x == 0) { gave_up = 0; emd3_flat_off = 0; }
+    if (threadIdx.x == 0) { gave_up = 0; emd3_flat_off = 0; emd3_flat_tpb = 1.0e9f; }
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
     const int b = (q / G) * 8 + xcd, g = q % G;
     if (b >= B) return;
@@ -1343,6 +1337,7 @@ __global__ __launch_bounds__(EMD_THREADS, 4) void emd_auction_team_kernel(const 
     const float r0 = fmaxf(r_first, r_first_floor) > 0.0f ? fmaxf(r_first, r_first_floor) : 1.0f;
     const float slack = 1.0e-5f + 4.0f * grid.mg;
 
+    int team_run = 0;                                    // rounds since the last balanced one
     for (int it = 0; ok && it < iters; ++it) {
         const bool last = it == iters - 1;
         unsigned long long* bid_w = bids + (size_t)(it & 1) * n;
@@ -1401,7 +1396,13 @@ __global__ __launch_bounds__(EMD_THREADS, 4) void emd_auction_team_kernel(const 
 #else
         unsigned* ftrace = nullptr;
 #endif
-        const bool flat = flat_min > 0 && it > 0 && Uown >= flat_min && flat_lds && !emd3_flat_off;
+        // Which form: the balanced one pays ~4 us of lists, sorting and barriers per round and then scans at the mean
+        // instead of the worst lane's load -- it wins when the round's rows hold enough targets: own bidders x targets per
+        // bid of the last balanced round (the second round always is one; a run of team rounds is interrupted every
+        // eighth round to measure again: crowded auctions grow their radii while the bidders dwindle).
+        const bool flat = flat_min > 0 && it > 0 && Uown >= flat_min && flat_lds && !emd3_flat_off &&
+                          ((float)Uown * emd3_flat_tpb >= (float)flat_work || team_run >= 7);
+        team_run = flat ? 0 : team_run + 1;
         if (flat) emd_flat_bid(npad, lgG, Uown, n, eps, slack, tag, bid_w, ftrace);
         if (!flat) emd_team_bid(npad, lgG, Uown, n, eps, slack, r0, tag, bid_w, tnum, tmax);
 
@@ -1589,11 +1590,12 @@ extern "C" int vpn_emd_fwd(const float* xyz1, const float* xyz2, int B, int n, f
         if (const char* e = getenv("VPN_EMD_TNUM")) tnum = atoi(e) > 0 ? atoi(e) : tnum;
         if (const char* e = getenv("VPN_EMD_TMAX")) tmax = atoi(e) > 0 ? atoi(e) : tmax;
         if (tmax > 64) tmax = 64;
-        int flat_min = 64;                                       // own bidders of a round from which the balanced form bids (0: never)
+        int flat_min = 16, flat_work = 4000;                     // the balanced form bids from flat_min own bidders and flat_work targets in a round's rows (flat_min 0: never)
         if (const char* e = getenv("VPN_EMD_FLAT_MIN")) flat_min = atoi(e);
+        if (const char* e = getenv("VPN_EMD_FLAT_WORK")) flat_work = atoi(e);
         if (coop) {
             void* args[] = {(void*)&xyz1, (void*)&xyz2, (void*)&B, (void*)&n, (void*)&npad, (void*)&G, (void*)&lgG, (void*)&eps, (void*)&iters,
-                            (void*)&dist, (void*)&assignment, (void*)&wsf, (void*)&counters, (void*)&tnum, (void*)&tmax, (void*)&flat_min, (void*)&flat_lds};
+                            (void*)&dist, (void*)&assignment, (void*)&wsf, (void*)&counters, (void*)&tnum, (void*)&tmax, (void*)&flat_min, (void*)&flat_lds, (void*)&flat_work};
             vpn::prof_begin("emd_auction_team_kernel", s);
             const hipError_t e = hipLaunchCooperativeKernel(kern, dim3(padded * G), dim3(EMD_THREADS), args, lds, s);
             vpn::prof_end(s);
@@ -1603,7 +1605,7 @@ extern "C" int vpn_emd_fwd(const float* xyz1, const float* xyz2, int B, int n, f
             G = 1; lgG = 0;
         }
         VPN_LAUNCH(emd_auction_team_kernel, dim3(padded * G), dim3(EMD_THREADS), (unsigned)lds_of(G), s, xyz1, xyz2, B, n, npad, G, lgG, eps,
-                   iters, dist, assignment, wsf, counters, tnum, tmax, flat_min, flat_lds);
+                   iters, dist, assignment, wsf, counters, tnum, tmax, flat_min, flat_lds, flat_work);
         VPN_LAUNCH_CHECK();
         return 0;
     }
