@@ -419,7 +419,13 @@ int vpn_trainstep_bwd(const float* params, const int32_t* kinds, uint64_t seed, 
  * wait is bounded (~0.5 s: dist = NaN, assignment = -1 for that sample rather than a hang).  Pass 1 when other streams or
  * processes share the GPU.  VPN_EMD_COOP_LAUNCH=1 in the environment launches cooperatively (the runtime then checks
  * residency itself; the call falls back to 1 if it refuses) -- not the default: a cooperative launch in a process that has
- * captured a HIP graph slows every later dispatch of that process by ~50 us.  Results do not depend on any of this. */
+ * captured a HIP graph slows every later dispatch of that process by ~50 us.  Results do not depend on any of this.
+ * For 128 <= n <= 2048 the auction is one workgroup per CU (1024 threads, <= 128 VGPRs, 131 KB of LDS at n = 2048,
+ * G = 4 at B = 64): kernels of ANOTHER stream that need <= 32 KB of LDS and <= 4 waves per SIMD run beside it, which is
+ * how TrainStepLossFunction uses it -- launch the auction first, so its workgroups are placed while the CUs are empty (a
+ * workgroup that must wait for a slot only makes its partners spin, bounded as above).  Environment, performance only:
+ * VPN_EMD_FLAT_WORK (default 4000: own bidders x targets per bid from which a round bids in the balanced form),
+ * VPN_EMD_FLAT_MIN (default 16; 0 = team form only), VPN_EMD_TNUM / VPN_EMD_TMAX (team size of the team form). */
 size_t vpn_emd_workspace(int B, int n);
 int vpn_emd_fwd(const float* xyz1, const float* xyz2, int B, int n, float eps, int iters,
                 float* dist, int32_t* assignment, void* workspace, int max_group, void* stream);

@@ -695,15 +695,18 @@ __global__ __launch_bounds__(EMD_THREADS) void emd_auction_grid_kernel(const flo
 //     that were best and second best in its last bid -- live in that workgroup's LDS.  Any two distinct targets bound the
 //     second-best value from below (min of their two current values), hence the radius R = 3 - that bound holds every
 //     target that can matter NOW: one scan per bid, with a radius that is exact unless a remembered target was repriced.
-//   * TEAMS: T lanes per bidder, T = the power of two that spreads the round's own bidders over the workgroup's 1024
-//     lanes (T = 64 in a late easy round, 2-4 in the crowded ones: 16-32 bidders per wave instead of one).  A team walks
-//     the (y, z) rows of a 16^3 grid inside the disc of radius R around the bidder and, per row, the cells of the chord:
-//     the scanned set is the sphere at cell resolution, not its bounding box of cells.
+//   * TEAMS: T lanes per bidder, T = the power of two that spreads the round's own bidders over ~1024 lanes (at most
+//     16).  A team walks the (y, z) rows of a 32 x 8 x 8 grid inside the disc of radius R around the bidder and, per row,
+//     the cells of the chord: the scanned set is the sphere at cell resolution, not its bounding box of cells.  Rounds with
+//     much work bid in the BALANCED FORM instead (emd_flat_bid below: the rows of all own bidders in one list sorted by
+//     length, dealt over the lanes; price filter; best two by LDS atomic maxima).
 //   * EXCHANGE BY TAGGED GRANULES (the hand-off form MI355X_MICROARCH.md prices at ~1 us: one naturally aligned 8-byte
 //     {tag | target | increment} written by ONE sc1 store, polled with sc1 loads): every workgroup knows the round's
 //     bidder list, so it knows which entries to wait for; no counter, no barrier, no atomics in memory.  GetMax
 //     (emd_cuda.cu:181-194) is an LDS 64-bit atomic max per target on every workgroup's own copy.
-//   * 16-bit state: 32 n + 18 n / G bytes of LDS + the cell table: two workgroups per CU, G = 8 at B = 64.
+//   * 16-bit state: 32 n + 18 n / G bytes of LDS + the cell table + the balanced form's lists (51.7 KB): ONE workgroup
+//     per CU with up to 128 VGPRs (both forms of the Bid phase inline without scratch), G = 4 at B = 64; the 32 KB of LDS
+//     and the wave slots it leaves are what the training step's other kernels run in beside it.
 // Same arithmetic, same tie rules: bit-equal to the oracle and to the other three kernels for every group size.
 #ifndef EMD_EG
 #define EMD_EG 8
@@ -1138,7 +1141,7 @@ __device__ __forceinline__ void emd_team_bid(int npad, int lgG, int Uown, int n,
             if (!(R < 1e30f)) R = __builtin_inff();
             // PRICE FILTER.  A target can enter the best two only if its value reaches the bound the radius came from,
             // 3 - d - price >= 3 - R: d <= R - price.  In a crowded auction that holds for ~4 of the ~200-400 targets a
-            // late bid walks (profiles/r04_emd_price_sim.txt), so the walk tests d^2 <= (R - price)^2 -- ten plain
+            // late bid walks (profiles/r04b_emd_price_sim.txt), so the walk tests d^2 <= (R - price)^2 -- ten plain
             // instructions, no square root; R carries `slack`, which covers the rounding of this test against the exact
             // value many times over -- and only the survivors get the exact value and the top-two update: a lane parks
             // its survivor and the wave evaluates the parked ones together when any lane finds a second one.  (The
