@@ -1012,6 +1012,9 @@ __device__ __forceinline__ void emd_flat_bid(int npad, int lgG, int Uown, int n,
         }
         { const int t = emd_wave_scan_incl(tr_nc); if (lane == 63 && t) atomicAdd(&f_nc, (unsigned)t); }
         __syncthreads();
+#ifdef EMD_TRACE_B
+        if (ftrace) ftrace[0] = (unsigned)__builtin_amdgcn_s_memrealtime();     // experiment: A column = up to the end of B's chords
+#endif
         if (wave == 0) {                                 // longest rows first
             const int h = (int)fhist[63 - lane];
             const int in = emd_wave_scan_incl(h);
