@@ -969,6 +969,7 @@ __device__ __forceinline__ void emd_flat_bid(int npad, int lgG, int Uown, int n,
         }
         __syncthreads();
         const int nb = f_nb, NR = f_nr;
+        if (nb <= 0) break;                              // cannot happen (a bidder has at most 64 rows); never spin on it: the partners' bounded wait reports the sample
 #ifdef EMD_TRACE
         if (ftrace) { ftrace[0] = (unsigned)__builtin_amdgcn_s_memrealtime(); ftrace[3] = (k0 == 0 ? 0u : ftrace[3]) + 0x1000000u; }
 #endif
