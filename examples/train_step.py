@@ -57,6 +57,17 @@ def training_losses(net, feats, gt_points, gt_sil, dists, elevs, azims, angles, 
     return total, {'view_cd': view_cd, 'obj_cd': obj_cd, 'sil': sil, 'vp_div': div, 'emd': emd}
 
 
+def training_losses_fused(net, feats, gt_points, gt_sil, dists, elevs, azims, angles, kinds, sample_num, weights, seed):
+    """The same loss as ONE autograd node (vpn_amd.TrainStepLossFunction: 9 launches forward with the auction on a second
+    stream, 1 backward).  Needs K * sample_num >= 512 sampled points against as many GT points."""
+    params = vpn_amd.pack_head_outputs(*net(feats))                               # [B,K,10]
+    size = gt_sil.shape[-1]
+    gt_canon = vpn_amd.view_to_obj_points(gt_points, dists, elevs, azims, angles)
+    view_cd, obj_cd, sil, div, emd, total = vpn_amd.TrainStepLossFunction.apply(
+        params, kinds, gt_points, gt_canon, gt_sil, dists, elevs, azims, angles, sample_num, seed, 0, size, size, weights)
+    return total, {'view_cd': view_cd, 'obj_cd': obj_cd, 'sil': sil, 'vp_div': div, 'emd': emd}   # the WEIGHTED terms
+
+
 def make_batch(B, K, sample_num, size, dev, seed=0):
     g = torch.Generator().manual_seed(seed)
     M = K * sample_num
@@ -83,7 +94,9 @@ def main():
     ap.add_argument('--prims', type=int, default=16)         # config.py:34
     ap.add_argument('--sample-num', type=int, default=128)   # config.py:8
     ap.add_argument('--size', type=int, default=128)         # config.py:49
+    ap.add_argument('--fused', action='store_true', help='the whole loss as one autograd node (TrainStepLossFunction)')
     args = ap.parse_args()
+    losses = training_losses_fused if args.fused else training_losses
     dev = torch.device('cuda')
     torch.manual_seed(1234)
     batch = make_batch(args.batch, args.prims, args.sample_num, args.size, dev)
@@ -92,7 +105,7 @@ def main():
     weights = (1.0, 1.0, 1.0, 0.1, 1.0)
     for it in range(args.steps):
         opt.zero_grad()
-        total, parts = training_losses(net, *batch, args.sample_num, weights, seed=1000 + it)
+        total, parts = losses(net, *batch, args.sample_num, weights, seed=1000 + it)
         total.backward()
         opt.step()
         print('step %3d  total %.5f  ' % (it, float(total.detach())) + '  '.join('%s %.5f' % (k, float(v.detach())) for k, v in parts.items()),
