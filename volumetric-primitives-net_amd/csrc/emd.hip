@@ -901,7 +901,7 @@ __shared__ unsigned emd3_tr_evals, emd3_tr_rows;
 // Its lists have LDS of their own behind the auction's state (one workgroup per CU: 160 KB).  A batch is up to
 // EMD_FLAT_SLOTS bidders and EMD_FLAT_ROWS rows: one batch per round at G >= 4.
 constexpr int EMD_FLAT_SLOTS = 512, EMD_FLAT_ROWS = 8192, EMD_FLAT_RPL = EMD_FLAT_ROWS / EMD_THREADS;
-constexpr int EMD_FLAT_BYTES = 32 * EMD_FLAT_SLOTS + 4 * EMD_FLAT_ROWS + 2 * EMD_FLAT_SLOTS + 2 * (EMD_FLAT_SLOTS + 4) + 512;
+constexpr int EMD_FLAT_BYTES = 8 + 32 * EMD_FLAT_SLOTS + 4 * EMD_FLAT_ROWS + 2 * EMD_FLAT_SLOTS + 2 * (EMD_FLAT_SLOTS + 4) + 512;   // 8: alignment of the first list
 static_assert(EMD_FLAT_BYTES % 8 == 0 && EMD_FLAT_SLOTS <= 512 && EMD_FLAT_ROWS <= 65535, "nine slot bits in a row entry; 16-bit row numbers");
 __shared__ int emd3_flat_off;        // a bidder lost its memory (degenerate clouds): its ball has to grow again, the teams do that
 __shared__ float emd3_flat_tpb;      // targets per bid in the rows of the last balanced round
@@ -922,7 +922,8 @@ __device__ __forceinline__ void emd_flat_bid(int npad, int lgG, int Uown, int n,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     static_assert(EG3 <= 8, "three bits per cell coordinate in fbox");
     constexpr int NB = EMD_FLAT_SLOTS;
-    float4* fxyzr = reinterpret_cast<float4*>(ownu + nown);                       // [NB] the slot's bidder and its radius
+    // (18 nown bytes of own-bidder state end on an 8-byte boundary only when nown is not a multiple of 8: float4 wants 16)
+    float4* fxyzr = reinterpret_cast<float4*>(reinterpret_cast<char*>(ownu + nown) + ((nown & 7) ? 8 : 0));   // [NB] the slot's bidder and its radius (nown is a multiple of 4)
     unsigned long long* fbest = reinterpret_cast<unsigned long long*>(fxyzr + NB);// [NB]
     unsigned long long* fsecond = fbest + NB;                                     // [NB]
     unsigned* fsorted = reinterpret_cast<unsigned*>(fsecond + NB);                // [EMD_FLAT_ROWS] rows by count, descending
@@ -990,6 +991,9 @@ __device__ __forceinline__ void emd_flat_bid(int npad, int lgG, int Uown, int n,
                 nxt = frow[lo + 1];
                 bd = fxyzr[lo];
             }
+#ifdef EMD_TRACE_B2
+            if (ftrace) ftrace[0] = (unsigned)__builtin_amdgcn_s_memrealtime();     // experiment: A column = up to the end of wave 0's slot search
+#endif
 #pragma unroll
             for (int j = 0; j < EMD_FLAT_RPL; ++j, ++f) {
                 ent[j] = 0u;
@@ -1011,6 +1015,9 @@ __device__ __forceinline__ void emd_flat_bid(int npad, int lgG, int Uown, int n,
                 }
             }
         }
+#ifdef EMD_TRACE_B2
+        if (ftrace) ftrace[1] = (unsigned)__builtin_amdgcn_s_memrealtime();         // experiment: B column = wave 0's rows (no barrier)
+#endif
         { const int t = emd_wave_scan_incl(tr_nc); if (lane == 63 && t) atomicAdd(&f_nc, (unsigned)t); }
         __syncthreads();
 #ifdef EMD_TRACE_B
@@ -1030,7 +1037,10 @@ __device__ __forceinline__ void emd_flat_bid(int npad, int lgG, int Uown, int n,
         // -- C: the rows, dealt back and forth over the lanes
         const int NZ = f_nz;
 #ifdef EMD_TRACE
-        if (ftrace) { ftrace[1] = (unsigned)__builtin_amdgcn_s_memrealtime(); ftrace[3] += (unsigned)NR; }
+#ifndef EMD_TRACE_B2
+        if (ftrace) ftrace[1] = (unsigned)__builtin_amdgcn_s_memrealtime();
+#endif
+        if (ftrace) ftrace[3] += (unsigned)NR;
 #endif
         for (int p = 0; p * EMD_THREADS < NZ; ++p) {
             const int rank = p * EMD_THREADS + ((p & 1) ? EMD_THREADS - 1 - tid : tid);
