@@ -265,9 +265,10 @@ def test_emd_cooperative_launch_is_opt_in_and_agrees(emd):
 def test_emd_balanced_form_agrees(emd):
     """Round 4: rounds with many bidders bid in the balanced form (emd.hip: the rows of all own bidders counting-sorted by
     length and dealt over the lanes, the price filter, best / second by LDS atomic maxima of (value, lowest index)); rounds
-    with little work in the team form (the switch: own bidders x targets per bid of the last balanced round against
-    VPN_EMD_FLAT_WORK, and at least VPN_EMD_FLAT_MIN own bidders).  FLAT_MIN = 0: teams only; FLAT_MIN = 1 with
-    FLAT_WORK = 0: balanced from the second round on; default 16 / 4000.  Same bits as the oracle whichever form bids, for every group size -- uniform clouds, the crowded auction
+    (one to 64 lanes per row, a wave per row of 63 targets and more); the first bids, degenerate clouds and -- when the
+    switch is moved -- rounds with little work in the team form (VPN_EMD_FLAT_MIN own bidders, VPN_EMD_FLAT_WORK = own
+    bidders x targets per bid of the last balanced round).  FLAT_MIN = 0: teams only; default (1 / 0): balanced from the
+    second round on; 64 / 4000: a mix of both.  Same bits as the oracle whichever form bids, for every group size -- uniform clouds, the crowded auction
     of the training step (points on small primitives against a cloud that fills the cube: 500+ bidders in every round),
     lattices (ties everywhere: the index rule lives in the keys), clouds far from the origin, and one workgroup per sample
     (2048 own bidders: several batches per round)."""
@@ -288,7 +289,7 @@ def test_emd_balanced_form_agrees(emd):
     cases = [uni, crowded, lattice, far, odd]
     refs = [O.emd_auction(a, b, e, it) for a, b, e, it in cases]
     try:
-        for flat_min, flat_work in (('0', None), ('1', '0'), (None, None)):
+        for flat_min, flat_work in (('0', None), ('64', '4000'), (None, None)):
             for key, v in (('VPN_EMD_FLAT_MIN', flat_min), ('VPN_EMD_FLAT_WORK', flat_work)):
                 os.environ.pop(key, None)
                 if v is not None:

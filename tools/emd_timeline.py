@@ -1,5 +1,5 @@
 """Per-round timeline of the auction kernel (library built with VPN_EXTRA_FLAGS=-DEMD_TRACE):
-    python tools/emd_timeline.py [uniform|step]
+    python tools/emd_timeline.py [uniform|step|converged]
 for sample 0: per round the bidders, the team size, rows / targets evaluated, and where the round's time went (list build,
 bids, waiting for the other workgroups' granules, assign), slowest workgroup of the sample."""
 import ctypes, os, sys, torch
@@ -12,6 +12,9 @@ B, n = int(os.environ.get('B', 64)), 2048
 if mode == 'uniform':
     g = torch.Generator().manual_seed(1)
     x1 = torch.rand(B, n, 3, generator=g).to(dev); x2 = torch.rand(B, n, 3, generator=g).to(dev)
+elif mode == 'converged':       # bench.py's c5.fused_partly_converged: GT on a target's surfaces, predictions = the target perturbed by 10 %
+    params, kinds, x2 = bench.c5_inputs(vpn_amd, B, 64, 32, 64, dev, 'surface')[:3]
+    x1 = vpn_amd.Sampling.sample_primitives(params, kinds, 32, seed=1234)
 else:
     params, x2 = bench.synth_inputs(B, 64, n, 1234, dev)
     x1 = vpn_amd.Sampling.sample_primitives(params, vpn_amd.kinds_tensor([0] * 64, dev), 32, seed=1234)

@@ -1042,16 +1042,13 @@ __device__ __forceinline__ void emd_flat_bid(int npad, int lgG, int Uown, int n,
 #endif
         if (ftrace) ftrace[3] += (unsigned)NR;
 #endif
-        for (int p = 0; p * EMD_THREADS < NZ; ++p) {
-            const int rank = p * EMD_THREADS + ((p & 1) ? EMD_THREADS - 1 - tid : tid);
-            int k = 0, kend = 0, sl = 0, pend = -1;
-            float x1 = 0.0f, y1 = 0.0f, z1 = 0.0f, R = -1.0f;
-            if (rank < NZ) {
-                const unsigned e = fsorted[rank];
-                k = (int)(e & 2047u); kend = k + (int)((e >> 11) & 4095u); sl = (int)(e >> 23);
-                const float4 bd = fxyzr[sl];
-                x1 = bd.x; y1 = bd.y; z1 = bd.z; R = bd.w;
-            }
+        // one row (or a lane's share of one): positions k, k + ST, ... below kend of the bidder in slot sl.  Four targets per
+        // trip, their loads in flight together, no branches: the results are lane masks, the tail of a row is a mask too.  A
+        // load past the row's end reads the next cells or, past n, whatever follows the targets in LDS: it is masked -- a
+        // target outside its row's chord must not be offered, its own row offers it.
+        auto scan = [&](const int ST, int k, int kend, int sl, float x1, float y1, float z1, float R) __attribute__((always_inline)) {
+            int pend = -1;
+            unsigned long long has = 0ull;               // lanes with a parked survivor
             auto offer = [&](int kk) {
                 const float v = emd_value(t4[kk], x1, y1, z1);
                 const unsigned long long key = ((unsigned long long)emd_ord(v) << 32) |
@@ -1059,11 +1056,6 @@ __device__ __forceinline__ void emd_flat_bid(int npad, int lgG, int Uown, int n,
                 const unsigned long long old = atomicMax(&fbest[sl], key);
                 atomicMax(&fsecond[sl], old < key ? old : key);
             };
-            unsigned long long has = 0ull;               // lanes with a parked survivor
-            // four targets per trip, their loads in flight together, no branches: the results are lane masks, the tail of
-            // a row (the lanes of a wave hold rows of one length) is a mask too.  A load past the row's end reads the next
-            // cells or, past n, the padding: it is masked -- a target outside its row's chord must not be offered, its
-            // own row offers it
             auto park = [&](unsigned long long pm, int kk) {
                 if (pm & has) {                          // some lane found its second one: the wave evaluates the parked ones
                     if (pend >= 0) { offer(pend); pend = -1; }
@@ -1072,27 +1064,63 @@ __device__ __forceinline__ void emd_flat_bid(int npad, int lgG, int Uown, int n,
                 __asm__("v_cndmask_b32 %0, %1, %2, %3" : "=v"(pend) : "v"(pend), "v"(kk), "s"(pm));
                 has |= pm;
             };
-#ifdef EMD_TRACE
-            const unsigned long long tc0 = __builtin_readcyclecounter();
-#endif
-            for (; k < kend; k += 4) {
+            for (; k < kend; k += 4 * ST) {
                 const float4* c = t4 + k;
-                const float4 c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
+                const float4 c0 = c[0], c1 = c[ST], c2 = c[2 * ST], c3 = c[3 * ST];
                 const int left = kend - k;
                 const unsigned long long m0 = __builtin_amdgcn_ballot_w64(emd_may_matter(c0, x1, y1, z1, R));
-                const unsigned long long m1 = __builtin_amdgcn_ballot_w64(emd_may_matter(c1, x1, y1, z1, R)) & __builtin_amdgcn_ballot_w64(left > 1);
-                const unsigned long long m2 = __builtin_amdgcn_ballot_w64(emd_may_matter(c2, x1, y1, z1, R)) & __builtin_amdgcn_ballot_w64(left > 2);
-                const unsigned long long m3 = __builtin_amdgcn_ballot_w64(emd_may_matter(c3, x1, y1, z1, R)) & __builtin_amdgcn_ballot_w64(left > 3);
-                park(m0, k); park(m1, k + 1); park(m2, k + 2); park(m3, k + 3);
+                const unsigned long long m1 = __builtin_amdgcn_ballot_w64(emd_may_matter(c1, x1, y1, z1, R)) & __builtin_amdgcn_ballot_w64(left > ST);
+                const unsigned long long m2 = __builtin_amdgcn_ballot_w64(emd_may_matter(c2, x1, y1, z1, R)) & __builtin_amdgcn_ballot_w64(left > 2 * ST);
+                const unsigned long long m3 = __builtin_amdgcn_ballot_w64(emd_may_matter(c3, x1, y1, z1, R)) & __builtin_amdgcn_ballot_w64(left > 3 * ST);
+                park(m0, k); park(m1, k + ST); park(m2, k + 2 * ST); park(m3, k + 3 * ST);
             }
-#ifdef EMD_TRACE
-            const unsigned long long tc1 = __builtin_readcyclecounter();
-#endif
             if (pend >= 0) offer(pend);
-#ifdef EMD_TRACE
-            if (tid == 0) { emd3_tr_evals += (unsigned)(tc1 - tc0); emd3_tr_rows += (unsigned)(__builtin_readcyclecounter() - tc1); }
-#endif
+        };
+        // rows of 63 targets and more (the last bin: the head of the list) are not a lane's job -- a cloud that sits on
+        // surfaces puts hundreds of targets into one row of cells: a WAVE takes each, its lanes striding through it
+        const int NL = (int)fhist[63];
+        for (int r = wave; r < NL; r += EMD_WAVES) {
+            const unsigned e = fsorted[r];
+            const int kst = (int)(e & 2047u), sl = (int)(e >> 23);
+            const float4 bd = fxyzr[sl];
+            scan(64, kst + lane, kst + (int)((e >> 11) & 4095u), sl, bd.x, bd.y, bd.z, bd.w);
         }
+        // the other rows: one lane each, dealt back and forth over the lanes -- or, when the round has fewer rows than lanes
+        // (a late round, a cloud on surfaces: there the round is as long as its longest row), 2, 4, ... 64 lanes each
+        int lgS = 0;
+        while (lgS < 6 && ((NZ - NL) << (lgS + 1)) <= EMD_THREADS) ++lgS;
+#ifdef EMD_TRACE
+        const unsigned long long tc0 = __builtin_readcyclecounter();
+#endif
+        if (lgS == 0) {
+            for (int p = 0; NL + p * EMD_THREADS < NZ; ++p) {
+                const int rank = NL + p * EMD_THREADS + ((p & 1) ? EMD_THREADS - 1 - tid : tid);
+                int k = 0, kend = 0, sl = 0;
+                float x1 = 0.0f, y1 = 0.0f, z1 = 0.0f, R = -1.0f;
+                if (rank < NZ) {
+                    const unsigned e = fsorted[rank];
+                    k = (int)(e & 2047u); kend = k + (int)((e >> 11) & 4095u); sl = (int)(e >> 23);
+                    const float4 bd = fxyzr[sl];
+                    x1 = bd.x; y1 = bd.y; z1 = bd.z; R = bd.w;
+                }
+                scan(1, k, kend, sl, x1, y1, z1, R);
+            }
+        } else {
+            const int rank = NL + (tid >> lgS);
+            int k = 0, kend = 0, sl = 0;
+            float x1 = 0.0f, y1 = 0.0f, z1 = 0.0f, R = -1.0f;
+            if (rank < NZ) {
+                const unsigned e = fsorted[rank];
+                k = (int)(e & 2047u); kend = k + (int)((e >> 11) & 4095u); sl = (int)(e >> 23);
+                k += tid & ((1 << lgS) - 1);
+                const float4 bd = fxyzr[sl];
+                x1 = bd.x; y1 = bd.y; z1 = bd.z; R = bd.w;
+            }
+            scan(1 << lgS, k, kend, sl, x1, y1, z1, R);
+        }
+#ifdef EMD_TRACE
+        if (tid == 0) emd3_tr_evals += (unsigned)(__builtin_readcyclecounter() - tc0);
+#endif
         __syncthreads();
 #ifdef EMD_TRACE
         if (ftrace) { ftrace[2] = (unsigned)__builtin_amdgcn_s_memrealtime(); ftrace[3] = (ftrace[3] & 0xff00ffffu) | (min(f_nc >> 10, 255u) << 16); }
@@ -1413,10 +1441,10 @@ __global__ __launch_bounds__(EMD_THREADS, 4) void emd_auction_team_kernel(const 
 #else
         unsigned* ftrace = nullptr;
 #endif
-        // Which form: the balanced one pays ~4 us of lists, sorting and barriers per round and then scans at the mean
-        // instead of the worst lane's load -- it wins when the round's rows hold enough targets: own bidders x targets per
-        // bid of the last balanced round (the second round always is one; a run of team rounds is interrupted every
-        // eighth round to measure again: crowded auctions grow their radii while the bidders dwindle).
+        // Which form: by default the balanced one from the second round on (the first bids have no memory: their ball has
+        // to grow, the teams do that).  The switch that remains for experiments: at least flat_min own bidders, and own
+        // bidders x targets per bid of the last balanced round >= flat_work (a run of team rounds is interrupted every
+        // eighth round to measure again).
         const bool flat = flat_min > 0 && it > 0 && Uown >= flat_min && flat_lds && !emd3_flat_off &&
                           ((float)Uown * emd3_flat_tpb >= (float)flat_work || team_run >= 7);
         team_run = flat ? 0 : team_run + 1;
@@ -1607,7 +1635,9 @@ extern "C" int vpn_emd_fwd(const float* xyz1, const float* xyz2, int B, int n, f
         if (const char* e = getenv("VPN_EMD_TNUM")) tnum = atoi(e) > 0 ? atoi(e) : tnum;
         if (const char* e = getenv("VPN_EMD_TMAX")) tmax = atoi(e) > 0 ? atoi(e) : tmax;
         if (tmax > 64) tmax = 64;
-        int flat_min = 16, flat_work = 4000;                     // the balanced form bids from flat_min own bidders and flat_work targets in a round's rows (flat_min 0: never)
+        // the balanced form bids every round after the first (measured: with 1 to 64 lanes per row it beats the teams in sparse
+        // rounds too); VPN_EMD_FLAT_MIN own bidders / VPN_EMD_FLAT_WORK targets in a round's rows move the switch (0 / -: teams only)
+        int flat_min = 1, flat_work = 0;
         if (const char* e = getenv("VPN_EMD_FLAT_MIN")) flat_min = atoi(e);
         if (const char* e = getenv("VPN_EMD_FLAT_WORK")) flat_work = atoi(e);
         if (coop) {
