@@ -903,11 +903,16 @@ __shared__ unsigned emd3_tr_evals, emd3_tr_rows;
 constexpr int EMD_FLAT_SLOTS = 512, EMD_FLAT_ROWS = 8192, EMD_FLAT_RPL = EMD_FLAT_ROWS / EMD_THREADS;
 constexpr int EMD_FLAT_BYTES = 8 + 32 * EMD_FLAT_SLOTS + 4 * EMD_FLAT_ROWS + 2 * EMD_FLAT_SLOTS + 2 * (EMD_FLAT_SLOTS + 4) + 512;   // 8: alignment of the first list
 static_assert(EMD_FLAT_BYTES % 8 == 0 && EMD_FLAT_SLOTS <= 512 && EMD_FLAT_ROWS <= 65535, "nine slot bits in a row entry; 16-bit row numbers");
+__device__ inline unsigned short* emd3_flat_frow(int npad, int lgG);
 __shared__ int emd3_flat_off;        // a bidder lost its memory (degenerate clouds): its ball has to grow again, the teams do that
 __shared__ float emd3_flat_tpb;      // targets per bid in the rows of the last balanced round
 
-__device__ __forceinline__ void emd_flat_bid(int npad, int lgG, int Uown, int n, float eps, float slack, unsigned tag,
-                                             unsigned long long* bid_w, unsigned* ftrace) {
+// r_first > 0: the FIRST bids of the auction (nobody has a memory yet): every bidder scans the ball of that radius; one
+// that finds two targets in it has found its best two (everything outside is farther than both, and no price is
+// negative), the others -- returned as a list in `frow`, their number as the result -- are left to the teams, whose ball
+// grows.  -1: more bidders or rows than one batch holds, nothing was done.
+__device__ __forceinline__ int emd_flat_bid(int npad, int lgG, int Uown, int n, float eps, float slack, unsigned tag,
+                                            unsigned long long* bid_w, unsigned* ftrace, float r_first) {
     const int nown = npad >> lgG;
     float4* t4 = reinterpret_cast<float4*>(emd3_dyn);
     unsigned long long* top_l = reinterpret_cast<unsigned long long*>(t4 + npad);
@@ -931,8 +936,10 @@ __device__ __forceinline__ void emd_flat_bid(int npad, int lgG, int Uown, int n,
     unsigned short* frow = fbox + NB;                                             // [NB + 4] first row of the slot
     unsigned* fhist = reinterpret_cast<unsigned*>(frow + NB + 4);                 // [64] rows per count
     unsigned* fcur = fhist + 64;                                                  // [64]
-    __shared__ int f_nb, f_nr, f_nz;
-    __shared__ unsigned f_nc;                            // targets in the round's rows: the work the next round's choice of form goes by
+    __shared__ int f_nb, f_nr, f_nz, f_left;
+    __shared__ unsigned f_nc;
+    const bool first = r_first > 0.0f;
+    if (tid == 0) f_left = 0;                            // targets in the round's rows: the work the next round's choice of form goes by
     if (tid == 0) f_nc = 0u;
     for (int k0 = 0; k0 < Uown;) {
         // -- A: one lane per bidder: radius from its memory, the square of rows around it
@@ -944,9 +951,12 @@ __device__ __forceinline__ void emd_flat_bid(int npad, int lgG, int Uown, int n,
         if (slot) {
             const int l = (int)ulist[ownu[kb]] >> lgG;
             const float x1 = ox[l], y1 = oy[l], z1 = oz[l];
-            const unsigned m = mem[l];
-            const float v1 = emd_value(t4[m & 0xffffu], x1, y1, z1), v2 = emd_value(t4[m >> 16], x1, y1, z1);
-            float R = (3.0f - fminf(v1, v2)) + slack;
+            float R = r_first;
+            if (!first) {
+                const unsigned m = mem[l];
+                const float v1 = emd_value(t4[m & 0xffffu], x1, y1, z1), v2 = emd_value(t4[m >> 16], x1, y1, z1);
+                R = (3.0f - fminf(v1, v2)) + slack;
+            }
             if (!(R < 1e30f)) R = __builtin_inff();
             const int cy0 = emd_cell3(y1 - R, grid.mn[1], grid.sc[1]), cy1 = emd_cell3(y1 + R, grid.mn[1], grid.sc[1]);
             const int cz0 = emd_cell3(z1 - R, grid.mn[2], grid.sc[2]), cz1 = emd_cell3(z1 + R, grid.mn[2], grid.sc[2]);
@@ -971,6 +981,7 @@ __device__ __forceinline__ void emd_flat_bid(int npad, int lgG, int Uown, int n,
         __syncthreads();
         const int nb = f_nb, NR = f_nr;
         if (nb <= 0) break;                              // cannot happen (a bidder has at most 64 rows); never spin on it: the partners' bounded wait reports the sample
+        if (first && nb < Uown) return -1;               // the first round in one batch or not at all (nothing has been bid yet)
 #ifdef EMD_TRACE
         if (ftrace) { ftrace[0] = (unsigned)__builtin_amdgcn_s_memrealtime(); ftrace[3] = (k0 == 0 ? 0u : ftrace[3]) + 0x1000000u; }
 #endif
@@ -1133,21 +1144,38 @@ __device__ __forceinline__ void emd_flat_bid(int npad, int lgG, int Uown, int n,
             if (kb1) { r.b = emd_unord((unsigned)(kb1 >> 32)); r.i = (int)(kb1 & 0xffffu); }
             if (kb2) { r.s = emd_unord((unsigned)(kb2 >> 32)); r.j = (int)(kb2 & 0xffffu); }
             const bool two = r.i >= 0 && r.j >= 0 && r.i != r.j;
-            mem[l] = two ? ((unsigned)r.i | ((unsigned)r.j << 16)) : EMD_MEM_NONE;
-            if (!two) emd3_flat_off = 1;
-            const float v = (r.b - r.s) + eps;                                          // :175-176
-            const unsigned t = (unsigned)min(max(r.i, 0), n - 1);
-            emd_st(bid_w + u, ((unsigned long long)((tag << 16) | t) << 32) | (unsigned)__float_as_int(v));
+            if (first && !two) {
+                frow[atomicAdd(&f_left, 1)] = (unsigned short)(k0 + tid);               // (frow is done with: the rows are sorted)
+            } else {
+                mem[l] = two ? ((unsigned)r.i | ((unsigned)r.j << 16)) : EMD_MEM_NONE;
+                if (!two) emd3_flat_off = 1;
+                const float v = (r.b - r.s) + eps;                                      // :175-176
+                const unsigned t = (unsigned)min(max(r.i, 0), n - 1);
+                emd_st(bid_w + u, ((unsigned long long)((tag << 16) | t) << 32) | (unsigned)__float_as_int(v));
+            }
         }
         k0 += nb;
         if (k0 < Uown) __syncthreads();                  // the next batch reuses the lists
     }
+    if (first) {
+        __syncthreads();                                 // the list of the bidders left over is complete
+        return f_left;
+    }
     if (tid == 0) emd3_flat_tpb = (float)f_nc / (float)Uown;     // (every batch's B phase, hence its f_nc, lies before a barrier)
+    return 0;
+}
+
+// where emd_flat_bid keeps `frow` (its list of left-over bidders after a first round): the same carving as above
+__device__ inline unsigned short* emd3_flat_frow(int npad, int lgG) {
+    const int nown = npad >> lgG;
+    char* base = reinterpret_cast<char*>(emd3_dyn) + (size_t)npad * 32 + (size_t)nown * 18 + ((nown & 7) ? 8 : 0);   // behind ownu, aligned
+    return reinterpret_cast<unsigned short*>(base + 32 * EMD_FLAT_SLOTS + 4 * EMD_FLAT_ROWS + 2 * EMD_FLAT_SLOTS);
 }
 
 // The team form of the Bid phase
 __device__ __forceinline__ void emd_team_bid(int npad, int lgG, int Uown, int n, float eps, float slack, float r0,
-                                                       unsigned tag, unsigned long long* bid_w, int tnum, int tmax) {
+                                             unsigned tag, unsigned long long* bid_w, int tnum, int tmax,
+                                             const unsigned short* sub = nullptr) {   // sub: Uown positions in ownu (the bidders a first balanced round left over)
     const int nown = npad >> lgG;
     float4* t4 = reinterpret_cast<float4*>(emd3_dyn);
     unsigned long long* top_l = reinterpret_cast<unsigned long long*>(t4 + npad);
@@ -1172,7 +1200,7 @@ __device__ __forceinline__ void emd_team_bid(int npad, int lgG, int Uown, int n,
         float x1 = 0.0f, y1 = 0.0f, z1 = 0.0f, R = -1.0f;
         unsigned m = EMD_MEM_NONE;
         if (have) {
-            u = ownu[kb]; l = (int)ulist[u] >> lgG;
+            u = ownu[sub ? (int)sub[kb] : kb]; l = (int)ulist[u] >> lgG;
             x1 = ox[l]; y1 = oy[l]; z1 = oz[l]; m = mem[l];
         }
         Top2 r{-1e9f, -1e9f, -1, -1};                        // :116
@@ -1448,8 +1476,15 @@ __global__ __launch_bounds__(EMD_THREADS, 4) void emd_auction_team_kernel(const 
         const bool flat = flat_min > 0 && it > 0 && Uown >= flat_min && flat_lds && !emd3_flat_off &&
                           ((float)Uown * emd3_flat_tpb >= (float)flat_work || team_run >= 7);
         team_run = flat ? 0 : team_run + 1;
-        if (flat) emd_flat_bid(npad, lgG, Uown, n, eps, slack, tag, bid_w, ftrace);
-        if (!flat) emd_team_bid(npad, lgG, Uown, n, eps, slack, r0, tag, bid_w, tnum, tmax);
+        if (flat) emd_flat_bid(npad, lgG, Uown, n, eps, slack, tag, bid_w, ftrace, -1.0f);
+        else {
+            // the first bids: the balanced form with the radius the teams would start from, the teams for whoever it leaves
+            int left = -1;
+            if (it == 0 && flat_min > 0 && flat_lds && Uown >= flat_min && Uown <= EMD_FLAT_SLOTS)
+                left = emd_flat_bid(npad, lgG, Uown, n, eps, slack, tag, bid_w, ftrace, r0);
+            if (left < 0) emd_team_bid(npad, lgG, Uown, n, eps, slack, r0, tag, bid_w, tnum, tmax);
+            else if (left > 0) emd_team_bid(npad, lgG, left, n, eps, slack, r0, tag, bid_w, tnum, tmax, emd3_flat_frow(npad, lgG));
+        }
 
         EMD_TR(2);
 #ifdef EMD_TRACE
