@@ -906,7 +906,6 @@ static_assert(EMD_FLAT_BYTES % 8 == 0 && EMD_FLAT_SLOTS <= 512 && EMD_FLAT_ROWS 
 __device__ inline unsigned short* emd3_flat_frow(int npad, int lgG);
 __shared__ int emd3_flat_off;        // a bidder lost its memory (degenerate clouds): its ball has to grow again, the teams do that
 __shared__ float emd3_flat_tpb;      // targets per bid in the rows of the last balanced round
-__shared__ int emd3_flat_rows, emd3_flat_nc;       // its rows, its targets
 
 // r_first > 0: the FIRST bids of the auction (nobody has a memory yet): every bidder scans the ball of that radius; one
 // that finds two targets in it has found its best two (everything outside is farther than both, and no price is
@@ -942,167 +941,112 @@ __device__ __forceinline__ int emd_flat_bid(int npad, int lgG, int Uown, int n, 
     const bool first = r_first > 0.0f;
     if (tid == 0) f_left = 0;                            // targets in the round's rows: the work the next round's choice of form goes by
     if (tid == 0) f_nc = 0u;
-    // few bidders AND, last time, fewer rows than lanes with a few targets each (a crowded auction at G = 16 has 30-100
-    // bidders with 26 rows of 12 targets each: that wants the sorted list; sorting the fused phase's rows from registers
-    // was measured too: the larger kernel costs the crowded rounds more than it gives the others)
-    int last_rows = 0;
-    const bool sparse = !first && Uown <= EMD_FLAT_ROWS / 64 && emd3_flat_rows <= EMD_THREADS && emd3_flat_nc <= 4 * EMD_THREADS;
     for (int k0 = 0; k0 < Uown;) {
-        int nb = 0, NR = 0, NZ = 0, NL = 0;
-        if (sparse) {
-            // -- A + B of a round with few bidders, in one: EIGHT lanes per bidder -- each computes the radius from the
-            //    bidder's memory and takes every eighth row of its square; the rows go to the list in whatever order the
-            //    waves arrive (C gives every row several lanes then: the order does not matter), no prefix sum, no search, no
-            //    sort: one barrier instead of five.  At most EMD_FLAT_ROWS / 64 bidders: their rows fit whatever their radii.
-            if (tid == 0) { f_nz = 0; }
-            if (tid < Uown) { fbest[tid] = 0ull; fsecond[tid] = 0ull; }
-            __syncthreads();
-            const int kb = tid >> 3, tl = tid & 7;
-            int tr_nc = 0;
-            if (kb < Uown) {
-                const int l = (int)ulist[ownu[kb]] >> lgG;
-                const float x1 = ox[l], y1 = oy[l], z1 = oz[l];
+        // -- A: one lane per bidder: radius from its memory, the square of rows around it
+        int nrows = 0, kb = k0 + tid;
+        const bool slot = tid < NB && kb < Uown;
+        if (tid == 0) { f_nb = 0; f_nr = 0; }
+        if (tid < 64) fhist[tid] = 0u;
+        if (tid < NB) { fbest[tid] = 0ull; fsecond[tid] = 0ull; }
+        if (slot) {
+            const int l = (int)ulist[ownu[kb]] >> lgG;
+            const float x1 = ox[l], y1 = oy[l], z1 = oz[l];
+            float R = r_first;
+            if (!first) {
                 const unsigned m = mem[l];
                 const float v1 = emd_value(t4[m & 0xffffu], x1, y1, z1), v2 = emd_value(t4[m >> 16], x1, y1, z1);
-                float R = (3.0f - fminf(v1, v2)) + slack;
-                if (!(R < 1e30f)) R = __builtin_inff();
-                const int cy0 = emd_cell3(y1 - R, grid.mn[1], grid.sc[1]), cy1 = emd_cell3(y1 + R, grid.mn[1], grid.sc[1]);
-                const int cz0 = emd_cell3(z1 - R, grid.mn[2], grid.sc[2]), cz1 = emd_cell3(z1 + R, grid.mn[2], grid.sc[2]);
-                const int ny = cy1 - cy0 + 1, nrows = ny * (cz1 - cz0 + 1);
-                if (tl == 0) fxyzr[kb] = make_float4(x1, y1, z1, R);
-                const float inv_ny = __builtin_amdgcn_rcpf((float)ny), R2 = R * R;
-                for (int r = tl; r < nrows; r += 8) {
-                    const int rz = (int)(((float)r + 0.5f) * inv_ny), ry = r - rz * ny;      // r + 0.5 is >= 1/16 from a multiple of ny
-                    int kst, cnt;
-                    emd_row_chord(x1, y1, z1, R2, cy0 + ry, cz0 + rz, grid, cell_start, kst, cnt);
-                    const unsigned long long on = __builtin_amdgcn_ballot_w64(cnt > 0);
-                    if (on) {                            // one counter add per wave and trip
-                        const int leader = __builtin_ctzll(on);
-                        int base = 0;
-                        if (lane == leader) base = atomicAdd(&f_nz, __builtin_popcountll(on));
-                        base = __builtin_amdgcn_readlane(base, leader);
-                        if (cnt > 0) {
-                            const int pos = base + __builtin_popcountll(on & ((1ull << lane) - 1ull));
-                            fsorted[pos] = (unsigned)kst | ((unsigned)cnt << 11) | ((unsigned)kb << 23);
-                            tr_nc += cnt;
-                        }
-                    }
-                }
+                R = (3.0f - fminf(v1, v2)) + slack;
             }
-            { const int t = emd_wave_scan_incl(tr_nc); if (lane == 63 && t) atomicAdd(&f_nc, (unsigned)t); }
-            __syncthreads();
-            nb = Uown; NR = NZ = f_nz; NL = 0;
+            if (!(R < 1e30f)) R = __builtin_inff();
+            const int cy0 = emd_cell3(y1 - R, grid.mn[1], grid.sc[1]), cy1 = emd_cell3(y1 + R, grid.mn[1], grid.sc[1]);
+            const int cz0 = emd_cell3(z1 - R, grid.mn[2], grid.sc[2]), cz1 = emd_cell3(z1 + R, grid.mn[2], grid.sc[2]);
+            const int ny = cy1 - cy0 + 1;
+            nrows = ny * (cz1 - cz0 + 1);
+            fxyzr[tid] = make_float4(x1, y1, z1, R);
+            fbox[tid] = (unsigned short)(cy0 | (cz0 << 3) | ((ny - 1) << 6));
+        }
+        const int incl = emd_wave_scan_incl(nrows);
+        if (lane == 63) wtot[wave] = (unsigned)incl;
+        __syncthreads();
+        if (tid < NB) {
+            int before = 0;
+            for (int w = 0; w < wave; ++w) before += (int)wtot[w];
+            const int end = before + incl;
+            frow[tid] = (unsigned short)min(end - nrows, 0xffff);      // lanes past the last bidder: the total (the end of the last slot)
+            if (tid == NB - 1) frow[NB] = (unsigned short)min(end, 0xffff);
+            const bool fits = slot && end <= EMD_FLAT_ROWS;      // a prefix of the slots: the batch
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(fits);
+            if (bal && lane == 63 - __builtin_clzll(bal)) { atomicAdd(&f_nb, __builtin_popcountll(bal)); atomicMax(&f_nr, end); }
+        }
+        __syncthreads();
+        const int nb = f_nb, NR = f_nr;
+        if (nb <= 0) break;                              // cannot happen (a bidder has at most 64 rows); never spin on it: the partners' bounded wait reports the sample
+        if (first && nb < Uown) return -1;               // the first round in one batch or not at all (nothing has been bid yet)
 #ifdef EMD_TRACE
-            if (ftrace) { ftrace[0] = ftrace[1] = (unsigned)__builtin_amdgcn_s_memrealtime(); ftrace[3] = 0x1000000u; }
+        if (ftrace) { ftrace[0] = (unsigned)__builtin_amdgcn_s_memrealtime(); ftrace[3] = (k0 == 0 ? 0u : ftrace[3]) + 0x1000000u; }
 #endif
-        } else {
-            // -- A: one lane per bidder: radius from its memory, the square of rows around it
-            int nrows = 0, kb = k0 + tid;
-            const bool slot = tid < NB && kb < Uown;
-            if (tid == 0) { f_nb = 0; f_nr = 0; }
-            if (tid < 64) fhist[tid] = 0u;
-            if (tid < NB) { fbest[tid] = 0ull; fsecond[tid] = 0ull; }
-            if (slot) {
-                const int l = (int)ulist[ownu[kb]] >> lgG;
-                const float x1 = ox[l], y1 = oy[l], z1 = oz[l];
-                float R = r_first;
-                if (!first) {
-                    const unsigned m = mem[l];
-                    const float v1 = emd_value(t4[m & 0xffffu], x1, y1, z1), v2 = emd_value(t4[m >> 16], x1, y1, z1);
-                    R = (3.0f - fminf(v1, v2)) + slack;
-                }
-                if (!(R < 1e30f)) R = __builtin_inff();
-                const int cy0 = emd_cell3(y1 - R, grid.mn[1], grid.sc[1]), cy1 = emd_cell3(y1 + R, grid.mn[1], grid.sc[1]);
-                const int cz0 = emd_cell3(z1 - R, grid.mn[2], grid.sc[2]), cz1 = emd_cell3(z1 + R, grid.mn[2], grid.sc[2]);
-                const int ny = cy1 - cy0 + 1;
-                nrows = ny * (cz1 - cz0 + 1);
-                fxyzr[tid] = make_float4(x1, y1, z1, R);
-                fbox[tid] = (unsigned short)(cy0 | (cz0 << 3) | ((ny - 1) << 6));
+        // -- B: the rows' chords, EMD_THREADS lanes over NR rows in runs of `rpl` consecutive ones (one search for the
+        //       slot per lane, then steps); histogram of the counts
+        unsigned ent[EMD_FLAT_RPL];
+        int tr_nc = 0;
+        {
+            const int rpl = (NR + EMD_THREADS - 1) / EMD_THREADS;
+            int f = tid * rpl, lo = 0, ry = 0, rz = 0, ny = 1, cy0 = 0, cz0 = 0, nxt = 0;
+            float4 bd = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (f < NR) {
+                int hi = nb;
+                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int)frow[mid] <= f) lo = mid; else hi = mid; }
+                const int r = f - (int)frow[lo], box = fbox[lo];
+                ny = ((box >> 6) & 7) + 1; cy0 = box & 7; cz0 = (box >> 3) & 7;
+                rz = (int)(((float)r + 0.5f) * __builtin_amdgcn_rcpf((float)ny)); ry = r - rz * ny;   // r + 0.5 is >= 1/16 from a multiple of ny
+                nxt = frow[lo + 1];
+                bd = fxyzr[lo];
             }
-            const int incl = emd_wave_scan_incl(nrows);
-            if (lane == 63) wtot[wave] = (unsigned)incl;
-            __syncthreads();
-            if (tid < NB) {
-                int before = 0;
-                for (int w = 0; w < wave; ++w) before += (int)wtot[w];
-                const int end = before + incl;
-                frow[tid] = (unsigned short)min(end - nrows, 0xffff);      // lanes past the last bidder: the total (the end of the last slot)
-                if (tid == NB - 1) frow[NB] = (unsigned short)min(end, 0xffff);
-                const bool fits = slot && end <= EMD_FLAT_ROWS;      // a prefix of the slots: the batch
-                const unsigned long long bal = __builtin_amdgcn_ballot_w64(fits);
-                if (bal && lane == 63 - __builtin_clzll(bal)) { atomicAdd(&f_nb, __builtin_popcountll(bal)); atomicMax(&f_nr, end); }
-            }
-            __syncthreads();
-            nb = f_nb; NR = f_nr;
-            if (nb <= 0) break;                              // cannot happen (a bidder has at most 64 rows); never spin on it: the partners' bounded wait reports the sample
-            if (first && nb < Uown) return -1;               // the first round in one batch or not at all (nothing has been bid yet)
-#ifdef EMD_TRACE
-            if (ftrace) { ftrace[0] = (unsigned)__builtin_amdgcn_s_memrealtime(); ftrace[3] = (k0 == 0 ? 0u : ftrace[3]) + 0x1000000u; }
+#ifdef EMD_TRACE_B2
+            if (ftrace) ftrace[0] = (unsigned)__builtin_amdgcn_s_memrealtime();     // experiment: A column = up to the end of wave 0's slot search
 #endif
-            // -- B: the rows' chords, EMD_THREADS lanes over NR rows in runs of `rpl` consecutive ones (one search for the
-            //       slot per lane, then steps); histogram of the counts
-            unsigned ent[EMD_FLAT_RPL];
-            int tr_nc = 0;
-            {
-                const int rpl = (NR + EMD_THREADS - 1) / EMD_THREADS;
-                int f = tid * rpl, lo = 0, ry = 0, rz = 0, ny = 1, cy0 = 0, cz0 = 0, nxt = 0;
-                float4 bd = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (f < NR) {
-                    int hi = nb;
-                    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int)frow[mid] <= f) lo = mid; else hi = mid; }
-                    const int r = f - (int)frow[lo], box = fbox[lo];
-                    ny = ((box >> 6) & 7) + 1; cy0 = box & 7; cz0 = (box >> 3) & 7;
-                    rz = (int)(((float)r + 0.5f) * __builtin_amdgcn_rcpf((float)ny)); ry = r - rz * ny;   // r + 0.5 is >= 1/16 from a multiple of ny
+#pragma unroll
+            for (int j = 0; j < EMD_FLAT_RPL; ++j, ++f) {
+                ent[j] = 0u;
+                if (j >= rpl || f >= NR) continue;
+                if (f == nxt) {                                  // the next slot's first row (every slot has rows)
+                    ++lo;
+                    const int box = fbox[lo];
+                    ny = ((box >> 6) & 7) + 1; cy0 = box & 7; cz0 = (box >> 3) & 7; ry = 0; rz = 0;
                     nxt = frow[lo + 1];
                     bd = fxyzr[lo];
                 }
-#ifdef EMD_TRACE_B2
-                if (ftrace) ftrace[0] = (unsigned)__builtin_amdgcn_s_memrealtime();     // experiment: A column = up to the end of wave 0's slot search
-#endif
-#pragma unroll
-                for (int j = 0; j < EMD_FLAT_RPL; ++j, ++f) {
-                    ent[j] = 0u;
-                    if (j >= rpl || f >= NR) continue;
-                    if (f == nxt) {                                  // the next slot's first row (every slot has rows)
-                        ++lo;
-                        const int box = fbox[lo];
-                        ny = ((box >> 6) & 7) + 1; cy0 = box & 7; cz0 = (box >> 3) & 7; ry = 0; rz = 0;
-                        nxt = frow[lo + 1];
-                        bd = fxyzr[lo];
-                    }
-                    int kst, cnt;
-                    emd_row_chord(bd.x, bd.y, bd.z, bd.w * bd.w, cy0 + ry, cz0 + rz, grid, cell_start, kst, cnt);
-                    if (++ry == ny) { ry = 0; ++rz; }
-                    if (cnt > 0) {
-                        ent[j] = (unsigned)kst | ((unsigned)cnt << 11) | ((unsigned)lo << 23);
-                        atomicAdd(&fhist[min(cnt, 63)], 1u);
-                        tr_nc += cnt;
-                    }
+                int kst, cnt;
+                emd_row_chord(bd.x, bd.y, bd.z, bd.w * bd.w, cy0 + ry, cz0 + rz, grid, cell_start, kst, cnt);
+                if (++ry == ny) { ry = 0; ++rz; }
+                if (cnt > 0) {
+                    ent[j] = (unsigned)kst | ((unsigned)cnt << 11) | ((unsigned)lo << 23);
+                    atomicAdd(&fhist[min(cnt, 63)], 1u);
+                    tr_nc += cnt;
                 }
             }
-#ifdef EMD_TRACE_B2
-            if (ftrace) ftrace[1] = (unsigned)__builtin_amdgcn_s_memrealtime();         // experiment: B column = wave 0's rows (no barrier)
-#endif
-            { const int t = emd_wave_scan_incl(tr_nc); if (lane == 63 && t) atomicAdd(&f_nc, (unsigned)t); }
-            __syncthreads();
-#ifdef EMD_TRACE_B
-            if (ftrace) ftrace[0] = (unsigned)__builtin_amdgcn_s_memrealtime();     // experiment: A column = up to the end of B's chords
-#endif
-            if (wave == 0) {                                 // longest rows first
-                const int h = (int)fhist[63 - lane];
-                const int in = emd_wave_scan_incl(h);
-                fcur[63 - lane] = (unsigned)(in - h);
-                if (lane == 63) f_nz = in;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < EMD_FLAT_RPL; ++j)
-                if (ent[j]) fsorted[atomicAdd(&fcur[min((int)((ent[j] >> 11) & 4095u), 63)], 1u)] = ent[j];
-            __syncthreads();
-            NZ = f_nz; NL = (int)fhist[63];
         }
-        last_rows = (k0 == 0 ? 0 : last_rows) + NZ;
+#ifdef EMD_TRACE_B2
+        if (ftrace) ftrace[1] = (unsigned)__builtin_amdgcn_s_memrealtime();         // experiment: B column = wave 0's rows (no barrier)
+#endif
+        { const int t = emd_wave_scan_incl(tr_nc); if (lane == 63 && t) atomicAdd(&f_nc, (unsigned)t); }
+        __syncthreads();
+#ifdef EMD_TRACE_B
+        if (ftrace) ftrace[0] = (unsigned)__builtin_amdgcn_s_memrealtime();     // experiment: A column = up to the end of B's chords
+#endif
+        if (wave == 0) {                                 // longest rows first
+            const int h = (int)fhist[63 - lane];
+            const int in = emd_wave_scan_incl(h);
+            fcur[63 - lane] = (unsigned)(in - h);
+            if (lane == 63) f_nz = in;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < EMD_FLAT_RPL; ++j)
+            if (ent[j]) fsorted[atomicAdd(&fcur[min((int)((ent[j] >> 11) & 4095u), 63)], 1u)] = ent[j];
+        __syncthreads();
         // -- C: the rows, dealt back and forth over the lanes
+        const int NZ = f_nz;
 #ifdef EMD_TRACE
 #ifndef EMD_TRACE_B2
         if (ftrace) ftrace[1] = (unsigned)__builtin_amdgcn_s_memrealtime();
@@ -1145,6 +1089,7 @@ __device__ __forceinline__ int emd_flat_bid(int npad, int lgG, int Uown, int n, 
         };
         // rows of 63 targets and more (the last bin: the head of the list) are not a lane's job -- a cloud that sits on
         // surfaces puts hundreds of targets into one row of cells: a WAVE takes each, its lanes striding through it
+        const int NL = (int)fhist[63];
         for (int r = wave; r < NL; r += EMD_WAVES) {
             const unsigned e = fsorted[r];
             const int kst = (int)(e & 2047u), sl = (int)(e >> 23);
@@ -1216,7 +1161,7 @@ __device__ __forceinline__ int emd_flat_bid(int npad, int lgG, int Uown, int n, 
         __syncthreads();                                 // the list of the bidders left over is complete
         return f_left;
     }
-    if (tid == 0) { emd3_flat_tpb = (float)f_nc / (float)Uown; emd3_flat_rows = last_rows; emd3_flat_nc = (int)f_nc; }   // (every batch's B phase, hence its f_nc, lies before a barrier)
+    if (tid == 0) emd3_flat_tpb = (float)f_nc / (float)Uown;     // (every batch's B phase, hence its f_nc, lies before a barrier)
     return 0;
 }
 
@@ -1355,7 +1300,7 @@ __global__ __launch_bounds__(EMD_THREADS, 4) void emd_auction_team_kernel(const 
     EmdGrid3& grid = emd3_grid;
     unsigned* const wtot = emd3_wtot;
     __shared__ int gave_up;
-    if (threadIdx.x == 0) { gave_up = 0; emd3_flat_off = 0; emd3_flat_tpb = 1.0e9f; emd3_flat_rows = emd3_flat_nc = 1 << 30; }
+    if (threadIdx.x == 0) { gave_up = 0; emd3_flat_off = 0; emd3_flat_tpb = 1.0e9f; }
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
     const int b = (q / G) * 8 + xcd, g = q % G;
     if (b >= B) return;
